@@ -1,0 +1,149 @@
+/*
+ * lob.h -- C ABI of the MI355X-native LSTM-ODE inner loop ("lob" = LSTM-ODE-BCI).
+ *
+ * The reference (khurrameycon/LSTM-ODE-BCI) is 100 % Python and has no FFI layer:
+ * its boundary for this path is three Python classes.  This header
+ * is the build-defined C ABI underneath those classes; every entry point cites the
+ * reference lines whose arithmetic it replaces (paths relative to the reference
+ * repository root).
+ *
+ * Conventions
+ *   - every pointer is a caller-owned DEVICE buffer (hipMalloc / torch allocator);
+ *   - `stream` is a hipStream_t passed as void*; nothing synchronises, nothing
+ *     allocates, no global mutable state;
+ *   - return value: 0 = ok; < 0 = argument error (LOB_E_*); > 0 = hipError_t of the
+ *     launch.  Functions never throw and never exit.
+ *   - internal activation layout is TIME-MAJOR: row index = t * Bp + b, where Bp is
+ *     the batch padded to a multiple of 32 (pad rows hold finite garbage/zeros and
+ *     are never read back by the caller).
+ */
+#ifndef LOB_H_
+#define LOB_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LOB_VERSION 100
+
+#define LOB_E_ARG   (-1)   /* null pointer / non-positive size                      */
+#define LOB_E_SHAPE (-2)   /* shape not supported by this kernel (see each entry)   */
+#define LOB_E_ALIGN (-3)   /* pointer / leading dimension alignment                 */
+
+#define LOB_ACT_NONE 0
+#define LOB_ACT_TANH 1     /* nn.Tanh  (04_lstm_model.py:119)                        */
+#define LOB_ACT_GELU 2     /* nn.GELU, exact erf form (04_lstm_model.py:176,198,201) */
+
+int lob_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * Dense layers.  C[M,N] = act(A[M,K] * W[N,K]^T + bias[N]); fp32 in, exact-fp32 MFMA
+ * (v_mfma_f32_32x32x2_f32), fp32 out.  A row-major with leading dimension lda, W is
+ * the torch nn.Linear weight (N,K) row-major with leading dimension ldw, bias may be
+ * NULL.  Replaces nn.Linear of input_proj (04_lstm_model.py:174), of the attention
+ * score MLP (04:118) and of the classifier (04:197,200,203).
+ * ---------------------------------------------------------------------------------- */
+int lob_gemm_nt_f32(const float* A, int lda, const float* W, int ldw, const float* bias,
+                    float* C, int ldc, int M, int N, int K, int act, void* stream);
+
+/* C[M,N] (+)= A[Kc,M]^T * B[Kc,N]  (contraction over the leading/row index; weight
+ * gradients dW = dY^T X).  Split over Kc across workgroups, fp32 atomics into C, so C
+ * must be zeroed (or hold the value to accumulate into) before the call.             */
+int lob_gemm_tn_f32(const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                    int M, int N, int Kc, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Input-side gate GEMM of one LSTM layer, both directions at once:
+ *   P = X[T*Bp, K] * Wih[D*4H, K]^T + bias[D*4H]       (bias = b_ih + b_hh)
+ * nn.LSTM call site 04_lstm_model.py:181-188, 211 (W_ih x_t + b_ih + b_hh of the cell).
+ * frag = 1: P is written in the accumulator-fragment order the persistent recurrent
+ *   kernel consumes, [D][T][Bp/32][H/32][4 gates][4][64 lanes][4] floats (requires
+ *   H % 32 == 0, Bp % 32 == 0);  frag = 0: P is row-major (T*Bp, D*4H).
+ * ---------------------------------------------------------------------------------- */
+int lob_gate_gemm_x_f32(const float* X, int ldx, const float* Wih, const float* bias,
+                        float* P, int T, int Bp, int H, int D, int K, int frag,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Recurrent part of one LSTM layer, all T steps inside one persistent kernel, both
+ * directions (grid = batch tiles x D):
+ *   z = P_t + W_hh h_{t-1};  i,f,g,o = split(z);  c = s(f) c + s(i) tanh(g);
+ *   h = s(o) tanh(c);   h_-1 = c_-1 = 0;  the reverse direction walks t = T-1..0.
+ * (torch nn.LSTM semantics; call site 04_lstm_model.py:211.)
+ *   P     gate pre-activations from lob_gate_gemm_x_f32 (frag=1 iff H == 128)
+ *   Whh   [D][4H][H]   (weight_hh_l{k}, weight_hh_l{k}_reverse stacked)
+ *   Y     [T][Bp][D*H] layer output, direction d in columns [d*H, (d+1)*H)
+ *   save  0: inference.  1: training -- P is overwritten in place with the ACTIVATED
+ *         gates (same layout) and Csave receives c_t ([D][T][Bp][H], fragment order
+ *         when frag) for the backward kernel.
+ * ---------------------------------------------------------------------------------- */
+int lob_lstm_rec_fwd_f32(float* P, const float* Whh, float* Y, float* Csave,
+                         int T, int Bp, int H, int D, int save, void* stream);
+
+/* Backward of the above (BPTT), one persistent kernel:
+ *   G     activated gates saved by the forward (in place of P); overwritten... no:
+ *   dP    [T*Bp][D*4H] row-major gradient w.r.t. the gate pre-activations (output)
+ *   dY    [T][Bp][D*H] gradient w.r.t. the layer output (input)
+ * dW_hh, dW_ih, db and dX follow from dP by lob_gemm_tn_f32 / lob_gemm_nt_f32.      */
+int lob_lstm_rec_bwd_f32(const float* G, const float* Csave, const float* Whh,
+                         const float* dY, float* dP, int T, int Bp, int H, int D,
+                         void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Row-wise LayerNorm (biased variance, eps) with affine, optional GELU, optional
+ * dropout, optional (b,t)->(t,b) row remap.  out[row'] = drop(act(LN(in[row]))).
+ *   remap_T > 0: in rows are ordered (b, t) with t < remap_T; out row = t*Bp + b.
+ *   remap_T = 0: out row = in row.
+ * nn.LayerNorm + nn.GELU + nn.Dropout of input_proj (04_lstm_model.py:175-177) and
+ * the post-LSTM nn.LayerNorm (04:192, 212).
+ * ---------------------------------------------------------------------------------- */
+int lob_layernorm_act_f32(const float* in, const float* gamma, const float* beta,
+                          float* out, int rows, int width, float eps, int act,
+                          int remap_T, int remap_B, int remap_Bp,
+                          float drop_p, uint64_t seed, void* stream);
+
+/* nn.Dropout (04_lstm_model.py:177,186,199,202): out[i] = in[i] * keep_i / (1-p), where
+ * keep_i is a counter-based hash of (seed, i): the backward pass applies the same call to the
+ * gradient with the same seed instead of storing a mask.  in == out is allowed.           */
+int lob_dropout_f32(const float* in, float* out, int64_t n, float p, uint64_t seed, void* stream);
+
+/* Additive attention pooling over time (Attention.forward, 04_lstm_model.py:123-128):
+ *   s[t,b] = U[t*Bp+b,:] . w2 + b2   (U = tanh(W1 v + b1), computed by lob_gemm_nt_f32)
+ *   a[b,:] = softmax_t(s[:,b]);   ctx[b,:] = sum_t a[b,t] * V[t*Bp+b,:]
+ *   V [T*Bp][W], U [T*Bp][W2], attn [B][T], ctx [B][W].                              */
+int lob_attn_pool_fwd_f32(const float* V, const float* U, const float* w2, const float* b2,
+                          float* ctx, float* attn, int T, int B, int Bp, int W, int W2,
+                          void* stream);
+
+/* Row softmax over `cols` (torch.softmax(logits, dim=1), 06_lstm_ode_integration.py:232). */
+int lob_softmax_rows_f32(const float* in, float* out, int rows, int cols, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Coupled LSTM -> ODE step 2 of predict_batch (06_lstm_ode_integration.py:372-401), one
+ * window per lane, fp64 arithmetic:
+ *   p_open = probs[b][0], p_closed = probs[b][1]                          (06:373-374)
+ *   y0 = [.2,.2,.6] if p_closed > .6 else [.6,.2,.2] if p_open > .6 else [.33,.34,.33]
+ *        then y0 /= sum(y0)                                    (06:377-382, 06:176)
+ *   k_af,k_pf *= 1 + alpha p_closed; k_fa,k_pa *= 1 + alpha p_open; all six max(.001,.)
+ *                                                                         (06:249-264)
+ *   t = linspace(t0, t1, n_points); fixed-step RK4 of dy/dt = Q^T max(y,0) with
+ *   `substeps` sub-steps per output interval (the reference calls LSODA)
+ *                                                              (06:158-172, 06:177)
+ *   traj = clip(traj,0,1); traj /= rowsum                                (06:178-179)
+ *   pred = traj[-1][2] > 0.5                                             (06:396-401)
+ * probs == NULL: un-modulated mode -- y0 is read from `y0_in` ([B][3] f64), rates are
+ * base_rates for every window (CognitiveStateODE.solve, 06:174-180 / 05:137-169).
+ * traj [B][n_points][3] f64 (may be NULL: only final/pred are written),
+ * final_state [B][3] f64 (may be NULL), pred [B] int64 (may be NULL).
+ * base_rates: HOST pointer to 6 doubles in the order k_ap,k_af,k_pa,k_pf,k_fa,k_fp.
+ * ---------------------------------------------------------------------------------- */
+int lob_ode_rk4_f64(const float* probs, const double* y0_in, const double* base_rates,
+                    double alpha, int n_points, double t0, double t1, int substeps,
+                    double* traj, double* final_state, int64_t* pred, int B, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LOB_H_ */

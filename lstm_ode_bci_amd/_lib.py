@@ -1,0 +1,64 @@
+"""ctypes binding of liblob.so (include/lob.h).  Fails loudly when the library is absent:
+there is no CPU fallback anywhere in the product path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "liblob.so")
+
+_lib = None
+
+_f32p = C.c_void_p
+_SIGS = {
+    "lob_version": ([], C.c_int),
+    "lob_gemm_nt_f32": ([_f32p, C.c_int, _f32p, C.c_int, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int,
+                         C.c_int, C.c_void_p], C.c_int),
+    "lob_gemm_tn_f32": ([_f32p, C.c_int, _f32p, C.c_int, _f32p, C.c_int, C.c_int, C.c_int, C.c_int,
+                         C.c_void_p], C.c_int),
+    "lob_gate_gemm_x_f32": ([_f32p, C.c_int, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                             C.c_int, C.c_void_p], C.c_int),
+    "lob_lstm_rec_fwd_f32": ([_f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                              C.c_void_p], C.c_int),
+    "lob_layernorm_act_f32": ([_f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int,
+                               C.c_int, C.c_float, C.c_uint64, C.c_void_p], C.c_int),
+    "lob_dropout_f32": ([_f32p, _f32p, C.c_int64, C.c_float, C.c_uint64, C.c_void_p], C.c_int),
+    "lob_attn_pool_fwd_f32": ([_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int,
+                               C.c_int, C.c_void_p], C.c_int),
+    "lob_softmax_rows_f32": ([_f32p, _f32p, C.c_int, C.c_int, C.c_void_p], C.c_int),
+    "lob_ode_rk4_f64": ([_f32p, C.c_void_p, C.POINTER(C.c_double), C.c_double, C.c_int, C.c_double, C.c_double,
+                         C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p], C.c_int),
+}
+
+
+class LobError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library; raises if liblob.so has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LobError(
+                f"{LIB_PATH} not found: the HIP extension is not built. "
+                "Run `python -m lstm_ode_bci_amd.build` (needs hipcc). There is no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (args, res) in _SIGS.items():
+            if not hasattr(l, name):
+                continue          # declared in lob.h but not built yet -> caught by tests/test_abi.py
+            fn = getattr(l, name)
+            fn.argtypes = args
+            fn.restype = res
+        _lib = l
+    return _lib
+
+
+_ERR = {-1: "LOB_E_ARG (null pointer / bad size)", -2: "LOB_E_SHAPE (unsupported shape)",
+        -3: "LOB_E_ALIGN (pointer / leading dimension alignment)"}
+
+
+def check(rc, what):
+    if rc != 0:
+        raise LobError(f"{what} failed: {_ERR.get(rc, f'hipError_t {rc}')}")

@@ -1,0 +1,130 @@
+"""Forward / backward pipelines of the drop-in model as ONE autograd node.
+
+The whole of ``EnhancedLSTMModel.forward`` (04_lstm_model.py:206-222) is a single
+``torch.autograd.Function``: forward launches the HIP kernels in order on the current
+stream and keeps what BPTT needs; backward launches the mirrored kernels and hands torch
+one gradient per parameter plus the input gradient (07_explainability.py:242-257 needs
+d logits / d x).  Saved activations are never modified by backward, so
+``backward(retain_graph=True)`` can be called repeatedly (07:254).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .ops import ACT_GELU, ACT_NONE, ACT_TANH, ceil32
+
+
+def _collect(model):
+    ps = [model.input_proj[0].weight, model.input_proj[0].bias,
+          model.input_proj[1].weight, model.input_proj[1].bias]
+    for layer in range(model.num_layers):
+        for tup in model.lstm.layer_params(layer):
+            ps.extend(tup)
+    ps += [model.layer_norm.weight, model.layer_norm.bias,
+           model.attention.attention[0].weight, model.attention.attention[0].bias,
+           model.attention.attention[2].weight, model.attention.attention[2].bias,
+           model.classifier[0].weight, model.classifier[0].bias,
+           model.classifier[3].weight, model.classifier[3].bias,
+           model.classifier[6].weight, model.classifier[6].bias]
+    return ps
+
+
+def _f32c(t):
+    t = t.detach()
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _seed(seed, k):
+    return (seed * 1000003 + k * 7919 + 12345) & ((1 << 63) - 1)
+
+
+def _forward_impl(x, ps, cfg, save):
+    """Returns (logits, attn, saved-dict or None)."""
+    L, D, H, (p_in, p_lstm, p_cls), seed = cfg
+    B, T, C = x.shape
+    Bp = ceil32(B)
+    W = H * D
+    frag = (H == 128)
+    x2d = x.reshape(B * T, C)
+    it = iter(ps)
+    proj_w, proj_b, ln0_g, ln0_b = next(it), next(it), next(it), next(it)
+    sv = {} if save else None
+
+    pre = ops.gemm_nt(x2d, proj_w, proj_b)                                   # (B*T, H), rows (b,t)
+    a = ops.layernorm_act(pre, ln0_g, ln0_b, act=ACT_GELU, remap=(T, B, Bp),
+                          drop_p=p_in, seed=_seed(seed, 0))                  # (T*Bp, H) time-major
+    if save:
+        sv["x2d"], sv["pre"], sv["a"] = x2d, pre, a
+        sv["layers"] = []
+    inp = a
+    for layer in range(L):
+        dirs = [(next(it), next(it), next(it), next(it)) for _ in range(D)]
+        wih = torch.cat([d[0] for d in dirs], 0) if D > 1 else dirs[0][0]
+        whh = torch.stack([d[1] for d in dirs], 0)
+        bias = torch.cat([d[2] + d[3] for d in dirs], 0)
+        P = ops.gate_gemm_x(inp, wih, bias, T, Bp, H, D, frag)
+        Y, Cs = ops.lstm_rec_fwd(P, whh, T, Bp, H, D, save)
+        nxt = Y
+        if layer + 1 < L and p_lstm > 0:
+            nxt = ops.dropout(Y, p_lstm, _seed(seed, 10 + layer))
+        if save:
+            sv["layers"].append({"inp": inp, "G": P, "C": Cs, "Y": Y, "wih": wih, "whh": whh})
+        inp = nxt
+    ln_g, ln_b = next(it), next(it)
+    a0w, a0b, a2w, a2b = next(it), next(it), next(it), next(it)
+    c0w, c0b, c3w, c3b, c6w, c6b = (next(it) for _ in range(6))
+    v = ops.layernorm_act(inp, ln_g, ln_b)                                   # (T*Bp, W)
+    u = ops.gemm_nt(v, a0w, a0b, act=ACT_TANH)                               # (T*Bp, W/2)
+    ctx, attn = ops.attn_pool_fwd(v, u, a2w.reshape(-1), a2b, T, B, Bp)
+    z1 = ops.gemm_nt(ctx, c0w, c0b, act=ACT_GELU)
+    z1d = ops.dropout(z1, p_cls, _seed(seed, 20)) if p_cls > 0 else z1
+    z2 = ops.gemm_nt(z1d, c3w, c3b, act=ACT_GELU)
+    z2d = ops.dropout(z2, p_cls, _seed(seed, 21)) if p_cls > 0 else z2
+    logits = ops.gemm_nt(z2d, c6w, c6b)
+    if save:
+        sv.update(ylast=inp, v=v, u=u, ctx=ctx, attn=attn, z1=z1, z1d=z1d, z2=z2, z2d=z2d)
+    return logits, attn, sv
+
+
+class _LobModelFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, cfg, *params):
+        ps = [_f32c(p) for p in params]
+        xf = _f32c(x)
+        need_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+        logits, attn, sv = _forward_impl(xf, ps, cfg, save=need_grad)
+        ctx.cfg = cfg
+        ctx.sv = sv
+        ctx.ps = ps if need_grad else None
+        ctx.x_shape = tuple(x.shape)
+        ctx.mark_non_differentiable(attn)
+        return logits, attn
+
+    @staticmethod
+    def backward(ctx, dlogits, _dattn):
+        from .backward import backward_impl
+        gx, gps = backward_impl(ctx.sv, ctx.ps, ctx.cfg, ctx.x_shape, dlogits.contiguous().float(),
+                                ctx.needs_input_grad)
+        return (gx, None) + tuple(gps)
+
+
+def lob_forward(model, x, drops, seed):
+    if not x.is_cuda:
+        raise ops._lib.LobError("EnhancedLSTMModel.forward: input must be on the GPU "
+                                "(the MI355X path has no CPU fallback)")
+    cfg = (model.num_layers, model.num_directions, model.hidden_size, tuple(float(d) for d in drops), int(seed))
+    with torch.autocast(device_type="cuda", enabled=False):
+        return _LobModelFn.apply(x, cfg, *_collect(model))
+
+
+def attention_forward(lstm_output, w1, b1, w2, b2):
+    """Stand-alone Attention.forward on a batch-first (B,T,W) tensor (inference only)."""
+    if not lstm_output.is_cuda:
+        raise ops._lib.LobError("Attention.forward: input must be on the GPU")
+    B, T, W = lstm_output.shape
+    v = _f32c(lstm_output).transpose(0, 1).contiguous().reshape(T * B, W)
+    u = ops.gemm_nt(v, _f32c(w1), _f32c(b1), act=ACT_TANH)
+    return ops.attn_pool_fwd(v, u, _f32c(w2).reshape(-1), _f32c(b2), T, B, B)

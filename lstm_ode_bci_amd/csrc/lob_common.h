@@ -1,0 +1,70 @@
+// Shared device helpers for the lob kernels (gfx950 / CDNA4 only, wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "lob.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define LOB_CHECK_LAUNCH()                                   \
+    do {                                                     \
+        hipError_t e__ = hipGetLastError();                  \
+        if (e__ != hipSuccess) return (int)e__;              \
+    } while (0)
+
+// exact-f32 matrix core op: D(32x32) += A(32x2) * B(2x32); lane l feeds
+// A[l&31][l>>5] and B[l>>5][l&31]  (cdna_hip_programming.md §3).
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// Row of accumulator register r (0..15) inside a 32x32 tile for this lane:
+// row = (r&3) + 8*(r>>2) + 4*(lane>>5); column = lane & 31.
+__device__ __forceinline__ int acc_row(int r, int lane) {
+    return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+}
+
+// Activations.  v_exp_f32 / v_rcp_f32 are ~1 ulp; the absolute error of the results
+// (<= ~1.5e-7) is what the 1e-5 logit parity budget sees.
+__device__ __forceinline__ float fast_sigmoid(float x) {
+    return __frcp_rn(1.0f + __expf(-x));
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+    // 1 - 2/(1+e^{2x}): saturates cleanly to +-1, no inf/inf.
+    return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x));
+}
+__device__ __forceinline__ float gelu_erf(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float apply_act(float x, int act) {
+    if (act == LOB_ACT_TANH) return tanhf(x);
+    if (act == LOB_ACT_GELU) return gelu_erf(x);
+    return x;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Counter-based RNG for dropout masks: the keep/drop decision of element `idx` depends
+// only on (seed, idx), so the backward pass regenerates the mask instead of storing it.
+__device__ __forceinline__ uint32_t lob_hash32(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (uint32_t)(z >> 32);
+}
+__device__ __forceinline__ float lob_dropout_scale(uint64_t seed, uint64_t idx, float p) {
+    // returns 0 (dropped) or 1/(1-p) (kept); p in [0,1)
+    const uint32_t thr = (uint32_t)(p * 4294967296.0);
+    return lob_hash32(seed, idx) >= thr ? 1.0f / (1.0f - p) : 0.0f;
+}

@@ -1,0 +1,126 @@
+// Batched three-state (Active/Passive/Fatigued) compartmental ODE, one window per lane.
+//
+// dy/dt = Q^T max(y, 0), six rates, linear; fp64 fixed-step RK4 with `substeps` sub-steps
+// per output interval.  Write-bandwidth bound: 24 B per window per output point (fp64
+// trajectory, the dtype the reference returns).  Each 64-lane wave stages CH output points
+// per window in LDS and writes them out as 24*CH-byte contiguous runs per window instead
+// of 64 scattered 24-B stores per step.
+#include "lob_common.h"
+
+namespace {
+
+constexpr int CH = 16;   // output points staged per window before a coalesced flush
+
+struct OdeArgs {
+    const float* probs; const double* y0_in;
+    double k_ap, k_af, k_pa, k_pf, k_fa, k_fp, alpha;
+    int n_points, substeps; double t0, t1;
+    double* traj; double* final_state; int64_t* pred; int B;
+};
+
+__device__ __forceinline__ void rhs(const double (&k)[6], double a, double p, double f,
+                                    double& da, double& dp, double& df) {
+    a = fmax(a, 0.0); p = fmax(p, 0.0); f = fmax(f, 0.0);
+    // k = {k_ap, k_af, k_pa, k_pf, k_fa, k_fp}; same operation order as the reference rhs
+    da = -k[0] * a - k[1] * a + k[2] * p + k[4] * f;
+    dp = k[0] * a - k[2] * p - k[3] * p + k[5] * f;
+    df = k[1] * a + k[3] * p - k[4] * f - k[5] * f;
+}
+
+__device__ __forceinline__ void post(double a, double p, double f, double (&o)[3]) {
+    a = fmin(fmax(a, 0.0), 1.0); p = fmin(fmax(p, 0.0), 1.0); f = fmin(fmax(f, 0.0), 1.0);
+    const double s = a + p + f;
+    o[0] = a / s; o[1] = p / s; o[2] = f / s;
+}
+
+__global__ __launch_bounds__(64) void ode_rk4_kernel(OdeArgs g) {
+    __shared__ double stage[64 * CH * 3];
+    const int lane = threadIdx.x;
+    const int b0 = blockIdx.x * 64;
+    const int b = b0 + lane;
+    const bool live = b < g.B;
+
+    double k[6] = {g.k_ap, g.k_af, g.k_pa, g.k_pf, g.k_fa, g.k_fp};
+    double a = 1.0 / 3, p = 1.0 / 3, f = 1.0 / 3;
+    if (live) {
+        if (g.probs) {
+            const float po32 = g.probs[2 * (size_t)b + 0], pc32 = g.probs[2 * (size_t)b + 1];
+            const double p_open = (double)po32, p_closed = (double)pc32;
+            // strict '>' on the float32 probabilities (np.float32 > 0.6 compares in float32
+            // under NumPy >= 2; differs from the float64 compare only at p == float32(0.6))
+            if (pc32 > 0.6f) { a = 0.2; p = 0.2; f = 0.6; }
+            else if (po32 > 0.6f) { a = 0.6; p = 0.2; f = 0.2; }
+            else { a = 0.33; p = 0.34; f = 0.33; }
+            k[1] = k[1] * (1.0 + g.alpha * p_closed);
+            k[3] = k[3] * (1.0 + g.alpha * p_closed);
+            k[4] = k[4] * (1.0 + g.alpha * p_open);
+            k[2] = k[2] * (1.0 + g.alpha * p_open);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) k[i] = fmax(0.001, k[i]);
+        } else {
+            a = g.y0_in[3 * (size_t)b + 0]; p = g.y0_in[3 * (size_t)b + 1]; f = g.y0_in[3 * (size_t)b + 2];
+        }
+        const double s = a + p + f;
+        a /= s; p /= s; f /= s;
+    }
+    const int n = g.n_points;
+    const double h = n > 1 ? (g.t1 - g.t0) / (double)(n - 1) / (double)g.substeps : 0.0;
+    double o[3];
+
+    for (int s0 = 0; s0 < n; s0 += CH) {
+        const int cnt = min(CH, n - s0);
+        for (int j = 0; j < cnt; ++j) {
+            if (s0 + j > 0) {
+                for (int ss = 0; ss < g.substeps; ++ss) {
+                    double k1a, k1p, k1f, k2a, k2p, k2f, k3a, k3p, k3f, k4a, k4p, k4f;
+                    rhs(k, a, p, f, k1a, k1p, k1f);
+                    rhs(k, a + 0.5 * h * k1a, p + 0.5 * h * k1p, f + 0.5 * h * k1f, k2a, k2p, k2f);
+                    rhs(k, a + 0.5 * h * k2a, p + 0.5 * h * k2p, f + 0.5 * h * k2f, k3a, k3p, k3f);
+                    rhs(k, a + h * k3a, p + h * k3p, f + h * k3f, k4a, k4p, k4f);
+                    a += h / 6.0 * (k1a + 2.0 * k2a + 2.0 * k3a + k4a);
+                    p += h / 6.0 * (k1p + 2.0 * k2p + 2.0 * k3p + k4p);
+                    f += h / 6.0 * (k1f + 2.0 * k2f + 2.0 * k3f + k4f);
+                }
+            }
+            if (g.traj) {
+                post(a, p, f, o);
+                double* st = stage + (lane * CH + j) * 3;
+                st[0] = o[0]; st[1] = o[1]; st[2] = o[2];
+            }
+        }
+        if (g.traj) {
+            __syncthreads();
+            const int per = cnt * 3;                       // doubles per window in this chunk
+            const int total = 64 * per;
+            for (int e = lane; e < total; e += 64) {
+                const int w = e / per, j = e - w * per;
+                if (b0 + w < g.B)
+                    g.traj[((size_t)(b0 + w) * n + s0) * 3 + j] = stage[w * CH * 3 + j];
+            }
+            __syncthreads();
+        }
+    }
+    if (live) {
+        post(a, p, f, o);
+        if (g.final_state) {
+            g.final_state[3 * (size_t)b + 0] = o[0]; g.final_state[3 * (size_t)b + 1] = o[1];
+            g.final_state[3 * (size_t)b + 2] = o[2];
+        }
+        if (g.pred) g.pred[b] = o[2] > 0.5 ? 1 : 0;
+    }
+}
+
+}  // namespace
+
+extern "C" int lob_ode_rk4_f64(const float* probs, const double* y0_in, const double* base_rates,
+                               double alpha, int n_points, double t0, double t1, int substeps,
+                               double* traj, double* final_state, int64_t* pred, int B, void* stream) {
+    if (!base_rates || B <= 0 || n_points <= 0 || substeps <= 0) return LOB_E_ARG;
+    if (!probs && !y0_in) return LOB_E_ARG;
+    if (!traj && !final_state && !pred) return LOB_E_ARG;
+    OdeArgs g{probs, y0_in, base_rates[0], base_rates[1], base_rates[2], base_rates[3], base_rates[4],
+              base_rates[5], alpha, n_points, substeps, t0, t1, traj, final_state, pred, B};
+    hipLaunchKernelGGL(ode_rk4_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, g);
+    LOB_CHECK_LAUNCH();
+    return 0;
+}

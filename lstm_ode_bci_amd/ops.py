@@ -1,0 +1,154 @@
+"""Thin host wrappers: torch tensors in, C-ABI calls out (raw device pointers + the current
+HIP stream).  torch is plumbing here (allocator, streams); all arithmetic is in liblob.so."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_TANH, ACT_GELU = 0, 1, 2
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())
+
+
+def _chk(t, name, dtype=torch.float32):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise _lib.LobError(f"{name}: expected a device tensor (the product path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise _lib.LobError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _lib.LobError(f"{name}: expected a contiguous tensor")
+
+
+def ceil32(n):
+    return (n + 31) // 32 * 32
+
+
+def gemm_nt(a, w, bias=None, act=ACT_NONE, out=None):
+    """out[M,N] = act(a[M,K] @ w[N,K]^T + bias)."""
+    _chk(a, "a"); _chk(w, "w"); _chk(bias, "bias")
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=torch.float32)
+    _chk(out, "out")
+    rc = _lib.lib().lob_gemm_nt_f32(_ptr(a), K, _ptr(w), K, _ptr(bias), _ptr(out), N, M, N, K, act, _stream())
+    _lib.check(rc, "lob_gemm_nt_f32")
+    return out
+
+
+def gemm_tn(a, b, out):
+    """out[M,N] += a[Kc,M]^T @ b[Kc,N]; a, b may be column slices of wider row-major tensors."""
+    Kc, M = a.shape
+    N = b.shape[1]
+    assert b.shape[0] == Kc and a.stride(1) == 1 and b.stride(1) == 1
+    _chk(out, "out")
+    rc = _lib.lib().lob_gemm_tn_f32(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), out.stride(0),
+                                    M, N, Kc, _stream())
+    _lib.check(rc, "lob_gemm_tn_f32")
+    return out
+
+
+def gate_gemm_x(x, wih, bias, T, Bp, H, D, frag):
+    """P = x[T*Bp,K] @ wih[D*4H,K]^T + bias, fragment order when frag."""
+    _chk(x, "x"); _chk(wih, "wih"); _chk(bias, "bias")
+    K = x.shape[1]
+    assert x.shape[0] == T * Bp and wih.shape == (D * 4 * H, K)
+    P = torch.empty((T * Bp, D * 4 * H), device=x.device, dtype=torch.float32)
+    rc = _lib.lib().lob_gate_gemm_x_f32(_ptr(x), K, _ptr(wih), _ptr(bias), _ptr(P), T, Bp, H, D, K,
+                                        1 if frag else 0, _stream())
+    _lib.check(rc, "lob_gate_gemm_x_f32")
+    return P
+
+
+def lstm_rec_fwd(P, whh, T, Bp, H, D, save):
+    """Runs the persistent recurrent kernel; returns (Y[T*Bp, D*H], Csave or None)."""
+    _chk(P, "P"); _chk(whh, "whh")
+    assert whh.shape == (D, 4 * H, H)
+    Y = torch.empty((T * Bp, D * H), device=P.device, dtype=torch.float32)
+    Cs = torch.empty((D * T * Bp * H,), device=P.device, dtype=torch.float32) if save else None
+    rc = _lib.lib().lob_lstm_rec_fwd_f32(_ptr(P), _ptr(whh), _ptr(Y), _ptr(Cs), T, Bp, H, D,
+                                         1 if save else 0, _stream())
+    _lib.check(rc, "lob_lstm_rec_fwd_f32")
+    return Y, Cs
+
+
+def layernorm_act(x, gamma, beta, act=ACT_NONE, eps=1e-5, remap=None, drop_p=0.0, seed=0, out=None):
+    """LN(+act, +dropout) over the last axis of x[rows, width]; remap=(T, B, Bp) relays rows
+    (b,t) -> t*Bp + b (out must then have T*Bp rows; pad rows are left untouched)."""
+    _chk(x, "x"); _chk(gamma, "gamma"); _chk(beta, "beta")
+    rows, width = x.shape
+    if remap is None:
+        rT = rB = rBp = 0
+        if out is None:
+            out = torch.empty_like(x)
+    else:
+        rT, rB, rBp = remap
+        if out is None:
+            out = torch.zeros((rT * rBp, width), device=x.device, dtype=torch.float32) if rBp != rB else \
+                torch.empty((rT * rBp, width), device=x.device, dtype=torch.float32)
+    _chk(out, "out")
+    rc = _lib.lib().lob_layernorm_act_f32(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(out), rows, width, eps, act,
+                                          rT, rB, rBp, float(drop_p), C.c_uint64(seed), _stream())
+    _lib.check(rc, "lob_layernorm_act_f32")
+    return out
+
+
+def dropout(x, p, seed, out=None):
+    _chk(x, "x")
+    if out is None:
+        out = torch.empty_like(x)
+    rc = _lib.lib().lob_dropout_f32(_ptr(x), _ptr(out), x.numel(), float(p), C.c_uint64(seed), _stream())
+    _lib.check(rc, "lob_dropout_f32")
+    return out
+
+
+def attn_pool_fwd(v, u, w2, b2, T, B, Bp):
+    _chk(v, "v"); _chk(u, "u"); _chk(w2, "w2"); _chk(b2, "b2")
+    W, W2 = v.shape[1], u.shape[1]
+    ctx = torch.empty((B, W), device=v.device, dtype=torch.float32)
+    attn = torch.empty((B, T), device=v.device, dtype=torch.float32)
+    rc = _lib.lib().lob_attn_pool_fwd_f32(_ptr(v), _ptr(u), _ptr(w2), _ptr(b2), _ptr(ctx), _ptr(attn),
+                                          T, B, Bp, W, W2, _stream())
+    _lib.check(rc, "lob_attn_pool_fwd_f32")
+    return ctx, attn
+
+
+def softmax_rows(x):
+    _chk(x, "x")
+    out = torch.empty_like(x)
+    rc = _lib.lib().lob_softmax_rows_f32(_ptr(x), _ptr(out), x.shape[0], x.shape[1], _stream())
+    _lib.check(rc, "lob_softmax_rows_f32")
+    return out
+
+
+def ode_rk4(base_rates, n_points, t0, t1, substeps, *, probs=None, alpha=0.0, y0=None,
+            want_traj=True, want_final=False, want_pred=True):
+    """Batched ODE solve.  probs (B,2) f32 -> coupled mode; y0 (B,3) f64 -> plain solve."""
+    src = probs if probs is not None else y0
+    B = src.shape[0]
+    dev = src.device
+    if probs is not None:
+        _chk(probs, "probs")
+    else:
+        _chk(y0, "y0", torch.float64)
+    traj = torch.empty((B, n_points, 3), device=dev, dtype=torch.float64) if want_traj else None
+    final = torch.empty((B, 3), device=dev, dtype=torch.float64) if want_final else None
+    pred = torch.empty((B,), device=dev, dtype=torch.int64) if want_pred else None
+    rates = (C.c_double * 6)(*[float(r) for r in base_rates])
+    rc = _lib.lib().lob_ode_rk4_f64(_ptr(probs), _ptr(y0), rates, float(alpha), int(n_points), float(t0),
+                                    float(t1), int(substeps), _ptr(traj), _ptr(final), _ptr(pred), B, _stream())
+    _lib.check(rc, "lob_ode_rk4_f64")
+    return traj, final, pred

@@ -1,0 +1,271 @@
+"""GPU parity tests (run with ``-m gpu`` on an MI355X): the HIP path, called through the
+C-ABI of liblob.so, against the oracle and the committed golden fixtures.
+
+Tolerances (fp32 path; BASELINE.json configs[1]):
+  logits / attention / context     <= 1e-5 abs vs the reference goldens and the oracle
+  ODE trajectories (RK4, 16 sub)   <= 1e-6 abs vs the reference's LSODA output (budget 5e-6)
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from lstm_ode_bci_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from lstm_ode_bci_amd import _lib
+    assert _lib.lib().lob_version() >= 100
+    return torch.device("cuda:0")
+
+
+def _model(sd, C, H, L, bi, dev):
+    from lstm_ode_bci_amd import EnhancedLSTMModel
+    m = EnhancedLSTMModel(input_size=C, hidden_size=H, num_layers=L, num_classes=2, dropout=0.4,
+                          bidirectional=bi)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    return m.to(dev).eval()
+
+
+# ------------------------------------------------------------------------------------------
+# kernels one by one
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K,act", [(256, 128, 64, 0), (300, 130, 61, 2), (1000, 512, 256, 1),
+                                       (5, 2, 64, 0), (129, 257, 33, 0), (4096, 1024, 128, 0)])
+def test_gemm_nt(dev, M, N, K, act):
+    from lstm_ode_bci_amd import ops
+    rng = np.random.default_rng(M + N + K)
+    a = torch.from_numpy(rng.standard_normal((M, K), dtype=np.float32)).to(dev)
+    w = torch.from_numpy(rng.standard_normal((N, K), dtype=np.float32)).to(dev)
+    b = torch.from_numpy(rng.standard_normal((N,), dtype=np.float32)).to(dev)
+    out = ops.gemm_nt(a, w, b, act=act).cpu().double()
+    ref = a.cpu().double() @ w.cpu().double().T + b.cpu().double()
+    if act == 1:
+        ref = torch.tanh(ref)
+    elif act == 2:
+        ref = torch.nn.functional.gelu(ref)
+    assert (out - ref).abs().max().item() < 2e-5 * max(1.0, K ** 0.5)
+
+
+def test_gemm_identity_asymmetric(dev):
+    """A = I with an asymmetric W catches a transposed C write (cdna guide §3)."""
+    from lstm_ode_bci_amd import ops
+    n = 128
+    a = torch.eye(n, device=dev)
+    w = torch.arange(n * n, device=dev, dtype=torch.float32).reshape(n, n) / 7.0
+    out = ops.gemm_nt(a, w)
+    assert torch.equal(out, w.T.contiguous())
+
+
+def test_layernorm_remap_and_gelu(dev):
+    from lstm_ode_bci_amd import ops
+    from oracle import restatement as R
+    rng = np.random.default_rng(3)
+    B, T, Wd = 5, 7, 128
+    x = rng.standard_normal((B * T, Wd), dtype=np.float32) * 3 + 1
+    g = rng.standard_normal(Wd).astype(np.float32)
+    b = rng.standard_normal(Wd).astype(np.float32)
+    Bp = 32
+    out = ops.layernorm_act(torch.from_numpy(x).to(dev), torch.from_numpy(g).to(dev), torch.from_numpy(b).to(dev),
+                            act=ops.ACT_GELU, remap=(T, B, Bp)).cpu().numpy().reshape(T, Bp, Wd)
+    ref = R.gelu_erf(R.layer_norm(x.astype(np.float64), g, b)).reshape(B, T, Wd).transpose(1, 0, 2)
+    assert np.abs(out[:, :B] - ref).max() < 2e-6
+    assert np.all(out[:, B:] == 0)
+    for Wd2 in (8, 16, 256, 512):
+        x2 = rng.standard_normal((33, Wd2), dtype=np.float32)
+        g2 = np.ones(Wd2, np.float32)
+        b2 = np.zeros(Wd2, np.float32)
+        o2 = ops.layernorm_act(torch.from_numpy(x2).to(dev), torch.from_numpy(g2).to(dev),
+                               torch.from_numpy(b2).to(dev)).cpu().numpy()
+        assert np.abs(o2 - R.layer_norm(x2.astype(np.float64), g2, b2)).max() < 2e-6
+
+
+@pytest.mark.parametrize("H,D,B", [(128, 2, 40), (128, 1, 32), (8, 2, 3), (32, 2, 5), (64, 1, 9)])
+def test_lstm_layer_vs_oracle(dev, H, D, B):
+    """gate GEMM + persistent recurrent kernel (fast H=128 path and generic path) vs the numpy
+    restatement of one layer."""
+    from lstm_ode_bci_amd import ops
+    from oracle import restatement as R
+    rng = np.random.default_rng(H + D + B)
+    T, K = 20, 48
+    Bp = ops.ceil32(B)
+    bound = 1 / np.sqrt(H)
+    x = rng.standard_normal((B, T, K), dtype=np.float32)
+    ws = [[rng.uniform(-bound, bound, s).astype(np.float32) for s in ((4 * H, K), (4 * H, H), (4 * H,), (4 * H,))]
+          for _ in range(D)]
+    xt = np.zeros((T, Bp, K), np.float32)
+    xt[:, :B] = x.transpose(1, 0, 2)
+    wih = torch.from_numpy(np.concatenate([w[0] for w in ws], 0)).to(dev)
+    whh = torch.from_numpy(np.stack([w[1] for w in ws], 0)).to(dev)
+    bias = torch.from_numpy(np.concatenate([w[2] + w[3] for w in ws], 0)).to(dev)
+    for save in (False, True):
+        P = ops.gate_gemm_x(torch.from_numpy(xt.reshape(T * Bp, K)).to(dev), wih, bias, T, Bp, H, D, H == 128)
+        Y, Cs = ops.lstm_rec_fwd(P, whh, T, Bp, H, D, save)
+        y = Y.cpu().numpy().reshape(T, Bp, D * H)[:, :B].transpose(1, 0, 2)
+        ref = np.concatenate([R.lstm_direction(x.astype(np.float64), *[w.astype(np.float64) for w in ws[d]], d == 1)
+                              for d in range(D)], -1)
+        assert np.abs(y - ref).max() < 5e-6, (H, D, save)
+
+
+def test_attention_pool_vs_oracle(dev):
+    from lstm_ode_bci_amd import Attention
+    from oracle import restatement as R
+    rng = np.random.default_rng(9)
+    B, T, Wd = 6, 50, 64
+    att = Attention(Wd).to(dev)
+    v = rng.standard_normal((B, T, Wd), dtype=np.float32)
+    ctx, w = att(torch.from_numpy(v).to(dev))
+    sd = {k: p.detach().cpu().numpy().astype(np.float64) for k, p in att.state_dict().items()}
+    u = np.tanh(v @ sd["attention.0.weight"].T + sd["attention.0.bias"])
+    s = u @ sd["attention.2.weight"].T + sd["attention.2.bias"]
+    a = R.softmax(s, axis=1)
+    assert np.abs(w.cpu().numpy() - a[..., 0]).max() < 1e-6
+    assert np.abs(ctx.cpu().numpy() - (a * v).sum(1)).max() < 2e-6
+    assert np.abs(w.cpu().numpy().sum(1) - 1).max() < 1e-6
+
+
+# ------------------------------------------------------------------------------------------
+# whole forward against the reference goldens
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("L", [1, 3])
+@pytest.mark.parametrize("bi", [0, 1])
+def test_forward_tiny_goldens(dev, L, bi):
+    d = np.load(os.path.join(GOLDEN, f"g1_tiny_L{L}_bi{bi}.npz"))
+    sd = {k[2:]: d[k] for k in d.files if k.startswith("w:")}
+    m = _model(sd, 5, 8, L, bool(bi), dev)
+    with torch.no_grad():
+        logits, attn = m(torch.from_numpy(d["x"]).to(dev), return_attention=True)
+    assert np.abs(logits.cpu().numpy() - d["logits"]).max() < TOL
+    assert np.abs(attn.cpu().numpy() - d["attn"]).max() < TOL
+
+
+@pytest.mark.parametrize("H", [128, 256])
+def test_forward_full_size_goldens(dev, H):
+    d = np.load(os.path.join(GOLDEN, f"g2_full_H{H}.npz"))
+    x, _ = syn.make_windows(8)
+    m = _model(syn.make_state_dict(61, H, 3, 2, True), 61, H, 3, True, dev)
+    with torch.no_grad():
+        logits, attn = m(torch.from_numpy(x).to(dev), return_attention=True)
+    assert logits.shape == (8, 2) and attn.shape == (8, 256) and logits.dtype == torch.float32
+    assert np.abs(logits.cpu().numpy() - d["logits"]).max() < TOL
+    assert np.abs(attn.cpu().numpy() - d["attn"]).max() < TOL
+    m3 = _model(syn.make_state_dict(61, H, 3, 2, True, lstm_scale=3.0), 61, H, 3, True, dev)
+    with torch.no_grad():
+        l3, a3 = m3(torch.from_numpy(x).to(dev), return_attention=True)
+    assert np.abs(l3.cpu().numpy() - d["logits_stress"]).max() < 5 * TOL    # saturated gates
+    assert np.abs(a3.cpu().numpy() - d["attn_stress"]).max() < TOL
+
+
+def test_forward_config1_b1024_vs_oracle(dev):
+    """BASELINE.json configs[1]: fwd-only, H=128, B=1024 (ragged: 1000), fp32, <= 1e-5 vs the CPU path."""
+    from oracle import torch_cpu_path as TP
+    B = 1000
+    sd = syn.make_state_dict(61, 128, 3, 2, True)
+    x, _ = syn.make_windows(B)
+    m = _model(sd, 61, 128, 3, True, dev)
+    with torch.no_grad():
+        logits, attn = m(torch.from_numpy(x).to(dev), return_attention=True)
+    ref = TP.build(sd, 61, 128)
+    idx = np.r_[0:48, B - 48:B]                      # oracle on the first/last windows: seconds
+    with torch.no_grad():
+        rl, ra = ref(torch.from_numpy(x[idx]), return_attention=True)
+    assert np.abs(logits.cpu().numpy()[idx] - rl.numpy()).max() < TOL
+    assert np.abs(attn.cpu().numpy()[idx] - ra.numpy()).max() < TOL
+    # batch-composition independence: every window is independent of its neighbours
+    with torch.no_grad():
+        l2 = m(torch.from_numpy(x[idx]).to(dev))
+    assert np.abs(l2.cpu().numpy() - logits.cpu().numpy()[idx]).max() < 1e-6
+
+
+# ------------------------------------------------------------------------------------------
+# ODE + coupling
+# ------------------------------------------------------------------------------------------
+def test_ode_grid_vs_reference(dev):
+    from lstm_ode_bci_amd import ops
+    d = np.load(os.path.join(GOLDEN, "g3_ode.npz"))
+    worst = 0.0
+    for pname, rates in (("default", syn.DEFAULT_RATES), ("fitted", syn.FITTED_RATES)):
+        for ai, alpha in enumerate(d["alphas"]):
+            for steps in (10, 20, 300):
+                key = f"{pname}_a{ai}_s{steps}"
+                if "traj_" + key not in d.files:
+                    continue
+                probs = torch.from_numpy(d["probs_" + key]).to(dev)
+                traj, final, pred = ops.ode_rk4([rates[k] for k in syn.RATE_KEYS], steps, 0.0, float(steps), 16,
+                                                probs=probs, alpha=float(alpha), want_final=True)
+                err = np.abs(traj.cpu().numpy() - d["traj_" + key]).max()
+                worst = max(worst, err)
+                assert err < 1e-6, (key, err)
+                assert np.array_equal(pred.cpu().numpy(), d["pred_" + key]), key
+                assert np.abs(final.cpu().numpy() - d["traj_" + key][:, -1]).max() < 1e-6
+    print("worst ODE |err| vs LSODA:", worst)
+
+
+def test_ode_class_solve(dev):
+    from lstm_ode_bci_amd import CognitiveStateODE
+    d = np.load(os.path.join(GOLDEN, "g3_ode.npz"))
+    ode = CognitiveStateODE(dict(syn.FITTED_RATES))
+    t, sol = ode.solve([0.5, 0.3, 0.2], (0, 7.5), 33)
+    assert sol.dtype == np.float64 and sol.shape == (33, 3)
+    assert np.array_equal(t, d["solve_t"])
+    assert np.abs(sol - d["solve_sol"]).max() < 1e-6
+    assert np.allclose(ode.ode_system([0.2, -0.1, 0.9], 0.0), d["ode_system"], atol=1e-15)
+    assert np.array_equal(ode.get_transition_matrix(), d["q_matrix"])
+    # conservation, steady state = null vector of Q^T
+    assert np.abs(sol.sum(1) - 1).max() < 1e-12
+    ss = CognitiveStateODE().get_steady_state()
+    q = CognitiveStateODE().get_transition_matrix()
+    assert np.abs(q.T @ np.array([ss["Active"], ss["Passive"], ss["Fatigued"]])).max() < 1e-8
+    # n_points = 1 and ragged batch sizes
+    t1, s1 = ode.solve([1, 1, 2], (0, 5), 1)
+    assert np.allclose(s1, [[0.25, 0.25, 0.5]])
+    y0 = np.random.default_rng(0).uniform(0.1, 1, (131, 3))
+    _, sb = ode.solve_batch(y0, (0, 20), 20)
+    from oracle import restatement as R
+    for i in (0, 64, 130):
+        _, r = R.solve_odeint(y0[i], (0, 20), 20, syn.FITTED_RATES)
+        assert np.abs(sb[i] - r).max() < 1e-6
+
+
+def test_coupled_predict_batch_goldens(dev):
+    from lstm_ode_bci_amd import CognitiveStateODE, LSTMODEIntegration
+    d = np.load(os.path.join(GOLDEN, "g4_coupled.npz"))
+    sd = syn.make_state_dict(61, 128, 3, 2, True)
+    sd["classifier.6.weight"] = sd["classifier.6.weight"] * d["cls6_scale"]
+    sd["classifier.6.bias"] = d["cls6_bias"]
+    x, _ = syn.make_windows(32, seed=11)
+    m = _model(sd, 61, 128, 3, True, dev)
+    for pname, rates, alpha in (("default", syn.DEFAULT_RATES, 0.5), ("fitted", syn.FITTED_RATES, 0.5),
+                                ("fitted_a1", syn.FITTED_RATES, 1.0)):
+        ode = CognitiveStateODE(dict(rates))
+        integ = LSTMODEIntegration(m, ode, coupling_strength=alpha)
+        traj, probs, pred = integ.predict_batch(x, forecast_steps=20, batch_size=16, show_progress=False)
+        assert traj.shape == (32, 20, 3) and traj.dtype == np.float64
+        assert probs.shape == (32, 2) and probs.dtype == np.float32
+        assert pred.shape == (32,) and pred.dtype == np.int64
+        # logits are scaled x400 in this fixture, so 1e-5 logit error -> ~1e-3 in probability
+        assert np.abs(probs - d["probs_" + pname]).max() < 2e-3
+        stable = np.abs(d["probs_" + pname] - 0.6).min(1) > 5e-3      # away from the branch thresholds
+        stable &= np.abs(d["probs_" + pname] - 0.4).min(1) > 5e-3
+        assert np.abs(traj[stable] - d["traj_" + pname][stable]).max() < 2e-3
+        far = np.abs(d["traj_" + pname][:, -1, 2] - 0.5) > 5e-3
+        assert np.array_equal(pred[far & stable], d["pred_" + pname][far & stable])
+        assert ode.params == dict(rates)
+        t1, p1, a1 = integ.predict_trajectory(x[:1], forecast_steps=20)
+        assert np.abs(t1 - traj[0]).max() < 1e-6 and p1.shape == (1, 2) and a1.shape == (1, 256)
+        pr, at = integ.get_lstm_probabilities(x[:4])
+        assert np.abs(pr - probs[:4]).max() < 1e-6 and at.shape == (4, 256)
+        # exactness of stage 2 on the reference's own probabilities
+        from lstm_ode_bci_amd import ops
+        tr2, _, pd2 = ops.ode_rk4([rates[k] for k in syn.RATE_KEYS], 20, 0.0, 20.0, 16,
+                                  probs=torch.from_numpy(d["probs_" + pname]).to(dev), alpha=alpha)
+        assert np.abs(tr2.cpu().numpy() - d["traj_" + pname]).max() < 1e-6
+        assert np.array_equal(pd2.cpu().numpy(), d["pred_" + pname])
