@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""Headline benchmark: EEG windows/s through the MI355X-native LSTM-ODE inner loop.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode train|fwd|coupled] [--batch B]
+
+One "step" = one pass of the hot path over one batch of B synthetic (256 x 61) windows per GPU
+(weak scaling: B per GPU is fixed, default 4096 = BASELINE.json configs[2]).  Inputs and
+weights are resident in HBM before the timed region.  For N > 1 the driver launches this file
+under torch.distributed.run, one rank per GPU (RCCL); windows are sharded over ranks with no
+data-path collective; the step ends with the one collective the path needs (all-gather of the
+logits for inference, gradient all-reduce for training).
+
+Prints ONE JSON line on rank 0 (contract in the task statement), carrying `roofline` (live HIP
+event timing of the dominant kernel vs the fp32 MFMA peak) and `cpu_baseline` (the oracle's
+torch-CPU layer stack -- the reference's CPU path semantically -- timed on this host's cores on a
+bounded sample; rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+T, C, H, L, D = 256, 61, 128, 3, 2
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+GATE_FLOP_FWD = 2 ** 29            # per window, SURVEY.md §8d
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mode", default=None, choices=["train", "fwd", "coupled"])
+    ap.add_argument("--batch", type=int, default=4096, help="windows per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--forecast-steps", type=int, default=300)
+    return ap.parse_args()
+
+
+def have_backward():
+    try:
+        from lstm_ode_bci_amd import backward  # noqa: F401
+        return True
+    except Exception:
+        return False
+
+
+def build_model(dev):
+    from lstm_ode_bci_amd import EnhancedLSTMModel
+    from lstm_ode_bci_amd import synthetic as syn
+    sd = syn.make_state_dict(C, H, L, 2, True)
+    m = EnhancedLSTMModel(input_size=C, hidden_size=H, num_layers=L, num_classes=2, dropout=0.4,
+                          bidirectional=True)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return m.to(dev), sd
+
+
+def kernel_roofline(dev, B):
+    """Per-launch durations of the two MFMA kernels, HIP events on the launch stream."""
+    from lstm_ode_bci_amd import ops
+    Bp = ops.ceil32(B)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    out = {}
+
+    def timeit(fn, n=5):
+        fn()
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        for s, e in evs:
+            s.record()
+            fn()
+            e.record()
+        torch.cuda.synchronize()
+        return float(np.mean([s.elapsed_time(e) for s, e in evs])) * 1e-3
+
+    for K in (H, D * H):
+        x = torch.randn((T * Bp, K), generator=g).to(dev)
+        wih = (torch.rand((D * 4 * H, K), generator=g) * 0.17 - 0.085).to(dev)
+        bias = torch.zeros(D * 4 * H, device=dev)
+        sec = timeit(lambda: ops.gate_gemm_x(x, wih, bias, T, Bp, H, D, True))
+        fl = 2.0 * T * Bp * D * 4 * H * K
+        out[f"gate_gemm_x_K{K}"] = {"sec": sec, "flop": fl, "tflops": fl / sec / 1e12}
+    P = ops.gate_gemm_x(x, wih, bias, T, Bp, H, D, True)
+    whh = (torch.rand((D, 4 * H, H), generator=g) * 0.17 - 0.085).to(dev)
+    sec = timeit(lambda: ops.lstm_rec_fwd(P, whh, T, Bp, H, D, False), n=3)
+    fl = 2.0 * T * Bp * D * 4 * H * H
+    out["lstm_rec_fwd"] = {"sec": sec, "flop": fl, "tflops": fl / sec / 1e12}
+    del P, x
+    return out
+
+
+def cpu_baseline(mode, sd):
+    """The reference's CPU path (same torch layer stack -> aten::lstm -> oneDNN), bounded sample."""
+    from oracle import torch_cpu_path as TP
+    from lstm_ode_bci_amd import synthetic as syn
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    m = TP.build(sd, C, H)
+    Bc = 128
+    x, y = syn.make_windows(Bc)
+    xt, yt = torch.from_numpy(x), torch.from_numpy(y)
+    t0 = time.perf_counter()
+    best, med, nthreads = 0.0, 0.0, 1
+    # oneDNN's RNN primitive does not scale to all host threads; keep the best thread count
+    for nt in sorted({min(ncores, n) for n in (8, 16, 32, 64)}):
+        torch.set_num_threads(nt)
+        if mode == "train":
+            b, md = TP.time_train_step(m, xt, yt, iters=2, warmup=1)
+        else:
+            b, md = TP.time_forward(m, xt, iters=3, warmup=1)
+        if b > best:
+            best, med, nthreads = b, md, nt
+    what = (f"fwd+bwd train-mode (dropout on, weighted CE), B={Bc}" if mode == "train"
+            else f"fwd eval-mode no_grad, B={Bc}") + ", best over 8/16/32/64 threads"
+    return {"value": best, "median": med, "unit": "windows/s", "cores": nthreads, "kind": "port",
+            "sample": what + f"; torch {torch.__version__} CPU (oneDNN), {time.perf_counter() - t0:.1f}s wall",
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with python -m torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from lstm_ode_bci_amd import CognitiveStateODE, LSTMODEIntegration
+    from lstm_ode_bci_amd import synthetic as syn
+
+    mode = a.mode or ("train" if have_backward() else "fwd")
+    B = a.batch
+    model, sd = build_model(dev)
+    # rank r owns global windows [r*B, (r+1)*B): independent shards, no data-path collective
+    x_np, y_np = syn.make_windows(B, T, C, seed=syn.INPUT_SEED + rank)
+    x = torch.from_numpy(x_np).to(dev)
+    y = torch.from_numpy(y_np).to(dev)
+    class_w = torch.tensor([1.0, 1.0], device=dev)
+    integ = LSTMODEIntegration(model, CognitiveStateODE(), 0.5)
+    gather_buf = torch.empty((world * B, 2), device=dev) if world > 1 else None
+    params = [p for p in model.parameters()]
+
+    def step():
+        if mode == "train":
+            model.train()
+            for p in params:
+                p.grad = None
+            logits = model(x)
+            loss = torch.nn.functional.cross_entropy(logits, y, weight=class_w)
+            loss.backward()
+            if world > 1:
+                flat = torch.cat([p.grad.reshape(-1) for p in params])
+                dist.all_reduce(flat)
+        elif mode == "fwd":
+            model.eval()
+            with torch.no_grad():
+                logits = model(x)
+                if world > 1:
+                    dist.all_gather_into_tensor(gather_buf, logits.contiguous())
+        else:
+            traj, probs, pred = integ.predict_batch_device(x, forecast_steps=a.forecast_steps, batch_size=B)
+            if world > 1:
+                dist.all_gather_into_tensor(gather_buf, probs.contiguous())
+
+    for _ in range(a.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        value = world * B * a.steps / dt
+        kr = kernel_roofline(dev, B)
+        gsec = kr[f"gate_gemm_x_K{H}"]["sec"] + (L - 1) * kr[f"gate_gemm_x_K{D * H}"]["sec"]
+        rsec = L * kr["lstm_rec_fwd"]["sec"]
+        dom = f"gate_gemm_x_K{D * H}" if gsec >= rsec else "lstm_rec_fwd"
+        roof = {"bound": "mfma", "kernel": dom, "achieved": kr[dom]["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": kr[dom]["tflops"] / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                "flop_per_launch": kr[dom]["flop"], "sec_per_launch": kr[dom]["sec"],
+                "all": {k: {"tflops": round(v["tflops"], 2), "ms": round(v["sec"] * 1e3, 3)} for k, v in kr.items()}}
+        flop_per_window = GATE_FLOP_FWD * (3 if mode == "train" else 1)
+        res = {
+            "metric": {"train": "eeg_windows_per_sec_fwd_bwd", "fwd": "eeg_windows_per_sec_fwd",
+                       "coupled": "eeg_windows_per_sec_fwd_ode"}[mode],
+            "value": value, "unit": "windows/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BiLSTM(3x128)+attn {mode}, (T=256,C=61) windows, B={B}/GPU, fp32 exact-MFMA"
+                                   + (f", RK4 ODE {a.forecast_steps} points" if mode == "coupled" else ""),
+                       "batch_per_gpu": B, "global_batch": world * B, "seq_len": T, "channels": C,
+                       "hidden": H, "layers": L, "mode": mode,
+                       "collective": ("none" if world == 1 else
+                                      ("all_reduce(grads 4.55MB)" if mode == "train" else "all_gather(logits)"))},
+            "gate_gemm_tflops_effective": value * flop_per_window / 1e12,
+            "gate_gemm_frac_of_fp32_mfma_peak": value * flop_per_window / 1e12 / FP32_MFMA_PEAK_TFLOPS / world,
+            "roofline": roof,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(mode, sd)
+            res["speedup_vs_cpu_baseline"] = value / res["cpu_baseline"]["value"]
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
