@@ -35,6 +35,7 @@ extern "C" {
 #define LOB_ACT_NONE 0
 #define LOB_ACT_TANH 1     /* nn.Tanh  (04_lstm_model.py:119)                        */
 #define LOB_ACT_GELU 2     /* nn.GELU, exact erf form (04_lstm_model.py:176,198,201) */
+#define LOB_ACCUMULATE 0x100  /* OR into `act` of lob_gemm_nt_f32: C += result instead of C = */
 
 int lob_version(void);
 
@@ -82,14 +83,40 @@ int lob_gate_gemm_x_f32(const float* X, int ldx, const float* Wih, const float* 
 int lob_lstm_rec_fwd_f32(float* P, const float* Whh, float* Y, float* Csave,
                          int T, int Bp, int H, int D, int save, void* stream);
 
-/* Backward of the above (BPTT), one persistent kernel:
- *   G     activated gates saved by the forward (in place of P); overwritten... no:
- *   dP    [T*Bp][D*4H] row-major gradient w.r.t. the gate pre-activations (output)
- *   dY    [T][Bp][D*H] gradient w.r.t. the layer output (input)
- * dW_hh, dW_ih, db and dX follow from dP by lob_gemm_tn_f32 / lob_gemm_nt_f32.      */
+/* Backward of the above (BPTT through time), one persistent kernel, both directions:
+ *   G      activated gates saved by the forward (save = 1), same layout as P; READ-ONLY
+ *   Csave  cell states saved by the forward; READ-ONLY (backward is re-entrant, 07:254)
+ *   dY     [T][Bp][D*H] gradient w.r.t. the layer output
+ *   dP     [T*Bp][D*4H] ROW-MAJOR gradient w.r.t. the gate pre-activations (output)
+ * dW_ih = dP^T X, dW_hh[d] = dP[:,d]^T H_prev, db = colsum(dP) (lob_gemm_tn_f32,
+ * lob_colsum_f32) and dX = dP W_ih (lob_gemm_nt_f32 with the transposed weight) follow.
+ * (torch autograd of nn.LSTM; training step 04_lstm_model.py:482-512.)                */
 int lob_lstm_rec_bwd_f32(const float* G, const float* Csave, const float* Whh,
                          const float* dY, float* dP, int T, int Bp, int H, int D,
                          void* stream);
+
+/* out[n] += sum_m A[m][n]  (bias gradients; fp32 atomics, `out` must be initialised). */
+int lob_colsum_f32(const float* A, int lda, int M, int N, float* out, void* stream);
+
+/* Element-wise activation and its backward (dx = dy * act'(pre)); classifier GELUs
+ * (04_lstm_model.py:198, 201) in training mode.                                       */
+int lob_act_f32(const float* in, float* out, int64_t n, int act, void* stream);
+int lob_act_bwd_f32(const float* dy, const float* pre, float* dx, int64_t n, int act, void* stream);
+
+/* Backward of lob_layernorm_act_f32 (same act / dropout seed / remap arguments).  x is the
+ * LayerNorm INPUT (rows in input order), dy the gradient of the output (rows in output
+ * order).  dgamma / dbeta are ACCUMULATED with fp32 atomics (initialise them).         */
+int lob_layernorm_act_bwd_f32(const float* x, const float* gamma, const float* beta, const float* dy,
+                              float* dx, float* dgamma, float* dbeta, int rows, int width, float eps,
+                              int act, int remap_T, int remap_B, int remap_Bp, float drop_p,
+                              uint64_t seed, void* stream);
+
+/* Backward of lob_attn_pool_fwd_f32.  dV [T*Bp][W] and dPreU [T*Bp][W2] are WRITTEN for rows
+ * b < B (pad rows untouched); dw2 [W2] is accumulated (atomics).  dPreU is the gradient w.r.t.
+ * the pre-tanh hidden W1 v + b1; the caller adds dPreU W1 into dV with lob_gemm_nt_f32.   */
+int lob_attn_pool_bwd_f32(const float* V, const float* U, const float* attn, const float* dctx,
+                          const float* w2, float* dV, float* dPreU, float* dw2,
+                          int T, int B, int Bp, int W, int W2, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Row-wise LayerNorm (biased variance, eps) with affine, optional GELU, optional

@@ -79,13 +79,21 @@ def _forward_impl(x, ps, cfg, save):
     v = ops.layernorm_act(inp, ln_g, ln_b)                                   # (T*Bp, W)
     u = ops.gemm_nt(v, a0w, a0b, act=ACT_TANH)                               # (T*Bp, W/2)
     ctx, attn = ops.attn_pool_fwd(v, u, a2w.reshape(-1), a2b, T, B, Bp)
-    z1 = ops.gemm_nt(ctx, c0w, c0b, act=ACT_GELU)
+    if save:       # keep the pre-activations of the two classifier GELUs for their backward
+        z1p = ops.gemm_nt(ctx, c0w, c0b)
+        z1 = ops.act(z1p, ACT_GELU)
+    else:
+        z1p, z1 = None, ops.gemm_nt(ctx, c0w, c0b, act=ACT_GELU)
     z1d = ops.dropout(z1, p_cls, _seed(seed, 20)) if p_cls > 0 else z1
-    z2 = ops.gemm_nt(z1d, c3w, c3b, act=ACT_GELU)
+    if save:
+        z2p = ops.gemm_nt(z1d, c3w, c3b)
+        z2 = ops.act(z2p, ACT_GELU)
+    else:
+        z2p, z2 = None, ops.gemm_nt(z1d, c3w, c3b, act=ACT_GELU)
     z2d = ops.dropout(z2, p_cls, _seed(seed, 21)) if p_cls > 0 else z2
     logits = ops.gemm_nt(z2d, c6w, c6b)
     if save:
-        sv.update(ylast=inp, v=v, u=u, ctx=ctx, attn=attn, z1=z1, z1d=z1d, z2=z2, z2d=z2d)
+        sv.update(ylast=inp, v=v, u=u, ctx=ctx, attn=attn, z1p=z1p, z1d=z1d, z2p=z2p, z2d=z2d)
     return logits, attn, sv
 
 
@@ -94,7 +102,7 @@ class _LobModelFn(torch.autograd.Function):
     def forward(ctx, x, cfg, *params):
         ps = [_f32c(p) for p in params]
         xf = _f32c(x)
-        need_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+        need_grad = any(ctx.needs_input_grad)      # grad mode is off inside Function.forward
         logits, attn, sv = _forward_impl(xf, ps, cfg, save=need_grad)
         ctx.cfg = cfg
         ctx.sv = sv

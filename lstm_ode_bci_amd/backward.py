@@ -1,0 +1,95 @@
+"""Backward pipeline of the drop-in model (the mirror of ``autograd._forward_impl``).
+
+Produces the gradient of every ``state_dict`` tensor and of the input window batch
+(04_lstm_model.py:490 ``loss.backward()``; 07_explainability.py:242-257 reads ``X.grad``).
+All arithmetic is HIP (liblob.so); torch only slices, transposes the small weight matrices
+and allocates.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .autograd import _seed
+from .ops import ACT_GELU, ceil32
+
+
+def _t(w):
+    return w.t().contiguous()
+
+
+def _linear_bwd(dy, x, w, need_dx=True):
+    """y = x w^T + b  ->  (dx, dw, db)."""
+    dw = torch.zeros_like(w)
+    ops.gemm_tn(dy, x, dw)
+    db = ops.colsum(dy)
+    dx = ops.gemm_nt(dy, _t(w)) if need_dx else None
+    return dx, dw, db
+
+
+def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad):
+    if sv is None:
+        raise RuntimeError("backward called on a forward that ran without grad tracking")
+    L, D, H, (p_in, p_lstm, p_cls), seed = cfg
+    B, T, C = x_shape
+    Bp = ceil32(B)
+    n = len(ps)
+    g = [None] * n
+    i_ln, i_a0w, i_a0b, i_a2w, i_a2b = n - 12, n - 10, n - 9, n - 8, n - 7
+    i_c0w, i_c3w, i_c6w = n - 6, n - 4, n - 2
+
+    # ---- classifier (04:196-204)
+    dz2d, g[i_c6w], g[i_c6w + 1] = _linear_bwd(dlogits, sv["z2d"], ps[i_c6w])
+    dz2 = ops.dropout(dz2d, p_cls, _seed(seed, 21)) if p_cls > 0 else dz2d
+    dz2p = ops.act_bwd(dz2, sv["z2p"], ACT_GELU)
+    dz1d, g[i_c3w], g[i_c3w + 1] = _linear_bwd(dz2p, sv["z1d"], ps[i_c3w])
+    dz1 = ops.dropout(dz1d, p_cls, _seed(seed, 20)) if p_cls > 0 else dz1d
+    dz1p = ops.act_bwd(dz1, sv["z1p"], ACT_GELU)
+    dctx, g[i_c0w], g[i_c0w + 1] = _linear_bwd(dz1p, sv["ctx"], ps[i_c0w])
+
+    # ---- attention pooling (04:123-128)
+    v, u = sv["v"], sv["u"]
+    dV, dU, dw2 = ops.attn_pool_bwd(v, u, sv["attn"], dctx, ps[i_a2w].reshape(-1), T, B, Bp)
+    g[i_a2w] = dw2.reshape(1, -1)
+    g[i_a2b] = torch.zeros_like(ps[i_a2b])            # b2 cancels in the softmax: exactly 0
+    g[i_a0w] = torch.zeros_like(ps[i_a0w])
+    ops.gemm_tn(dU, v, g[i_a0w])
+    g[i_a0b] = ops.colsum(dU)
+    ops.gemm_nt(dU, _t(ps[i_a0w]), out=dV, accumulate=True)
+
+    # ---- post-LSTM LayerNorm (04:212)
+    dY, g[i_ln], g[i_ln + 1] = ops.layernorm_act_bwd(sv["ylast"], ps[i_ln], ps[i_ln + 1], dV)
+
+    # ---- LSTM stack, last layer first (04:211)
+    for layer in reversed(range(L)):
+        lay = sv["layers"][layer]
+        if layer + 1 < L and p_lstm > 0:
+            dY = ops.dropout(dY, p_lstm, _seed(seed, 10 + layer))
+        dP = ops.lstm_rec_bwd(lay["G"], lay["C"], lay["whh"], dY, T, Bp, H, D)
+        inp, Y, wih = lay["inp"], lay["Y"], lay["wih"]
+        dwih = torch.zeros_like(wih)
+        ops.gemm_tn(dP, inp, dwih)
+        dbias = ops.colsum(dP)
+        base = 4 + layer * 4 * D
+        for d in range(D):
+            dwhh = torch.zeros_like(ps[base + 4 * d + 1])
+            if T > 1:
+                a_sl = dP[:, d * 4 * H:(d + 1) * 4 * H]
+                y_sl = Y[:, d * H:(d + 1) * H]
+                if d == 0:      # h_prev(t) = h(t-1)
+                    ops.gemm_tn(a_sl[Bp:], y_sl[:(T - 1) * Bp], dwhh)
+                else:           # reverse direction: h_prev(t) = h(t+1)
+                    ops.gemm_tn(a_sl[:(T - 1) * Bp], y_sl[Bp:], dwhh)
+            g[base + 4 * d + 0] = dwih[d * 4 * H:(d + 1) * 4 * H]
+            g[base + 4 * d + 1] = dwhh
+            g[base + 4 * d + 2] = dbias[d * 4 * H:(d + 1) * 4 * H]
+            g[base + 4 * d + 3] = dbias[d * 4 * H:(d + 1) * 4 * H]
+        dY = ops.gemm_nt(dP, _t(wih))
+        del dP
+
+    # ---- input projection: Linear -> LayerNorm -> GELU -> Dropout (04:173-178)
+    dpre, g[2], g[3] = ops.layernorm_act_bwd(sv["pre"], ps[2], ps[3], dY, act=ACT_GELU, remap=(T, B, Bp),
+                                             drop_p=p_in, seed=_seed(seed, 0))
+    gx2d, g[0], g[1] = _linear_bwd(dpre, sv["x2d"], ps[0], need_dx=bool(needs_input_grad[0]))
+    gx = gx2d.reshape(B, T, C) if gx2d is not None else None
+    return gx, g

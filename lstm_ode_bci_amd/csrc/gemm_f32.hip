@@ -19,7 +19,7 @@ constexpr int BM = 128, BN = 128, BK = 32, LDT = 36;
 
 struct GemmNT {
     const float* A; const float* W; const float* bias; float* C;
-    int lda, ldw, ldc, M, N, K, act;
+    int lda, ldw, ldc, M, N, K, act, accumulate;
     // fragment epilogue (gate pre-activations): N = D*4H, M = T*Bp
     int T, Bp, H, D;
 };
@@ -126,7 +126,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT g) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + 64 * wr + 32 * i + acc_row(r, lane);
-                    if (row < g.M) g.C[(size_t)row * g.ldc + col] = apply_act(acc[i][j][r] + bv, g.act);
+                    if (row < g.M) {
+                        float* dst = g.C + (size_t)row * g.ldc + col;
+                        const float val = apply_act(acc[i][j][r] + bv, g.act);
+                        *dst = g.accumulate ? *dst + val : val;
+                    }
                 }
             }
     } else {
@@ -156,6 +160,132 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT g) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------
+// C[M,N] += A[Kc,M]^T * B[Kc,N]  -- weight gradients.  The contraction index is the ROW index
+// of both operands (time x batch, ~1M), the output is small, so the grid splits Kc and every
+// workgroup adds its 128x128 partial tile with fp32 atomics (each wave-instruction covers two
+// 128-B row segments = the full-rate shape).  Operands are staged [k][m] so that an MFMA
+// operand read is one conflict-free ds_read_b32 (consecutive lanes, consecutive addresses).
+// ------------------------------------------------------------------------------------
+constexpr int TLD = 132;   // LDS row stride (floats) of a [32 k][128 m] tile
+
+struct GemmTN {
+    const float* A; const float* B; float* C;
+    int lda, ldb, ldc, M, N, Kc, kchunk;
+};
+
+template <bool VEC>
+__device__ __forceinline__ void load_tile_k(const float* __restrict__ G, int ld, int k0, int kend,
+                                            int c0, int cols, int tid, f32x4 (&r)[4]) {
+    // tile [32 k][128 cols]; thread -> (k = tid/32 + 8i, c4 = (tid%32)*4)
+    const int kk = tid >> 5, c4 = (tid & 31) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = k0 + kk + 8 * i, c = c0 + c4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k < kend) {
+            const float* p = G + (size_t)k * ld + c;
+            if (VEC) {
+                if (c < cols) v = *reinterpret_cast<const f32x4*>(p);
+            } else {
+                if (c + 0 < cols) v[0] = p[0];
+                if (c + 1 < cols) v[1] = p[1];
+                if (c + 2 < cols) v[2] = p[2];
+                if (c + 3 < cols) v[3] = p[3];
+            }
+        }
+        r[i] = v;
+    }
+}
+
+__device__ __forceinline__ void store_tile_k(float* S, int tid, const f32x4 (&r)[4]) {
+    const int kk = tid >> 5, c4 = (tid & 31) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(S + (kk + 8 * i) * TLD + c4) = r[i];
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN g) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * 2 * 32 * TLD];
+    float* As = lds;
+    float* Bs = lds + 2 * 32 * TLD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int ntm = (g.M + 127) / 128, ntn = (g.N + 127) / 128;
+    const int tile = blockIdx.x % (ntm * ntn), chunk = blockIdx.x / (ntm * ntn);
+    const int m0 = (tile / ntn) * 128, n0 = (tile % ntn) * 128;
+    const int kbeg = chunk * g.kchunk, kend = min(g.Kc, kbeg + g.kchunk);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 ra[4], rb[4];
+    load_tile_k<VEC>(g.A, g.lda, kbeg, kend, m0, g.M, tid, ra);
+    load_tile_k<VEC>(g.B, g.ldb, kbeg, kend, n0, g.N, tid, rb);
+    store_tile_k(As, tid, ra);
+    store_tile_k(Bs, tid, rb);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
+        if (k0 + 32 < kend) {
+            load_tile_k<VEC>(g.A, g.lda, k0 + 32, kend, m0, g.M, tid, ra);
+            load_tile_k<VEC>(g.B, g.ldb, k0 + 32, kend, n0, g.N, tid, rb);
+        }
+        const float* as = As + buf * 32 * TLD + (16 * (lane >> 5)) * TLD + 64 * wr + (lane & 31);
+        const float* bs = Bs + buf * 32 * TLD + (16 * (lane >> 5)) * TLD + 64 * wc + (lane & 31);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float a0 = as[s * TLD], a1 = as[s * TLD + 32];
+            const float b0 = bs[s * TLD], b1 = bs[s * TLD + 32];
+            acc[0][0] = mfma32(a0, b0, acc[0][0]);
+            acc[0][1] = mfma32(a0, b1, acc[0][1]);
+            acc[1][0] = mfma32(a1, b0, acc[1][0]);
+            acc[1][1] = mfma32(a1, b1, acc[1][1]);
+        }
+        if (k0 + 32 < kend) {
+            store_tile_k(As + (buf ^ 1) * 32 * TLD, tid, ra);
+            store_tile_k(Bs + (buf ^ 1) * 32 * TLD, tid, rb);
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + 64 * wc + 32 * j + (lane & 31);
+            if (col >= g.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + 64 * wr + 32 * i + acc_row(r, lane);
+                if (row < g.M) atomicAdd(g.C + (size_t)row * g.ldc + col, acc[i][j][r]);
+            }
+        }
+}
+
+// out[n] += sum_m A[m][n]  (bias gradients).  Block = 256 threads = 64 column-lanes x 4 row-groups.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A, int lda, int M, int N,
+                                                     int rows_per_block, float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int ncb = (N + 63) / 64;
+    const int cb = blockIdx.x % ncb, rb = blockIdx.x / ncb;
+    const int col = cb * 64 + cl;
+    const int r0 = rb * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float s = 0.f;
+    if (col < N)
+        for (int r = r0 + rg; r < r1; r += 4) s += A[(size_t)r * lda + col];
+    red[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0 && col < N) atomicAdd(out + col, red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int launch_nt(const GemmNT& g, int epi, hipStream_t s) {
@@ -179,8 +309,8 @@ extern "C" int lob_gemm_nt_f32(const float* A, int lda, const float* W, int ldw,
                                float* C, int ldc, int M, int N, int K, int act, void* stream) {
     if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return LOB_E_ARG;
     if (lda < K || ldw < K || ldc < N) return LOB_E_SHAPE;
-    if (act < LOB_ACT_NONE || act > LOB_ACT_GELU) return LOB_E_ARG;
-    GemmNT g{A, W, bias, C, lda, ldw, ldc, M, N, K, act, 0, 0, 0, 0};
+    if ((act & 0xff) > LOB_ACT_GELU || act < 0) return LOB_E_ARG;
+    GemmNT g{A, W, bias, C, lda, ldw, ldc, M, N, K, act & 0xff, (act >> 8) & 1, 0, 0, 0, 0};
     return launch_nt(g, 0, (hipStream_t)stream);
 }
 
@@ -194,6 +324,39 @@ extern "C" int lob_gate_gemm_x_f32(const float* X, int ldx, const float* Wih, co
         if ((H % 32) || (Bp % 32)) return LOB_E_SHAPE;
         if (!aligned16(P)) return LOB_E_ALIGN;
     }
-    GemmNT g{X, Wih, bias, P, ldx, K, N, T * Bp, N, K, LOB_ACT_NONE, T, Bp, H, D};
+    GemmNT g{X, Wih, bias, P, ldx, K, N, T * Bp, N, K, LOB_ACT_NONE, 0, T, Bp, H, D};
     return launch_nt(g, frag ? 1 : 0, (hipStream_t)stream);
+}
+
+extern "C" int lob_gemm_tn_f32(const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                               int M, int N, int Kc, void* stream) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || Kc <= 0) return LOB_E_ARG;
+    if (lda < M || ldb < N || ldc < N) return LOB_E_SHAPE;
+    const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    // ~2048 workgroups in flight; chunk a multiple of 32 rows, at least 256
+    int nchunk = (2048 + tiles - 1) / tiles;
+    int kchunk = (Kc + nchunk - 1) / nchunk;
+    kchunk = ((kchunk + 31) / 32) * 32;
+    if (kchunk < 256) kchunk = 256;
+    nchunk = (Kc + kchunk - 1) / kchunk;
+    GemmTN g{A, B, C, lda, ldb, ldc, M, N, Kc, kchunk};
+    const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0) && (M % 4 == 0) && (N % 4 == 0);
+    const dim3 grid((unsigned)(tiles * nchunk)), block(256);
+    if (vec) hipLaunchKernelGGL((gemm_tn_kernel<true>), grid, block, 0, (hipStream_t)stream, g);
+    else     hipLaunchKernelGGL((gemm_tn_kernel<false>), grid, block, 0, (hipStream_t)stream, g);
+    LOB_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int lob_colsum_f32(const float* A, int lda, int M, int N, float* out, void* stream) {
+    if (!A || !out || M <= 0 || N <= 0 || lda < N) return LOB_E_ARG;
+    const int ncb = (N + 63) / 64;
+    int nrb = (M + 1023) / 1024;
+    if (nrb > 1024) nrb = 1024;
+    const int rpb = (M + nrb - 1) / nrb;
+    nrb = (M + rpb - 1) / rpb;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)(ncb * nrb)), dim3(256), 0, (hipStream_t)stream,
+                       A, lda, M, N, rpb, out);
+    LOB_CHECK_LAUNCH();
+    return 0;
 }

@@ -191,6 +191,169 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_generic_kernel(
     }
 }
 
+
+// ------------------------------------------------------------------------------------
+// BPTT, H = 128 fast path.  Mirror of the forward kernel: wave w owns hidden units
+// [32w, 32w+32); W_hh^T fragments (contraction over the 512 gate rows) live in 256 VGPRs.
+// Per step: cell backward (wave-local, VALU) -> dgates tile in LDS (32 x 512) -> barrier ->
+//   dh_{t-1} = dgates * W_hh  (256 MFMAs per wave)  +  coalesced copy of the tile to dP (HBM)
+// -> barrier.  Saved activations (G, Csave) are read-only: backward is re-entrant.
+// ------------------------------------------------------------------------------------
+constexpr int DG_LD = 516;   // 512 + 4: row stride = 129 x 16 B, odd -> conflict-free ds_read_b128
+
+__global__ __launch_bounds__(256, 1) void lstm_rec_bwd_h128_kernel(
+    const float* __restrict__ G, const float* __restrict__ Csave, const float* __restrict__ Whh,
+    const float* __restrict__ dY, float* __restrict__ dP, int T, int Bp) {
+    constexpr int H = 128;
+    __shared__ __attribute__((aligned(16))) float dgs[32 * DG_LD];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int bt = blockIdx.x, d = blockIdx.y, D = gridDim.y, NBT = gridDim.x;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    float wt[16][16];
+    {
+        const float* wb = Whh + (size_t)d * 4 * H * H + 32 * w + l31;
+#pragma unroll
+        for (int nb = 0; nb < 16; ++nb)
+#pragma unroll
+            for (int s = 0; s < 16; ++s) wt[nb][s] = wb[(size_t)(32 * nb + 16 * hi + s) * H];
+    }
+    const size_t gstep = (size_t)NBT * 16 * 1024, cstep = (size_t)NBT * 4096;
+    const float* gblk = G + ((size_t)d * T * NBT + bt) * 16 * 1024 + (size_t)w * 4096 + lane * 4;
+    const float* cblk = Csave + ((size_t)d * T * NBT + bt) * 4096 + (size_t)w * 1024 + lane * 4;
+    const int DH = D * H, D4H = D * 4 * H;
+    const float* dyb = dY + (size_t)(bt * 32) * DH + d * H + 32 * w + l31;
+
+    const int t_first = d ? 0 : T - 1, dt = d ? 1 : -1;   // backward walk; c_{prev} lives at t + dt
+    f32x16 gt[4], ct, cp, dhrec;
+    float dy[16], dcarry[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dcarry[r] = 0.f; dhrec[r] = 0.f; }
+
+    auto load_step = [&](int t) {
+        const float* gp = gblk + (size_t)t * gstep;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(gp + g * 1024 + q * 256);
+                gt[g][4 * q] = v[0]; gt[g][4 * q + 1] = v[1]; gt[g][4 * q + 2] = v[2]; gt[g][4 * q + 3] = v[3];
+            }
+        const int tp = t + dt;
+        if (tp >= 0 && tp < T) {
+            const float* cq = cblk + (size_t)tp * cstep;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(cq + q * 256);
+                cp[4 * q] = v[0]; cp[4 * q + 1] = v[1]; cp[4 * q + 2] = v[2]; cp[4 * q + 3] = v[3];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cp[r] = 0.f;
+        }
+        const float* dp = dyb + (size_t)t * Bp * DH;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dy[r] = dp[(size_t)acc_row(r, lane) * DH];
+    };
+    {
+        const float* cq = cblk + (size_t)t_first * cstep;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(cq + q * 256);
+            ct[4 * q] = v[0]; ct[4 * q + 1] = v[1]; ct[4 * q + 2] = v[2]; ct[4 * q + 3] = v[3];
+        }
+    }
+    load_step(t_first);
+
+    for (int step = 0; step < T; ++step) {
+        const int t = t_first + dt * step;
+        float* dgw = dgs + 32 * w + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float ig = gt[0][r], fg = gt[1][r], gg = gt[2][r], og = gt[3][r];
+            const float dh = dy[r] + dhrec[r];
+            const float tc = fast_tanh(ct[r]);
+            const float dc = dcarry[r] + dh * og * (1.f - tc * tc);
+            dcarry[r] = dc * fg;
+            float* p = dgw + acc_row(r, lane) * DG_LD;
+            p[0 * H] = dc * gg * ig * (1.f - ig);
+            p[1 * H] = dc * cp[r] * fg * (1.f - fg);
+            p[2 * H] = dc * ig * (1.f - gg * gg);
+            p[3 * H] = dh * tc * og * (1.f - og);
+        }
+        ct = cp;
+        __syncthreads();
+        if (step + 1 < T) load_step(t + dt);
+        // ---- dh_{t-1} = dgates * W_hh   (contraction over 512 gate rows)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dhrec[r] = 0.f;
+        const float* arow = dgs + l31 * DG_LD + 16 * hi;
+#pragma unroll
+        for (int nb = 0; nb < 16; ++nb) {
+            f32x4 a[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const f32x4*>(arow + 32 * nb + 4 * q);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dhrec = mfma32(a[q][e], wt[nb][4 * q + e], dhrec);
+        }
+        // ---- dgates tile -> dP (row-major [T*Bp][D*4H]), 2 KB contiguous per row
+        float* dpb = dP + ((size_t)t * Bp + bt * 32) * D4H + d * 4 * H;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int idx = tid + 256 * i, row = idx >> 7, c4 = (idx & 127) * 4;
+            *reinterpret_cast<f32x4*>(dpb + (size_t)row * D4H + c4) =
+                *reinterpret_cast<const f32x4*>(dgs + row * DG_LD + c4);
+        }
+        __syncthreads();
+    }
+}
+
+// Generic BPTT (any H): G row-major activated gates, Csave [D][T][Bp][H].
+__global__ __launch_bounds__(256) void lstm_rec_bwd_generic_kernel(
+    const float* __restrict__ G, const float* __restrict__ Csave, const float* __restrict__ Whh,
+    const float* __restrict__ dY, float* __restrict__ dP, int T, int Bp, int H) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* dg = sm;                    // [RB][4H]
+    float* dhrec = sm + RB * 4 * H;    // [RB][H]
+    float* dcar = dhrec + RB * H;      // [RB][H]
+    const int tid = threadIdx.x, d = blockIdx.y, D = gridDim.y, b0 = blockIdx.x * RB;
+    const float* W = Whh + (size_t)d * 4 * H * H;
+    for (int i = tid; i < RB * H; i += blockDim.x) { dhrec[i] = 0.f; dcar[i] = 0.f; }
+    __syncthreads();
+    const int t_first = d ? 0 : T - 1, dt = d ? 1 : -1;
+    for (int step = 0; step < T; ++step) {
+        const int t = t_first + dt * step, tp = t + dt;
+        for (int idx = tid; idx < RB * H; idx += blockDim.x) {
+            const int r = idx / H, u = idx % H, b = b0 + r;
+            if (b >= Bp) { for (int g = 0; g < 4; ++g) dg[r * 4 * H + g * H + u] = 0.f; continue; }
+            const float* grow = G + ((size_t)t * Bp + b) * (D * 4 * H) + (size_t)d * 4 * H;
+            const float ig = grow[u], fg = grow[H + u], gg = grow[2 * H + u], og = grow[3 * H + u];
+            const float ctv = Csave[(((size_t)d * T + t) * Bp + b) * H + u];
+            const float cpv = (tp >= 0 && tp < T) ? Csave[(((size_t)d * T + tp) * Bp + b) * H + u] : 0.f;
+            const float dh = dY[((size_t)t * Bp + b) * (D * H) + d * H + u] + dhrec[idx];
+            const float tc = fast_tanh(ctv);
+            const float dc = dcar[idx] + dh * og * (1.f - tc * tc);
+            dcar[idx] = dc * fg;
+            const float v0 = dc * gg * ig * (1.f - ig), v1 = dc * cpv * fg * (1.f - fg);
+            const float v2 = dc * ig * (1.f - gg * gg), v3 = dh * tc * og * (1.f - og);
+            float* o = dg + r * 4 * H;
+            o[u] = v0; o[H + u] = v1; o[2 * H + u] = v2; o[3 * H + u] = v3;
+            float* prow = dP + ((size_t)t * Bp + b) * (D * 4 * H) + (size_t)d * 4 * H;
+            prow[u] = v0; prow[H + u] = v1; prow[2 * H + u] = v2; prow[3 * H + u] = v3;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < RB * H; idx += blockDim.x) {
+            const int r = idx / H, k = idx % H;
+            float s = 0.f;
+            for (int n = 0; n < 4 * H; ++n) s = fmaf(dg[r * 4 * H + n], W[(size_t)n * H + k], s);
+            dhrec[idx] = s;
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 extern "C" int lob_lstm_rec_fwd_f32(float* P, const float* Whh, float* Y, float* Csave,
@@ -211,6 +374,26 @@ extern "C" int lob_lstm_rec_fwd_f32(float* P, const float* Whh, float* Y, float*
         if (smem > 64 * 1024) return LOB_E_SHAPE;
         if (save) hipLaunchKernelGGL((lstm_rec_fwd_generic_kernel<true>), grid, block, smem, s, P, Whh, Y, Csave, T, Bp, H);
         else      hipLaunchKernelGGL((lstm_rec_fwd_generic_kernel<false>), grid, block, smem, s, P, Whh, Y, Csave, T, Bp, H);
+    }
+    LOB_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int lob_lstm_rec_bwd_f32(const float* G, const float* Csave, const float* Whh,
+                                    const float* dY, float* dP, int T, int Bp, int H, int D,
+                                    void* stream) {
+    if (!G || !Csave || !Whh || !dY || !dP || T <= 0 || Bp <= 0 || H <= 0 || (D != 1 && D != 2)) return LOB_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (H == 128) {
+        if (Bp % 32) return LOB_E_SHAPE;
+        if ((reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(Csave) |
+             reinterpret_cast<uintptr_t>(dP)) & 15) return LOB_E_ALIGN;
+        hipLaunchKernelGGL(lstm_rec_bwd_h128_kernel, dim3(Bp / 32, D), dim3(256), 0, s, G, Csave, Whh, dY, dP, T, Bp);
+    } else {
+        const size_t smem = (size_t)6 * RB * H * sizeof(float);
+        if (smem > 64 * 1024) return LOB_E_SHAPE;
+        hipLaunchKernelGGL(lstm_rec_bwd_generic_kernel, dim3((Bp + RB - 1) / RB, D), dim3(256), smem, s,
+                           G, Csave, Whh, dY, dP, T, Bp, H);
     }
     LOB_CHECK_LAUNCH();
     return 0;

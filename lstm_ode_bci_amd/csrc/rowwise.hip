@@ -108,6 +108,157 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
         out[i] = in[i] * lob_dropout_scale(seed, i, p);
 }
 
+
+__device__ __forceinline__ float gelu_grad(float x) {
+    // d/dx [0.5 x (1 + erf(x/sqrt2))] = 0.5 (1 + erf(x/sqrt2)) + x exp(-x^2/2) / sqrt(2 pi)
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * expf(-0.5f * x * x) * 0.39894228040143267794f;
+}
+
+__global__ __launch_bounds__(256) void act_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n, int act) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = apply_act(in[i], act);
+}
+
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ pre,
+                                                      float* __restrict__ dx, size_t n, int act) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float x = pre[i];
+        float g = 1.f;
+        if (act == LOB_ACT_GELU) g = gelu_grad(x);
+        else if (act == LOB_ACT_TANH) { const float t = tanhf(x); g = 1.f - t * t; }
+        dx[i] = dy[i] * g;
+    }
+}
+
+// Backward of layernorm_act_kernel.  One wave per row; per-wave register partials of
+// dgamma / dbeta, one atomicAdd per column per wave at the end.
+__global__ __launch_bounds__(256) void layernorm_act_bwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
+    int rows, int width, float eps, int act, int remap_T, int remap_B, int remap_Bp, float drop_p, uint64_t seed) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int per = (width + 63) >> 6;
+    float dga[LN_MAX_PER_LANE], dba[LN_MAX_PER_LANE], gm[LN_MAX_PER_LANE], bt[LN_MAX_PER_LANE];
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+        const int c = lane + 64 * i;
+        dga[i] = 0.f; dba[i] = 0.f;
+        gm[i] = (i < per && c < width) ? gamma[c] : 0.f;
+        bt[i] = (i < per && c < width) ? beta[c] : 0.f;
+    }
+    const float invw = 1.0f / (float)width;
+    for (int row = wave; row < rows; row += nwaves) {
+        const float* xr = x + (size_t)row * width;
+        int orow = row;
+        if (remap_T > 0) { const int b = row / remap_T, t = row % remap_T; orow = t * remap_Bp + b; }
+        const float* dyr = dy + (size_t)orow * width;
+        float v[LN_MAX_PER_LANE], go[LN_MAX_PER_LANE];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+            const int c = lane + 64 * i;
+            const bool ok = (i < per && c < width);
+            v[i] = ok ? xr[c] : 0.f;
+            go[i] = ok ? dyr[c] : 0.f;
+            s += v[i];
+        }
+        const float mean = wave_sum(s) * invw;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+            const int c = lane + 64 * i;
+            const float dl = (i < per && c < width) ? v[i] - mean : 0.f;
+            q += dl * dl;
+        }
+        const float rstd = rsqrtf(wave_sum(q) * invw + eps);
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+            const int c = lane + 64 * i;
+            if (i < per && c < width) {
+                const float xh = (v[i] - mean) * rstd;
+                float g = go[i];
+                if (drop_p > 0.f) g *= lob_dropout_scale(seed, (uint64_t)orow * width + c, drop_p);
+                if (act == LOB_ACT_GELU) g *= gelu_grad(xh * gm[i] + bt[i]);
+                dga[i] += g * xh;
+                dba[i] += g;
+                const float dxh = g * gm[i];
+                v[i] = xh; go[i] = dxh;
+                m1 += dxh; m2 += dxh * xh;
+            } else { v[i] = 0.f; go[i] = 0.f; }
+        }
+        m1 = wave_sum(m1) * invw;
+        m2 = wave_sum(m2) * invw;
+        float* dxr = dx + (size_t)row * width;
+#pragma unroll
+        for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+            const int c = lane + 64 * i;
+            if (i < per && c < width) dxr[c] = rstd * (go[i] - m1 - v[i] * m2);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+        const int c = lane + 64 * i;
+        if (i < per && c < width) { atomicAdd(dgamma + c, dga[i]); atomicAdd(dbeta + c, dba[i]); }
+    }
+}
+
+// Backward of attn_pool_fwd_kernel, one workgroup per window.
+//   dV[t,b,:]    = a[t] * dctx[b,:]                      (the W1 path is added by a GEMM afterwards)
+//   ds[t]        = a[t] * (da[t] - sum_t a da),  da[t] = dctx . V[t,b,:]
+//   dPreU[t,b,j] = ds[t] * w2[j] * (1 - U^2);   dw2[j] += sum_t ds[t] U[t,b,j]
+__global__ __launch_bounds__(256) void attn_pool_bwd_kernel(
+    const float* __restrict__ V, const float* __restrict__ U, const float* __restrict__ attn,
+    const float* __restrict__ dctx, const float* __restrict__ w2, float* __restrict__ dV,
+    float* __restrict__ dPreU, float* __restrict__ dw2, int T, int Bp, int W, int W2) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* a = sm;            // [T]
+    float* ds = sm + T;       // [T]  (da, then ds)
+    float* dc = sm + 2 * T;   // [W]
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int t = tid; t < T; t += 256) a[t] = attn[(size_t)b * T + t];
+    for (int c = tid; c < W; c += 256) dc[c] = dctx[(size_t)b * W + c];
+    __syncthreads();
+    for (int t = wave; t < T; t += 4) {
+        const float* v = V + ((size_t)t * Bp + b) * W;
+        float s = 0.f;
+        for (int c = lane; c < W; c += 64) s = fmaf(dc[c], v[c], s);
+        s = wave_sum(s);
+        if (lane == 0) ds[t] = s;
+    }
+    __syncthreads();
+    float dot = 0.f;
+    for (int t = tid; t < T; t += 256) dot = fmaf(a[t], ds[t], dot);
+    dot = wave_sum(dot);
+    if (lane == 0) red[wave] = dot;
+    __syncthreads();
+    dot = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    for (int t = tid; t < T; t += 256) ds[t] = a[t] * (ds[t] - dot);
+    __syncthreads();
+    for (int c = tid; c < W; c += 256) {
+        const float g = dc[c];
+        float* o = dV + (size_t)b * W + c;
+        for (int t = 0; t < T; ++t) o[(size_t)t * Bp * W] = a[t] * g;
+    }
+    for (int j = tid; j < W2; j += 256) {
+        const float wj = w2[j];
+        const float* u = U + (size_t)b * W2 + j;
+        float* o = dPreU + (size_t)b * W2 + j;
+        float acc = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const float uv = u[(size_t)t * Bp * W2];
+            acc = fmaf(ds[t], uv, acc);
+            o[(size_t)t * Bp * W2] = ds[t] * wj * (1.f - uv * uv);
+        }
+        atomicAdd(dw2 + j, acc);
+    }
+}
+
 }  // namespace
 
 extern "C" int lob_dropout_f32(const float* in, float* out, int64_t n, float p, uint64_t seed, void* stream) {
@@ -151,6 +302,53 @@ extern "C" int lob_softmax_rows_f32(const float* in, float* out, int rows, int c
     if (!in || !out || rows <= 0 || cols <= 0) return LOB_E_ARG;
     hipLaunchKernelGGL(softmax_rows_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        in, out, rows, cols);
+    LOB_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int lob_act_f32(const float* in, float* out, int64_t n, int act, void* stream) {
+    if (!in || !out || n <= 0) return LOB_E_ARG;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(act_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, out, (size_t)n, act);
+    LOB_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int lob_act_bwd_f32(const float* dy, const float* pre, float* dx, int64_t n, int act, void* stream) {
+    if (!dy || !pre || !dx || n <= 0) return LOB_E_ARG;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, pre, dx, (size_t)n, act);
+    LOB_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int lob_layernorm_act_bwd_f32(const float* x, const float* gamma, const float* beta, const float* dy,
+                                         float* dx, float* dgamma, float* dbeta, int rows, int width, float eps,
+                                         int act, int remap_T, int remap_B, int remap_Bp, float drop_p,
+                                         uint64_t seed, void* stream) {
+    if (!x || !gamma || !beta || !dy || !dx || !dgamma || !dbeta || rows <= 0 || width <= 0) return LOB_E_ARG;
+    if (width > 64 * LN_MAX_PER_LANE) return LOB_E_SHAPE;
+    if (drop_p < 0.f || drop_p >= 1.f) return LOB_E_ARG;
+    if (remap_T > 0 && (remap_B <= 0 || remap_Bp < remap_B || rows != remap_T * remap_B)) return LOB_E_SHAPE;
+    int blocks = (rows + 3) / 4;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(layernorm_act_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, dy,
+                       dx, dgamma, dbeta, rows, width, eps, act, remap_T, remap_B, remap_Bp, drop_p, seed);
+    LOB_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int lob_attn_pool_bwd_f32(const float* V, const float* U, const float* attn, const float* dctx,
+                                     const float* w2, float* dV, float* dPreU, float* dw2,
+                                     int T, int B, int Bp, int W, int W2, void* stream) {
+    if (!V || !U || !attn || !dctx || !w2 || !dV || !dPreU || !dw2) return LOB_E_ARG;
+    if (T <= 0 || B <= 0 || Bp < B || W <= 0 || W2 <= 0) return LOB_E_ARG;
+    const size_t smem = ((size_t)2 * T + W) * sizeof(float);
+    if (smem > 60 * 1024) return LOB_E_SHAPE;
+    hipLaunchKernelGGL(attn_pool_bwd_kernel, dim3(B), dim3(256), smem, (hipStream_t)stream,
+                       V, U, attn, dctx, w2, dV, dPreU, dw2, T, Bp, W, W2);
     LOB_CHECK_LAUNCH();
     return 0;
 }

@@ -35,8 +35,8 @@ def ceil32(n):
     return (n + 31) // 32 * 32
 
 
-def gemm_nt(a, w, bias=None, act=ACT_NONE, out=None):
-    """out[M,N] = act(a[M,K] @ w[N,K]^T + bias)."""
+def gemm_nt(a, w, bias=None, act=ACT_NONE, out=None, accumulate=False):
+    """out[M,N] (+)= act(a[M,K] @ w[N,K]^T + bias)."""
     _chk(a, "a"); _chk(w, "w"); _chk(bias, "bias")
     M, K = a.shape
     N = w.shape[0]
@@ -44,6 +44,8 @@ def gemm_nt(a, w, bias=None, act=ACT_NONE, out=None):
     if out is None:
         out = torch.empty((M, N), device=a.device, dtype=torch.float32)
     _chk(out, "out")
+    if accumulate:
+        act = act | 0x100
     rc = _lib.lib().lob_gemm_nt_f32(_ptr(a), K, _ptr(w), K, _ptr(bias), _ptr(out), N, M, N, K, act, _stream())
     _lib.check(rc, "lob_gemm_nt_f32")
     return out
@@ -152,3 +154,72 @@ def ode_rk4(base_rates, n_points, t0, t1, substeps, *, probs=None, alpha=0.0, y0
                                     float(t1), int(substeps), _ptr(traj), _ptr(final), _ptr(pred), B, _stream())
     _lib.check(rc, "lob_ode_rk4_f64")
     return traj, final, pred
+
+
+# ---------------------------------------------------------------------------------------------
+# backward-side wrappers
+# ---------------------------------------------------------------------------------------------
+def lstm_rec_bwd(G, Cs, whh, dY, T, Bp, H, D):
+    """BPTT through one layer; returns dP[T*Bp, D*4H] (row-major)."""
+    _chk(G, "G"); _chk(Cs, "Csave"); _chk(whh, "whh"); _chk(dY, "dY")
+    assert dY.shape == (T * Bp, D * H)
+    dP = torch.empty((T * Bp, D * 4 * H), device=G.device, dtype=torch.float32)
+    rc = _lib.lib().lob_lstm_rec_bwd_f32(_ptr(G), _ptr(Cs), _ptr(whh), _ptr(dY), _ptr(dP), T, Bp, H, D, _stream())
+    _lib.check(rc, "lob_lstm_rec_bwd_f32")
+    return dP
+
+
+def colsum(a, out=None):
+    """out[N] += column sums of a[M,N] (a may be a column slice of a wider row-major tensor)."""
+    M, N = a.shape
+    assert a.stride(1) == 1
+    if out is None:
+        out = torch.zeros((N,), device=a.device, dtype=torch.float32)
+    rc = _lib.lib().lob_colsum_f32(_ptr(a), a.stride(0), M, N, _ptr(out), _stream())
+    _lib.check(rc, "lob_colsum_f32")
+    return out
+
+
+def act(x, kind):
+    _chk(x, "x")
+    out = torch.empty_like(x)
+    rc = _lib.lib().lob_act_f32(_ptr(x), _ptr(out), x.numel(), kind, _stream())
+    _lib.check(rc, "lob_act_f32")
+    return out
+
+
+def act_bwd(dy, pre, kind):
+    _chk(dy, "dy"); _chk(pre, "pre")
+    dx = torch.empty_like(pre)
+    rc = _lib.lib().lob_act_bwd_f32(_ptr(dy), _ptr(pre), _ptr(dx), pre.numel(), kind, _stream())
+    _lib.check(rc, "lob_act_bwd_f32")
+    return dx
+
+
+def layernorm_act_bwd(x, gamma, beta, dy, act=ACT_NONE, eps=1e-5, remap=None, drop_p=0.0, seed=0):
+    """Returns (dx [rows,width] in INPUT row order, dgamma, dbeta)."""
+    _chk(x, "x"); _chk(gamma, "gamma"); _chk(beta, "beta"); _chk(dy, "dy")
+    rows, width = x.shape
+    rT, rB, rBp = (0, 0, 0) if remap is None else remap
+    dx = torch.empty_like(x)
+    dg = torch.zeros_like(gamma)
+    db = torch.zeros_like(beta)
+    rc = _lib.lib().lob_layernorm_act_bwd_f32(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(dy), _ptr(dx), _ptr(dg), _ptr(db),
+                                              rows, width, eps, act, rT, rB, rBp, float(drop_p), C.c_uint64(seed),
+                                              _stream())
+    _lib.check(rc, "lob_layernorm_act_bwd_f32")
+    return dx, dg, db
+
+
+def attn_pool_bwd(v, u, attn, dctx, w2, T, B, Bp):
+    """Returns (dV [T*Bp,W], dPreU [T*Bp,W2], dw2 [W2]); pad rows are zero."""
+    _chk(v, "v"); _chk(u, "u"); _chk(attn, "attn"); _chk(dctx, "dctx"); _chk(w2, "w2")
+    W, W2 = v.shape[1], u.shape[1]
+    alloc = torch.zeros if Bp != B else torch.empty
+    dV = alloc((T * Bp, W), device=v.device, dtype=torch.float32)
+    dU = alloc((T * Bp, W2), device=v.device, dtype=torch.float32)
+    dw2 = torch.zeros((W2,), device=v.device, dtype=torch.float32)
+    rc = _lib.lib().lob_attn_pool_bwd_f32(_ptr(v), _ptr(u), _ptr(attn), _ptr(dctx), _ptr(w2), _ptr(dV), _ptr(dU),
+                                          _ptr(dw2), T, B, Bp, W, W2, _stream())
+    _lib.check(rc, "lob_attn_pool_bwd_f32")
+    return dV, dU, dw2

@@ -269,3 +269,138 @@ def test_coupled_predict_batch_goldens(dev):
                                   probs=torch.from_numpy(d["probs_" + pname]).to(dev), alpha=alpha)
         assert np.abs(tr2.cpu().numpy() - d["traj_" + pname]).max() < 1e-6
         assert np.array_equal(pd2.cpu().numpy(), d["pred_" + pname])
+
+
+# ------------------------------------------------------------------------------------------
+# backward: gradients of every parameter and of the input vs the reference (goldens + oracle)
+# ------------------------------------------------------------------------------------------
+def _grads(m, x, y, dev):
+    m.zero_grad(set_to_none=True)
+    xg = torch.from_numpy(x).to(dev).requires_grad_(True)
+    loss = torch.nn.functional.cross_entropy(m(xg), torch.from_numpy(y).to(dev))
+    loss.backward()
+    return float(loss), {k: p.grad.detach().cpu().numpy() for k, p in m.named_parameters()}, xg.grad.cpu().numpy()
+
+
+def _close(a, b, rtol=2e-4, atol=2e-6):
+    return np.abs(a - b).max() <= atol + rtol * np.abs(b).max()
+
+
+@pytest.mark.parametrize("M,N,Kc", [(128, 128, 4096), (1024, 256, 10000), (61, 128, 999), (2, 64, 37), (512, 128, 70000)])
+def test_gemm_tn_and_colsum(dev, M, N, Kc):
+    from lstm_ode_bci_amd import ops
+    rng = np.random.default_rng(M + N)
+    a = torch.from_numpy(rng.standard_normal((Kc, M), dtype=np.float32)).to(dev)
+    b = torch.from_numpy(rng.standard_normal((Kc, N), dtype=np.float32)).to(dev)
+    out = torch.zeros((M, N), device=dev)
+    ops.gemm_tn(a, b, out)
+    ref = a.cpu().double().T @ b.cpu().double()
+    assert (out.cpu().double() - ref).abs().max().item() < 3e-5 * Kc ** 0.5
+    cs = ops.colsum(a).cpu().double()
+    assert (cs - a.cpu().double().sum(0)).abs().max().item() < 3e-5 * Kc ** 0.5
+
+
+@pytest.mark.parametrize("L", [1, 3])
+@pytest.mark.parametrize("bi", [0, 1])
+def test_backward_tiny_goldens(dev, L, bi):
+    d = np.load(os.path.join(GOLDEN, f"g1_tiny_L{L}_bi{bi}.npz"))
+    sd = {k[2:]: d[k] for k in d.files if k.startswith("w:")}
+    m = _model(sd, 5, 8, L, bool(bi), dev)
+    loss, gp, gx = _grads(m, d["x"], d["y"], dev)
+    assert abs(loss - float(d["loss"])) < 1e-5
+    assert _close(gx, d["grad_x"]), np.abs(gx - d["grad_x"]).max()
+    for k, g in gp.items():
+        assert _close(g, d["g:" + k]), (k, np.abs(g - d["g:" + k]).max())
+
+
+def test_backward_full_size_vs_reference(dev):
+    from oracle import torch_cpu_path as TP
+    d = np.load(os.path.join(GOLDEN, "g2_full_H128.npz"))
+    sd = syn.make_state_dict(61, 128, 3, 2, True)
+    x, y = syn.make_windows(8)
+    m = _model(sd, 61, 128, 3, True, dev)
+    loss, gp, gx = _grads(m, x, y, dev)
+    assert abs(loss - float(d["loss"])) < 1e-5
+    names = [str(n) for n in d["grad_names"]]
+    l2 = np.array([np.sqrt((gp[k].astype(np.float64) ** 2).sum()) for k in names])
+    assert np.allclose(l2, d["grad_l2"], rtol=5e-4, atol=1e-8), np.abs(l2 / np.maximum(d["grad_l2"], 1e-30) - 1).max()
+    assert _close(gx[:, ::32], d["grad_x_slice"])
+    assert _close(gp["classifier.6.weight"], d["grad_cls6_w"])
+    assert _close(gp["lstm.weight_hh_l2"][::64, ::16], d["grad_whh_l2_slice"])
+    assert _close(gp["lstm.weight_ih_l0_reverse"][::64, ::16], d["grad_wih_l0r_slice"])
+    assert _close(gp["input_proj.0.weight"][::16], d["grad_proj_w_slice"])
+    # every element of every gradient against the oracle's autograd (ragged batch: 37 windows)
+    x2, y2 = syn.make_windows(37, seed=3)
+    ref = TP.build(sd, 61, 128)
+    rl, rgp, rgx = TP.loss_and_grads(ref, torch.from_numpy(x2), torch.from_numpy(y2))
+    l2_, gp2, gx2 = _grads(m, x2, y2, dev)
+    assert abs(l2_ - rl) < 1e-5
+    assert _close(gx2, rgx)
+    for k in rgp:
+        assert _close(gp2[k], rgp[k]), (k, np.abs(gp2[k] - rgp[k]).max(), np.abs(rgp[k]).max())
+
+
+def test_backward_retained_graph_and_input_grads(dev):
+    """07_explainability.py:242-257: one forward, B backward calls on a retained graph, reading X.grad."""
+    sd = syn.make_state_dict(61, 128, 3, 2, True)
+    x, _ = syn.make_windows(4, 64, 61, seed=2)
+    m = _model(sd, 61, 128, 3, True, dev)
+    xg = torch.from_numpy(x).to(dev).requires_grad_(True)
+    out = m(xg)
+    grads = []
+    for i in range(4):
+        m.zero_grad()
+        if xg.grad is not None:
+            xg.grad.zero_()
+        out[i, 1].backward(retain_graph=True)
+        grads.append(xg.grad.clone())
+    for i in range(4):          # window i's logit depends on window i only
+        for j in range(4):
+            if i != j:
+                assert grads[i][j].abs().max().item() == 0.0
+        assert grads[i][i].abs().max().item() > 0
+    m.zero_grad(); xg.grad.zero_()
+    out[0, 1].backward(retain_graph=True)
+    assert torch.equal(xg.grad, grads[0])            # saved activations were not modified
+
+
+def test_train_mode_dropout(dev):
+    sd = syn.make_state_dict(61, 128, 3, 2, True)
+    x, y = syn.make_windows(16, 32, 61, seed=4)
+    m = _model(sd, 61, 128, 3, True, dev).train()
+    torch.manual_seed(123)
+    l1, g1, gx1 = _grads(m, x, y, dev)
+    torch.manual_seed(123)
+    l2, g2, gx2 = _grads(m, x, y, dev)
+    assert l1 == l2 and np.array_equal(gx1, gx2)      # same torch seed -> same masks
+    l3, _, _ = _grads(m, x, y, dev)
+    assert l3 != l1                                  # fresh masks on the next call
+    m.eval()
+    l4, _, _ = _grads(m, x, y, dev)
+    assert l4 != l1
+    # the masks keep ~ (1-p) of the elements, scaled by 1/(1-p)
+    from lstm_ode_bci_amd import ops
+    ones = torch.ones(1 << 20, device=dev)
+    dr = ops.dropout(ones, 0.4, 777)
+    keep = (dr > 0).float().mean().item()
+    assert abs(keep - 0.6) < 5e-3 and abs(dr.max().item() - 1 / 0.6) < 1e-6
+    # finite-difference check of the train-mode backward under a FIXED seed (dropout included)
+    from lstm_ode_bci_amd.autograd import _LobModelFn, _collect
+    cfg = (3, 2, 128, (0.2, 0.4, 0.4), 99)
+    xs = torch.from_numpy(x[:4]).to(dev)
+    ps = _collect(m)
+    w = ps[-2]                                        # classifier.6.weight
+    yy = torch.from_numpy(y[:4]).to(dev)
+
+    def f():
+        return torch.nn.functional.cross_entropy(_LobModelFn.apply(xs, cfg, *ps)[0], yy)
+    m.zero_grad()
+    f().backward()
+    ga = w.grad[0, 3].item()
+    with torch.no_grad():
+        w[0, 3] += 1e-2
+        lp = f().item()
+        w[0, 3] -= 2e-2
+        lm = f().item()
+        w[0, 3] += 1e-2
+    assert abs((lp - lm) / 2e-2 - ga) < 2e-3 * max(1.0, abs(ga))
