@@ -1,0 +1,59 @@
+"""Multi-GPU execution of the coupled path: one process per GPU, windows sharded
+contiguously over ranks, no data-path collective (every window is independent through
+04_lstm_model.py:206-222 and 06_lstm_ode_integration.py:372-401), ONE all-gather at the end
+to collate per-window outputs (RCCL over xGMI when the backend is "nccl").
+
+The reference is single-process; this is the only collective the build adds.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n, world, rank):
+    """Contiguous balanced split of n windows: the first n % world ranks get one extra."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def all_gather_rows(local, n_total, group=None):
+    """Collate per-rank row blocks (split as in ``shard_bounds``) into the full (n_total, ...)
+    tensor on every rank.  Uneven shards are padded to the largest shard for the collective."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return local
+    per = (n_total + world - 1) // world
+    pad = per - local.shape[0]
+    buf = local if pad == 0 else torch.cat([local, local.new_zeros((pad,) + tuple(local.shape[1:]))], 0)
+    out = local.new_empty((world * per,) + tuple(local.shape[1:]))
+    dist.all_gather_into_tensor(out, buf.contiguous(), group=group)
+    if n_total % world == 0:
+        return out
+    parts = []
+    for r in range(world):
+        lo, hi = shard_bounds(n_total, world, r)
+        parts.append(out[r * per:r * per + (hi - lo)])
+    return torch.cat(parts, 0)
+
+
+def sharded_apply(X, fn, group=None):
+    """Run ``fn(X[lo:hi]) -> tuple of per-window tensors`` on this rank's shard and collate
+    every output over the ranks.  With one rank this is just ``fn(X)``."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return fn(X)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = len(X)
+    lo, hi = shard_bounds(n, world, rank)
+    outs = fn(X[lo:hi])
+    return tuple(None if o is None else all_gather_rows(o, n, group) for o in outs)
+
+
+def predict_batch_sharded(integ, X_batch, forecast_steps=20, batch_size=512, gather_trajectories=True, group=None):
+    """``LSTMODEIntegration.predict_batch`` over all ranks of the default process group.
+    Returns device tensors (trajectories (N,steps,3) f64 | None, probs (N,2) f32, predictions (N,) i64),
+    identical on every rank and bit-identical to the single-GPU result."""
+    def fn(Xs):
+        return integ.predict_batch_device(Xs, forecast_steps, batch_size, want_traj=gather_trajectories)
+    return sharded_apply(X_batch, fn, group)

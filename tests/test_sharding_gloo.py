@@ -1,0 +1,53 @@
+"""CPU, world_size 2, gloo: the N > 1 path (shard -> compute -> all-gather collate) returns
+exactly what one process returns.  The per-shard compute is a deterministic stand-in (the real
+one needs a GPU); everything else is the product code path of lstm_ode_bci_amd.sharding."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _fake_compute(X):
+    s = X.reshape(len(X), -1).double().sum(1)
+    probs = torch.stack([torch.sigmoid(s), 1 - torch.sigmoid(s)], 1).float()
+    traj = (s[:, None, None] * torch.arange(1, 7, dtype=torch.float64).reshape(1, 2, 3))
+    pred = (s > 0).long()
+    return traj, probs, pred
+
+
+def _worker(rank, world, port, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lstm_ode_bci_amd import sharding
+    X = torch.from_numpy(np.random.default_rng(0).standard_normal((n, 4, 3)).astype(np.float32))
+    out = sharding.sharded_apply(X, _fake_compute)
+    ref = _fake_compute(X)
+    ok = all(torch.equal(a, b) for a, b in zip(out, ref))
+    lo, hi = sharding.shard_bounds(n, world, rank)
+    q.put((rank, ok, hi - lo))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [10, 7])
+def test_two_ranks_collate_bit_identical(n):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
+    assert sum(cnt for _, _, cnt in res) == n
