@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=4096, help="windows per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--forecast-steps", type=int, default=300)
+    ap.add_argument("--precision", default=None, choices=["fp32", "mixed"],
+                    help="mixed = bf16 MFMA inputs for the gate GEMMs under autocast, fp32 recurrence/accumulate "
+                         "(BASELINE.json configs[2]); default: mixed for train, fp32 otherwise")
     return ap.parse_args()
 
 
@@ -143,6 +146,7 @@ def main():
     from lstm_ode_bci_amd import synthetic as syn
 
     mode = a.mode or ("train" if have_backward() else "fwd")
+    precision = a.precision or ("mixed" if mode == "train" else "fp32")
     B = a.batch
     model, sd = build_model(dev)
     # rank r owns global windows [r*B, (r+1)*B): independent shards, no data-path collective
@@ -155,12 +159,16 @@ def main():
     params = [p for p in model.parameters()]
 
     def step():
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(precision == "mixed")):
+            _step()
+
+    def _step():
         if mode == "train":
             model.train()
             for p in params:
                 p.grad = None
             logits = model(x)
-            loss = torch.nn.functional.cross_entropy(logits, y, weight=class_w)
+            loss = torch.nn.functional.cross_entropy(logits.float(), y, weight=class_w)
             loss.backward()
             if world > 1:
                 flat = torch.cat([p.grad.reshape(-1) for p in params])
@@ -209,11 +217,12 @@ def main():
                        "coupled": "eeg_windows_per_sec_fwd_ode"}[mode],
             "value": value, "unit": "windows/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BiLSTM(3x128)+attn {mode}, (T=256,C=61) windows, B={B}/GPU, fp32 exact-MFMA"
+            "vs_baseline": None, "dtype": "f32" if precision == "fp32" else "bf16", "data": "synthetic",
+            "config": {"workload": f"BiLSTM(3x128)+attn {mode}, (T=256,C=61) windows, B={B}/GPU, " + ("fp32 exact-MFMA" if precision == "fp32" else
+                                                       "bf16 gate GEMMs + fp32 recurrence/accumulate (autocast)")
                                    + (f", RK4 ODE {a.forecast_steps} points" if mode == "coupled" else ""),
                        "batch_per_gpu": B, "global_batch": world * B, "seq_len": T, "channels": C,
-                       "hidden": H, "layers": L, "mode": mode,
+                       "hidden": H, "layers": L, "mode": mode, "precision": precision,
                        "collective": ("none" if world == 1 else
                                       ("all_reduce(grads 4.55MB)" if mode == "train" else "all_gather(logits)"))},
             "gate_gemm_tflops_effective": value * flop_per_window / 1e12,

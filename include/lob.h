@@ -87,16 +87,36 @@ int lob_lstm_rec_fwd_f32(float* P, const float* Whh, float* Y, float* Csave,
  *   G      activated gates saved by the forward (save = 1), same layout as P; READ-ONLY
  *   Csave  cell states saved by the forward; READ-ONLY (backward is re-entrant, 07:254)
  *   dY     [T][Bp][D*H] gradient w.r.t. the layer output
- *   dP     [T*Bp][D*4H] ROW-MAJOR gradient w.r.t. the gate pre-activations (output)
+ *   dP     [T*Bp][D*4H] ROW-MAJOR gradient w.r.t. the gate pre-activations (output), fp32 or bf16
  * dW_ih = dP^T X, dW_hh[d] = dP[:,d]^T H_prev, db = colsum(dP) (lob_gemm_tn_f32,
  * lob_colsum_f32) and dX = dP W_ih (lob_gemm_nt_f32 with the transposed weight) follow.
  * (torch autograd of nn.LSTM; training step 04_lstm_model.py:482-512.)                */
 int lob_lstm_rec_bwd_f32(const float* G, const float* Csave, const float* Whh,
-                         const float* dY, float* dP, int T, int Bp, int H, int D,
-                         void* stream);
+                         const float* dY, void* dP, int dp_bf16, float* dbias,
+                         int T, int Bp, int H, int D, void* stream);
+/*   dp_bf16  1: dP is written as bf16 (mixed-precision mode: its consumers are bf16 MFMA GEMMs)
+ *   dbias    [D*4H] bias gradient, accumulated in-kernel with fp32 atomics (initialise it); may be
+ *            NULL; must be NULL on the generic (H != 128) path -- use lob_colsum_f32/_bf16 there. */
 
 /* out[n] += sum_m A[m][n]  (bias gradients; fp32 atomics, `out` must be initialised). */
 int lob_colsum_f32(const float* A, int lda, int M, int N, float* out, void* stream);
+
+int lob_colsum_bf16(const void* A, int lda, int M, int N, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Mixed-precision variants (BASELINE.json configs[2] "bf16 gate-GEMMs + fp32 recurrence"; the
+ * reference's training loop runs under autocast, 04_lstm_model.py:487): operands are rounded to
+ * bf16 on their way into LDS, products are exact, accumulation and outputs are fp32
+ * (v_mfma_f32_32x32x16_bf16).  `a_bf16` / `b_bf16` = 1 when that operand is stored as bf16 in HBM
+ * (dP from lob_lstm_rec_bwd_f32), 0 for fp32 storage.  Shapes as the _f32 entry points; K % 8 == 0
+ * and 16-byte aligned bases are required (LOB_E_ALIGN otherwise: use the fp32 entry point).
+ * ---------------------------------------------------------------------------------- */
+int lob_gemm_nt_bf16(const void* A, int a_bf16, int lda, const float* W, int ldw, const float* bias,
+                     float* C, int ldc, int M, int N, int K, int act, void* stream);
+int lob_gate_gemm_x_bf16(const float* X, int ldx, const float* Wih, const float* bias,
+                         float* P, int T, int Bp, int H, int D, int K, void* stream);
+int lob_gemm_tn_bf16(const void* A, int a_bf16, int lda, const void* B, int b_bf16, int ldb,
+                     float* C, int ldc, int M, int N, int Kc, void* stream);
 
 /* Element-wise activation and its backward (dx = dy * act'(pre)); classifier GELUs
  * (04_lstm_model.py:198, 201) in training mode.                                       */

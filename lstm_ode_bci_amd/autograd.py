@@ -43,7 +43,7 @@ def _seed(seed, k):
 
 def _forward_impl(x, ps, cfg, save):
     """Returns (logits, attn, saved-dict or None)."""
-    L, D, H, (p_in, p_lstm, p_cls), seed = cfg
+    L, D, H, (p_in, p_lstm, p_cls), seed, mixed = cfg
     B, T, C = x.shape
     Bp = ceil32(B)
     W = H * D
@@ -65,7 +65,7 @@ def _forward_impl(x, ps, cfg, save):
         wih = torch.cat([d[0] for d in dirs], 0) if D > 1 else dirs[0][0]
         whh = torch.stack([d[1] for d in dirs], 0)
         bias = torch.cat([d[2] + d[3] for d in dirs], 0)
-        P = ops.gate_gemm_x(inp, wih, bias, T, Bp, H, D, frag)
+        P = ops.gate_gemm_x(inp, wih, bias, T, Bp, H, D, frag, mixed=mixed)
         Y, Cs = ops.lstm_rec_fwd(P, whh, T, Bp, H, D, save)
         nxt = Y
         if layer + 1 < L and p_lstm > 0:
@@ -77,7 +77,7 @@ def _forward_impl(x, ps, cfg, save):
     a0w, a0b, a2w, a2b = next(it), next(it), next(it), next(it)
     c0w, c0b, c3w, c3b, c6w, c6b = (next(it) for _ in range(6))
     v = ops.layernorm_act(inp, ln_g, ln_b)                                   # (T*Bp, W)
-    u = ops.gemm_nt(v, a0w, a0b, act=ACT_TANH)                               # (T*Bp, W/2)
+    u = ops.gemm_nt(v, a0w, a0b, act=ACT_TANH, mixed=mixed)                  # (T*Bp, W/2)
     ctx, attn = ops.attn_pool_fwd(v, u, a2w.reshape(-1), a2b, T, B, Bp)
     if save:       # keep the pre-activations of the two classifier GELUs for their backward
         z1p = ops.gemm_nt(ctx, c0w, c0b)
@@ -123,7 +123,12 @@ def lob_forward(model, x, drops, seed):
     if not x.is_cuda:
         raise ops._lib.LobError("EnhancedLSTMModel.forward: input must be on the GPU "
                                 "(the MI355X path has no CPU fallback)")
-    cfg = (model.num_layers, model.num_directions, model.hidden_size, tuple(float(d) for d in drops), int(seed))
+    # mixed precision (bf16 MFMA inputs for the gate / attention GEMMs, fp32 everything else) when the
+    # caller runs the model under autocast, as the reference's training and inference loops do on a GPU
+    # (04_lstm_model.py:487, 06_lstm_ode_integration.py:349), or when model.gate_gemm_dtype == "bf16".
+    mixed = bool(torch.is_autocast_enabled("cuda")) or getattr(model, "gate_gemm_dtype", "f32") == "bf16"
+    cfg = (model.num_layers, model.num_directions, model.hidden_size, tuple(float(d) for d in drops), int(seed),
+           mixed)
     with torch.autocast(device_type="cuda", enabled=False):
         return _LobModelFn.apply(x, cfg, *_collect(model))
 

@@ -30,7 +30,7 @@ def _linear_bwd(dy, x, w, need_dx=True):
 def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad):
     if sv is None:
         raise RuntimeError("backward called on a forward that ran without grad tracking")
-    L, D, H, (p_in, p_lstm, p_cls), seed = cfg
+    L, D, H, (p_in, p_lstm, p_cls), seed, mixed = cfg
     B, T, C = x_shape
     Bp = ceil32(B)
     n = len(ps)
@@ -53,9 +53,9 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad):
     g[i_a2w] = dw2.reshape(1, -1)
     g[i_a2b] = torch.zeros_like(ps[i_a2b])            # b2 cancels in the softmax: exactly 0
     g[i_a0w] = torch.zeros_like(ps[i_a0w])
-    ops.gemm_tn(dU, v, g[i_a0w])
+    ops.gemm_tn(dU, v, g[i_a0w], mixed=mixed)
     g[i_a0b] = ops.colsum(dU)
-    ops.gemm_nt(dU, _t(ps[i_a0w]), out=dV, accumulate=True)
+    ops.gemm_nt(dU, _t(ps[i_a0w]), out=dV, accumulate=True, mixed=mixed)
 
     # ---- post-LSTM LayerNorm (04:212)
     dY, g[i_ln], g[i_ln + 1] = ops.layernorm_act_bwd(sv["ylast"], ps[i_ln], ps[i_ln + 1], dV)
@@ -65,11 +65,10 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad):
         lay = sv["layers"][layer]
         if layer + 1 < L and p_lstm > 0:
             dY = ops.dropout(dY, p_lstm, _seed(seed, 10 + layer))
-        dP = ops.lstm_rec_bwd(lay["G"], lay["C"], lay["whh"], dY, T, Bp, H, D)
+        dP, dbias = ops.lstm_rec_bwd(lay["G"], lay["C"], lay["whh"], dY, T, Bp, H, D, dp_bf16=mixed)
         inp, Y, wih = lay["inp"], lay["Y"], lay["wih"]
         dwih = torch.zeros_like(wih)
-        ops.gemm_tn(dP, inp, dwih)
-        dbias = ops.colsum(dP)
+        ops.gemm_tn(dP, inp, dwih, mixed=mixed)
         base = 4 + layer * 4 * D
         for d in range(D):
             dwhh = torch.zeros_like(ps[base + 4 * d + 1])
@@ -77,14 +76,14 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad):
                 a_sl = dP[:, d * 4 * H:(d + 1) * 4 * H]
                 y_sl = Y[:, d * H:(d + 1) * H]
                 if d == 0:      # h_prev(t) = h(t-1)
-                    ops.gemm_tn(a_sl[Bp:], y_sl[:(T - 1) * Bp], dwhh)
+                    ops.gemm_tn(a_sl[Bp:], y_sl[:(T - 1) * Bp], dwhh, mixed=mixed)
                 else:           # reverse direction: h_prev(t) = h(t+1)
-                    ops.gemm_tn(a_sl[:(T - 1) * Bp], y_sl[Bp:], dwhh)
+                    ops.gemm_tn(a_sl[:(T - 1) * Bp], y_sl[Bp:], dwhh, mixed=mixed)
             g[base + 4 * d + 0] = dwih[d * 4 * H:(d + 1) * 4 * H]
             g[base + 4 * d + 1] = dwhh
             g[base + 4 * d + 2] = dbias[d * 4 * H:(d + 1) * 4 * H]
             g[base + 4 * d + 3] = dbias[d * 4 * H:(d + 1) * 4 * H]
-        dY = ops.gemm_nt(dP, _t(wih))
+        dY = ops.gemm_nt(dP, _t(wih), mixed=mixed)
         del dP
 
     # ---- input projection: Linear -> LayerNorm -> GELU -> Dropout (04:173-178)

@@ -1,0 +1,404 @@
+// bf16-input / fp32-accumulate MFMA GEMMs (v_mfma_f32_32x32x16_bf16) for the mixed-precision
+// mode (BASELINE.json configs[2]: "bf16 gate-GEMMs + fp32 recurrence"; the reference's own
+// training loop runs the model under autocast, 04_lstm_model.py:487).
+//
+// Operands live in HBM as fp32 (activations, weights) or bf16 (dP written by the BPTT kernel)
+// and are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) while being staged into LDS; products are
+// exact, accumulation is fp32.  At 16x the fp32 MFMA rate these kernels are HBM-bound
+// (arithmetic intensity ~110 FLOP/B vs a machine balance of ~400): what matters is coalesced
+// 16-B global accesses and enough of them in flight, not the MFMA schedule.
+//
+// Tiles: 128x128 output per 256-thread workgroup (4 waves as 2x2, 2x2 32x32 accumulators each),
+// contraction in steps of 64 through double-buffered LDS; LDS rows are 64 bf16 + 16 B pad =
+// 144 B = 9 x 16-B slots (odd), so a wave's ds_read_b128 fragment reads are conflict-free.
+#include "lob_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int TM = 128, TN_ = 128, TK = 64;
+constexpr int LDB = 72;                 // LDS row stride in bf16 elements (144 B)
+
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+struct NTArgs {
+    const void* A; const float* W; const float* bias; float* C;
+    int lda, ldw, ldc, M, N, K, act, accumulate;
+    int T, Bp, H, D;     // fragment epilogue
+};
+
+// ---- staging: [rows][64 k] tile, source rows are K-contiguous ----------------------------
+// fp32 source: thread -> row = tid/16 + 16 i (i<8), 4 floats at k = (tid%16)*4
+__device__ __forceinline__ void ld_rows_f32(const float* __restrict__ G, int ld, int row0, int rows,
+                                            int k0, int K, int tid, f32x4 (&r)[8]) {
+    const int rr = tid >> 4, c4 = (tid & 15) * 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = row0 + rr + 16 * i, k = k0 + c4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < rows && k < K) v = *reinterpret_cast<const f32x4*>(G + (size_t)row * ld + k);
+        r[i] = v;
+    }
+}
+__device__ __forceinline__ void st_rows_f32(__bf16* S, int tid, const f32x4 (&r)[8]) {
+    const int rr = tid >> 4, c4 = (tid & 15) * 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        bf16x4 h = {(__bf16)r[i][0], (__bf16)r[i][1], (__bf16)r[i][2], (__bf16)r[i][3]};
+        *reinterpret_cast<bf16x4*>(S + (rr + 16 * i) * LDB + c4) = h;
+    }
+}
+// bf16 source: thread -> row = tid/8 + 32 i (i<4), 8 bf16 at k = (tid%8)*8
+__device__ __forceinline__ void ld_rows_bf16(const __bf16* __restrict__ G, int ld, int row0, int rows,
+                                             int k0, int K, int tid, bf16x8 (&r)[4]) {
+    const int rr = tid >> 3, c8 = (tid & 7) * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = row0 + rr + 32 * i, k = k0 + c8;
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (__bf16)0.f;
+        if (row < rows && k < K) v = *reinterpret_cast<const bf16x8*>(G + (size_t)row * ld + k);
+        r[i] = v;
+    }
+}
+__device__ __forceinline__ void st_rows_bf16(__bf16* S, int tid, const bf16x8 (&r)[4]) {
+    const int rr = tid >> 3, c8 = (tid & 7) * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<bf16x8*>(S + (rr + 32 * i) * LDB + c8) = r[i];
+}
+
+__device__ __forceinline__ void mma_tile(const __bf16* As, const __bf16* Bs, int wr, int wc, int lane,
+                                         f32x16 (&acc)[2][2]) {
+    const __bf16* ap = As + (64 * wr + (lane & 31)) * LDB + 8 * (lane >> 5);
+    const __bf16* bp = Bs + (64 * wc + (lane & 31)) * LDB + 8 * (lane >> 5);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ap + 16 * s);
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ap + 32 * LDB + 16 * s);
+        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(bp + 16 * s);
+        const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(bp + 32 * LDB + 16 * s);
+        acc[0][0] = mfma_bf16(a0, b0, acc[0][0]);
+        acc[0][1] = mfma_bf16(a0, b1, acc[0][1]);
+        acc[1][0] = mfma_bf16(a1, b0, acc[1][0]);
+        acc[1][1] = mfma_bf16(a1, b1, acc[1][1]);
+    }
+}
+
+template <bool A_BF16, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(NTArgs g) {
+    __shared__ __attribute__((aligned(16))) __bf16 lds[2 * 2 * TM * LDB];
+    __bf16* As = lds;
+    __bf16* Ws = lds + 2 * TM * LDB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int ntn = (g.N + TN_ - 1) / TN_;
+    const int m0 = (blockIdx.x / ntn) * TM, n0 = (blockIdx.x % ntn) * TN_;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 ra[8], rw[8];
+    bf16x8 rab[4];
+    const int nk = (g.K + TK - 1) / TK;
+    if (A_BF16) ld_rows_bf16(reinterpret_cast<const __bf16*>(g.A), g.lda, m0, g.M, 0, g.K, tid, rab);
+    else        ld_rows_f32(reinterpret_cast<const float*>(g.A), g.lda, m0, g.M, 0, g.K, tid, ra);
+    ld_rows_f32(g.W, g.ldw, n0, g.N, 0, g.K, tid, rw);
+    if (A_BF16) st_rows_bf16(As, tid, rab); else st_rows_f32(As, tid, ra);
+    st_rows_f32(Ws, tid, rw);
+    __syncthreads();
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) {
+            if (A_BF16) ld_rows_bf16(reinterpret_cast<const __bf16*>(g.A), g.lda, m0, g.M, (kt + 1) * TK, g.K, tid, rab);
+            else        ld_rows_f32(reinterpret_cast<const float*>(g.A), g.lda, m0, g.M, (kt + 1) * TK, g.K, tid, ra);
+            ld_rows_f32(g.W, g.ldw, n0, g.N, (kt + 1) * TK, g.K, tid, rw);
+        }
+        mma_tile(As + buf * TM * LDB, Ws + buf * TM * LDB, wr, wc, lane, acc);
+        if (kt + 1 < nk) {
+            if (A_BF16) st_rows_bf16(As + (buf ^ 1) * TM * LDB, tid, rab); else st_rows_f32(As + (buf ^ 1) * TM * LDB, tid, ra);
+            st_rows_f32(Ws + (buf ^ 1) * TM * LDB, tid, rw);
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    if (EPI == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + 64 * wc + 32 * j + (lane & 31);
+                if (col >= g.N) continue;
+                const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + 64 * wr + 32 * i + acc_row(r, lane);
+                    if (row < g.M) {
+                        float* dst = g.C + (size_t)row * g.ldc + col;
+                        const float val = apply_act(acc[i][j][r] + bv, g.act);
+                        *dst = g.accumulate ? *dst + val : val;
+                    }
+                }
+            }
+    } else {
+        const int NBT = g.Bp >> 5, NW = g.H >> 5, H4 = 4 * g.H;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int mrow = m0 + 64 * wr + 32 * i;
+            if (mrow >= g.M) continue;
+            const int t = mrow / g.Bp, bt = (mrow % g.Bp) >> 5;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int ncol = n0 + 64 * wc + 32 * j;
+                if (ncol >= g.N) continue;
+                const int d = ncol / H4, gg = (ncol % H4) / g.H, w = (ncol % g.H) >> 5;
+                const float bv = g.bias ? g.bias[ncol + (lane & 31)] : 0.f;
+                float* dst = g.C + ((((size_t)(d * g.T + t) * NBT + bt) * NW + w) * 4 + gg) * 1024 + lane * 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v = {acc[i][j][4 * q + 0] + bv, acc[i][j][4 * q + 1] + bv,
+                               acc[i][j][4 * q + 2] + bv, acc[i][j][4 * q + 3] + bv};
+                    *reinterpret_cast<f32x4*>(dst + q * 256) = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// C[M,N] += A[Kc,M]^T B[Kc,N]  (weight gradients), bf16 MFMA.  The contraction index is the ROW
+// index of both sources, i.e. both operands are "K-major".  The source tiles are copied into LDS
+// as they are ([k][m], 16-B coalesced global loads, 8/16-B LDS stores) and the MFMA fragments
+// (8 consecutive k for one m per lane) are produced by gfx950's transposing LDS read
+// ds_read_b64_tr_b16: per 16-lane group it reads a 4(k) x 16(m) block and hands lane i column i.
+// LDS rows are 128 bf16 + 32 pad = 320 B: the four k-rows of a block then sit 64 B apart modulo
+// the 256-B bank row and the 32 lanes of a half-wave cover it exactly once (conflict-free).
+// ------------------------------------------------------------------------------------------
+constexpr int TK2 = 32;      // contraction rows per stage
+constexpr int LDK = 160;     // LDS row stride in bf16 elements (320 B)
+
+struct TNArgs {
+    const void* A; const void* B; float* C;
+    int lda, ldb, ldc, M, N, Kc, kchunk, tiles;
+};
+
+// fp32 source: thread -> k = tid/32 + 8 i (i<4), 4 floats at col (tid%32)*4
+__device__ __forceinline__ void ldk_f32(const float* __restrict__ G, int ld, int k0, int kend, int c0, int cols,
+                                        int tid, f32x4 (&r)[4]) {
+    const int kk = tid >> 5, c4 = (tid & 31) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = k0 + kk + 8 * i, c = c0 + c4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k < kend && c < cols) v = *reinterpret_cast<const f32x4*>(G + (size_t)k * ld + c);
+        r[i] = v;
+    }
+}
+__device__ __forceinline__ void stk_f32(__bf16* S, int tid, const f32x4 (&r)[4]) {
+    const int kk = tid >> 5, c4 = (tid & 31) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        bf16x4 h = {(__bf16)r[i][0], (__bf16)r[i][1], (__bf16)r[i][2], (__bf16)r[i][3]};
+        *reinterpret_cast<bf16x4*>(S + (kk + 8 * i) * LDK + c4) = h;
+    }
+}
+// bf16 source: thread -> k = tid/16 + 16 i (i<2), 8 bf16 at col (tid%16)*8
+__device__ __forceinline__ void ldk_bf16(const __bf16* __restrict__ G, int ld, int k0, int kend, int c0, int cols,
+                                         int tid, bf16x8 (&r)[2]) {
+    const int kk = tid >> 4, c8 = (tid & 15) * 8;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int k = k0 + kk + 16 * i, c = c0 + c8;
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (__bf16)0.f;
+        if (k < kend && c < cols) v = *reinterpret_cast<const bf16x8*>(G + (size_t)k * ld + c);
+        r[i] = v;
+    }
+}
+__device__ __forceinline__ void stk_bf16(__bf16* S, int tid, const bf16x8 (&r)[2]) {
+    const int kk = tid >> 4, c8 = (tid & 15) * 8;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<bf16x8*>(S + (kk + 16 * i) * LDK + c8) = r[i];
+}
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+// fragment of the 32-column block starting at column `cb`, k-step s (16 rows) of a [k][col] LDS image
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16* S, int cb, int s, int lane) {
+    const int h = lane >> 5, mh = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
+    const __bf16* a = S + (16 * s + 8 * h + q) * LDK + cb + 16 * mh + 4 * p;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a + 4 * LDK));
+    bf16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return f;
+}
+
+template <bool A_BF16, bool B_BF16>
+__global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(TNArgs g) {
+    __shared__ __attribute__((aligned(16))) __bf16 lds[2 * 2 * TK2 * LDK];
+    __bf16* As = lds;
+    __bf16* Bs = lds + 2 * TK2 * LDK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int ntn = (g.N + 127) / 128;
+    // workgroups of one contraction chunk are 8 apart in blockIdx -> they share an XCD (L2) and run
+    // together, so the source tiles they have in common are fetched from HBM once (speed only).
+    const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+    const int tile = rest % g.tiles, chunk = (rest / g.tiles) * 8 + xcd;
+    const int m0 = (tile / ntn) * 128, n0 = (tile % ntn) * 128;
+    const int kbeg = chunk * g.kchunk, kend = min(g.Kc, kbeg + g.kchunk);
+    if (kbeg >= kend) return;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 raf[4], rbf[4];
+    bf16x8 rah[2], rbh[2];
+    auto load = [&](int k0) {
+        if (A_BF16) ldk_bf16(reinterpret_cast<const __bf16*>(g.A), g.lda, k0, kend, m0, g.M, tid, rah);
+        else        ldk_f32(reinterpret_cast<const float*>(g.A), g.lda, k0, kend, m0, g.M, tid, raf);
+        if (B_BF16) ldk_bf16(reinterpret_cast<const __bf16*>(g.B), g.ldb, k0, kend, n0, g.N, tid, rbh);
+        else        ldk_f32(reinterpret_cast<const float*>(g.B), g.ldb, k0, kend, n0, g.N, tid, rbf);
+    };
+    auto store = [&](int b) {
+        if (A_BF16) stk_bf16(As + b * TK2 * LDK, tid, rah); else stk_f32(As + b * TK2 * LDK, tid, raf);
+        if (B_BF16) stk_bf16(Bs + b * TK2 * LDK, tid, rbh); else stk_f32(Bs + b * TK2 * LDK, tid, rbf);
+    };
+    load(kbeg);
+    store(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += TK2) {
+        const bool more = k0 + TK2 < kend;
+        if (more) load(k0 + TK2);
+        const __bf16* as = As + buf * TK2 * LDK;
+        const __bf16* bs = Bs + buf * TK2 * LDK;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const bf16x8 a0 = tr_frag(as, 64 * wr, s, lane), a1 = tr_frag(as, 64 * wr + 32, s, lane);
+            const bf16x8 b0 = tr_frag(bs, 64 * wc, s, lane), b1 = tr_frag(bs, 64 * wc + 32, s, lane);
+            acc[0][0] = mfma_bf16(a0, b0, acc[0][0]);
+            acc[0][1] = mfma_bf16(a0, b1, acc[0][1]);
+            acc[1][0] = mfma_bf16(a1, b0, acc[1][0]);
+            acc[1][1] = mfma_bf16(a1, b1, acc[1][1]);
+        }
+        if (more) store(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + 64 * wc + 32 * j + (lane & 31);
+            if (col >= g.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + 64 * wr + 32 * i + acc_row(r, lane);
+                if (row < g.M) atomicAdd(g.C + (size_t)row * g.ldc + col, acc[i][j][r]);
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const __bf16* __restrict__ A, int lda, int M, int N,
+                                                          int rows_per_block, float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int ncb = (N + 63) / 64;
+    const int cb = blockIdx.x % ncb, rb = blockIdx.x / ncb;
+    const int col = cb * 64 + cl;
+    const int r0 = rb * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float s = 0.f;
+    if (col < N)
+        for (int r = r0 + rg; r < r1; r += 4) s += (float)A[(size_t)r * lda + col];
+    red[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0 && col < N) atomicAdd(out + col, red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+// A: fp32 (a_bf16 = 0) or bf16 (a_bf16 = 1) row-major [M][lda]; W fp32 [N][ldw]; C fp32.
+extern "C" int lob_gemm_nt_bf16(const void* A, int a_bf16, int lda, const float* W, int ldw, const float* bias,
+                                float* C, int ldc, int M, int N, int K, int act, void* stream) {
+    if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return LOB_E_ARG;
+    if (lda < K || ldw < K || ldc < N) return LOB_E_SHAPE;
+    if ((act & 0xff) > LOB_ACT_GELU || act < 0) return LOB_E_ARG;
+    if (!al16(A) || !al16(W) || (K % 8) || (lda % 8) || (ldw % 4)) return LOB_E_ALIGN;
+    NTArgs g{A, W, bias, C, lda, ldw, ldc, M, N, K, act & 0xff, (act >> 8) & 1, 0, 0, 0, 0};
+    const dim3 grid((unsigned)(((M + TM - 1) / TM) * ((N + TN_ - 1) / TN_))), block(256);
+    if (a_bf16) hipLaunchKernelGGL((gemm_nt_bf16_kernel<true, 0>), grid, block, 0, (hipStream_t)stream, g);
+    else        hipLaunchKernelGGL((gemm_nt_bf16_kernel<false, 0>), grid, block, 0, (hipStream_t)stream, g);
+    LOB_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int lob_gate_gemm_x_bf16(const float* X, int ldx, const float* Wih, const float* bias,
+                                    float* P, int T, int Bp, int H, int D, int K, void* stream) {
+    if (!X || !Wih || !P || T <= 0 || Bp <= 0 || H <= 0 || K <= 0 || (D != 1 && D != 2)) return LOB_E_ARG;
+    if (ldx < K || (H % 32) || (Bp % 32)) return LOB_E_SHAPE;
+    if (!al16(X) || !al16(Wih) || !al16(P) || (K % 8) || (ldx % 8)) return LOB_E_ALIGN;
+    const int N = D * 4 * H, M = T * Bp;
+    NTArgs g{X, Wih, bias, P, ldx, K, N, M, N, K, LOB_ACT_NONE, 0, T, Bp, H, D};
+    const dim3 grid((unsigned)(((M + TM - 1) / TM) * ((N + TN_ - 1) / TN_))), block(256);
+    hipLaunchKernelGGL((gemm_nt_bf16_kernel<false, 1>), grid, block, 0, (hipStream_t)stream, g);
+    LOB_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int lob_gemm_tn_bf16(const void* A, int a_bf16, int lda, const void* B, int b_bf16, int ldb,
+                                float* C, int ldc, int M, int N, int Kc, void* stream) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || Kc <= 0) return LOB_E_ARG;
+    if (lda < M || ldb < N || ldc < N) return LOB_E_SHAPE;
+    // 16-byte vector loads along the column index of both sources
+    const int am = a_bf16 ? 8 : 4, bm = b_bf16 ? 8 : 4;
+    if ((M % am) || (lda % am) || (N % bm) || (ldb % bm) || !al16(A) || !al16(B)) return LOB_E_ALIGN;
+    const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    int nchunk = (2048 + tiles - 1) / tiles;
+    int kchunk = (Kc + nchunk - 1) / nchunk;
+    kchunk = ((kchunk + TK2 - 1) / TK2) * TK2;
+    if (kchunk < 512) kchunk = 512;
+    nchunk = (Kc + kchunk - 1) / kchunk;
+    const int nchunk8 = ((nchunk + 7) / 8) * 8;
+    TNArgs g{A, B, C, lda, ldb, ldc, M, N, Kc, kchunk, tiles};
+    const dim3 grid((unsigned)(tiles * nchunk8)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (a_bf16 && b_bf16)       hipLaunchKernelGGL((gemm_tn_bf16_kernel<true, true>), grid, block, 0, s, g);
+    else if (a_bf16)            hipLaunchKernelGGL((gemm_tn_bf16_kernel<true, false>), grid, block, 0, s, g);
+    else if (b_bf16)            hipLaunchKernelGGL((gemm_tn_bf16_kernel<false, true>), grid, block, 0, s, g);
+    else                        hipLaunchKernelGGL((gemm_tn_bf16_kernel<false, false>), grid, block, 0, s, g);
+    LOB_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int lob_colsum_bf16(const void* A, int lda, int M, int N, float* out, void* stream) {
+    if (!A || !out || M <= 0 || N <= 0 || lda < N) return LOB_E_ARG;
+    const int ncb = (N + 63) / 64;
+    int nrb = (M + 1023) / 1024;
+    if (nrb > 1024) nrb = 1024;
+    const int rpb = (M + nrb - 1) / nrb;
+    nrb = (M + rpb - 1) / rpb;
+    hipLaunchKernelGGL(colsum_bf16_kernel, dim3((unsigned)(ncb * nrb)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const __bf16*>(A), lda, M, N, rpb, out);
+    LOB_CHECK_LAUNCH();
+    return 0;
+}

@@ -27,23 +27,34 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_h128_kernel(
     float* __restrict__ Csave, int T, int Bp) {
     constexpr int H = 128;
     __shared__ __attribute__((aligned(16))) float hs[2 * 32 * HS_LD];
+    // k-block 3 of the W_hh slice lives in LDS ([wave][gate][16 steps][64 lanes], lane-contiguous =
+    // conflict-free ds_read_b32): 192 + 64 = the 256 values per lane, 64 VGPRs freed for the
+    // P prefetch and the cell update (no scratch spills).
+    __shared__ float wls[4 * 4 * 16 * 64];
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave index, provably uniform
     const int bt = blockIdx.x, d = blockIdx.y, D = gridDim.y, NBT = gridDim.x;
     const int l31 = lane & 31, hi = lane >> 5;
 
     // ---- W_hh slice -> registers.  B operand of step (kb, q, e): W[n][k = 32kb + 16hi + 4q + e]
-    f32x4 wr[4][4][4];
+    f32x4 wr[4][3][4];
     {
         const float* wbase = Whh + (size_t)d * 4 * H * H;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float* row = wbase + (size_t)(g * H + 32 * w + l31) * H + 16 * hi;
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
+            for (int kb = 0; kb < 3; ++kb)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     wr[g][kb][q] = *reinterpret_cast<const f32x4*>(row + 32 * kb + 4 * q);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(row + 96 + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wls[((w * 4 + g) * 16 + 4 * q + e) * 64 + lane] = v[e];
+            }
         }
     }
     for (int i = tid; i < 2 * 32 * HS_LD; i += 256) hs[i] = 0.f;
@@ -54,9 +65,12 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_h128_kernel(
 
     // per-(d,t,bt) block of P: [w][g][q][lane][4]
     const size_t pstep = (size_t)NBT * 4 * 4 * 1024;               // floats per t
-    float* pblk = P + ((size_t)d * T * NBT + bt) * 4 * 4 * 1024 + (size_t)w * 4 * 1024 + lane * 4;
+    // (wave-uniform pointer) + (one 32-bit lane offset) addressing: see the backward kernel
+    float* pblk = P + ((size_t)d * T * NBT + bt) * 4 * 4 * 1024 + (size_t)w * 4 * 1024;
     const size_t cstep = (size_t)NBT * 4 * 1024;
-    float* cblk = SAVE ? Csave + ((size_t)d * T * NBT + bt) * 4 * 1024 + (size_t)w * 1024 + lane * 4 : nullptr;
+    float* cblk = SAVE ? Csave + ((size_t)d * T * NBT + bt) * 4 * 1024 + (size_t)w * 1024 : nullptr;
+    const unsigned frag_off = lane * 4;
+    const unsigned y_off = (unsigned)(4 * hi * (D * H) + l31);
 
     const int t_first = d ? T - 1 : 0, dt = d ? -1 : 1;
     f32x16 pn[4];
@@ -66,7 +80,7 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_h128_kernel(
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(p + g * 1024 + q * 256);
+                f32x4 v = *reinterpret_cast<const f32x4*>((p + g * 1024 + q * 256) + frag_off);
                 pn[g][4 * q + 0] = v[0]; pn[g][4 * q + 1] = v[1]; pn[g][4 * q + 2] = v[2]; pn[g][4 * q + 3] = v[3];
             }
     }
@@ -84,14 +98,14 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_h128_kernel(
             for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    f32x4 v = *reinterpret_cast<const f32x4*>(p + g * 1024 + q * 256);
+                    f32x4 v = *reinterpret_cast<const f32x4*>((p + g * 1024 + q * 256) + frag_off);
                     pn[g][4 * q + 0] = v[0]; pn[g][4 * q + 1] = v[1]; pn[g][4 * q + 2] = v[2]; pn[g][4 * q + 3] = v[3];
                 }
         }
         // ---- z += h_{t-1} * W_hh^T
         const float* hrow = hs + cur * 32 * HS_LD + l31 * HS_LD + 16 * hi;
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
+        for (int kb = 0; kb < 3; ++kb) {
             f32x4 a[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const f32x4*>(hrow + 32 * kb + 4 * q);
@@ -103,9 +117,22 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_h128_kernel(
                     for (int g = 0; g < 4; ++g)
                         acc[g] = mfma32(a[q][e], wr[g][kb][q][e], acc[g]);
         }
+        {
+            f32x4 a[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const f32x4*>(hrow + 96 + 4 * q);
+            const float* wl = wls + (size_t)w * 4 * 16 * 64 + lane;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        acc[g] = mfma32(a[q][e], wl[(g * 16 + 4 * q + e) * 64], acc[g]);
+        }
         // ---- cell update (wave-local), h_t -> LDS (other buffer) and HBM
-        float* hnext = hs + (cur ^ 1) * 32 * HS_LD + 32 * w + l31;
-        float* yrow = Y + ((size_t)t * Bp + bt * 32) * (D * H) + d * H + 32 * w + l31;
+        float* hnext = hs + (cur ^ 1) * 32 * HS_LD + 32 * w + l31 + 4 * hi * HS_LD;
+        float* yrow = Y + ((size_t)t * Bp + bt * 32) * (D * H) + d * H + 32 * w;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float ig = fast_sigmoid(acc[0][r]);
@@ -114,9 +141,9 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_h128_kernel(
             const float og = fast_sigmoid(acc[3][r]);
             c[r] = fg * c[r] + ig * gg;
             const float h = og * fast_tanh(c[r]);
-            const int row = acc_row(r, lane);
+            const int row = (r & 3) + 8 * (r >> 2);          // + 4*hi folded into the lane offsets
             hnext[row * HS_LD] = h;
-            yrow[(size_t)row * (D * H)] = h;
+            (yrow + (size_t)row * (D * H))[y_off] = h;
             if (SAVE) { acc[0][r] = ig; acc[1][r] = fg; acc[2][r] = gg; acc[3][r] = og; }
         }
         if (SAVE) {
@@ -126,13 +153,13 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_h128_kernel(
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     f32x4 v = {acc[g][4 * q + 0], acc[g][4 * q + 1], acc[g][4 * q + 2], acc[g][4 * q + 3]};
-                    *reinterpret_cast<f32x4*>(p + g * 1024 + q * 256) = v;
+                    *reinterpret_cast<f32x4*>((p + g * 1024 + q * 256) + frag_off) = v;
                 }
             float* cp = cblk + (size_t)t * cstep;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 f32x4 v = {c[4 * q + 0], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]};
-                *reinterpret_cast<f32x4*>(cp + q * 256) = v;
+                *reinterpret_cast<f32x4*>((cp + q * 256) + frag_off) = v;
             }
         }
         __syncthreads();
@@ -199,67 +226,82 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_generic_kernel(
 //   dh_{t-1} = dgates * W_hh  (256 MFMAs per wave)  +  coalesced copy of the tile to dP (HBM)
 // -> barrier.  Saved activations (G, Csave) are read-only: backward is re-entrant.
 // ------------------------------------------------------------------------------------
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 constexpr int DG_LD = 516;   // 512 + 4: row stride = 129 x 16 B, odd -> conflict-free ds_read_b128
 
+template <bool DP_BF16>
 __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_h128_kernel(
     const float* __restrict__ G, const float* __restrict__ Csave, const float* __restrict__ Whh,
-    const float* __restrict__ dY, float* __restrict__ dP, int T, int Bp) {
+    const float* __restrict__ dY, void* __restrict__ dPv, float* __restrict__ dbias, int T, int Bp) {
     constexpr int H = 128;
     __shared__ __attribute__((aligned(16))) float dgs[32 * DG_LD];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    __shared__ float wls[4 * 4 * 16 * 64];      // gate-row blocks 12..15 of the W_hh^T slice (see forward)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave index, provably uniform
     const int bt = blockIdx.x, d = blockIdx.y, D = gridDim.y, NBT = gridDim.x;
     const int l31 = lane & 31, hi = lane >> 5;
 
-    float wt[16][16];
+    float wt[12][16];
     {
         const float* wb = Whh + (size_t)d * 4 * H * H + 32 * w + l31;
 #pragma unroll
-        for (int nb = 0; nb < 16; ++nb)
+        for (int nb = 0; nb < 12; ++nb)
 #pragma unroll
             for (int s = 0; s < 16; ++s) wt[nb][s] = wb[(size_t)(32 * nb + 16 * hi + s) * H];
+#pragma unroll
+        for (int nb = 12; nb < 16; ++nb)
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                wls[((w * 4 + nb - 12) * 16 + s) * 64 + lane] = wb[(size_t)(32 * nb + 16 * hi + s) * H];
     }
+    // Addressing: every access is (wave-uniform pointer, SGPRs) + (ONE 32-bit per-lane offset), so
+    // the 20 fragment loads, 16 dY loads and 16 dP stores of a step share three offset VGPRs.
     const size_t gstep = (size_t)NBT * 16 * 1024, cstep = (size_t)NBT * 4096;
-    const float* gblk = G + ((size_t)d * T * NBT + bt) * 16 * 1024 + (size_t)w * 4096 + lane * 4;
-    const float* cblk = Csave + ((size_t)d * T * NBT + bt) * 4096 + (size_t)w * 1024 + lane * 4;
+    const float* gwave = G + ((size_t)d * T * NBT + bt) * 16 * 1024 + (size_t)w * 4096;
+    const float* cwave = Csave + ((size_t)d * T * NBT + bt) * 4096 + (size_t)w * 1024;
+    const unsigned frag_off = lane * 4;
     const int DH = D * H, D4H = D * 4 * H;
-    const float* dyb = dY + (size_t)(bt * 32) * DH + d * H + 32 * w + l31;
+    const float* dywave = dY + (size_t)(bt * 32) * DH + d * H + 32 * w;
+    const unsigned dy_off = (unsigned)(4 * hi * DH + l31);
+    const unsigned dp_off = (unsigned)((tid >> 7) * D4H + (tid & 127) * 4);
 
     const int t_first = d ? 0 : T - 1, dt = d ? 1 : -1;   // backward walk; c_{prev} lives at t + dt
     f32x16 gt[4], ct, cp, dhrec;
     float dy[16], dcarry[16];
+    float dbsum[4] = {0.f, 0.f, 0.f, 0.f};      // bias gradient of this lane's unit, summed over rows and time
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dcarry[r] = 0.f; dhrec[r] = 0.f; }
 
     auto load_step = [&](int t) {
-        const float* gp = gblk + (size_t)t * gstep;
+        const float* gp = gwave + (size_t)t * gstep;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(gp + g * 1024 + q * 256);
+                const f32x4 v = *reinterpret_cast<const f32x4*>((gp + g * 1024 + q * 256) + frag_off);
                 gt[g][4 * q] = v[0]; gt[g][4 * q + 1] = v[1]; gt[g][4 * q + 2] = v[2]; gt[g][4 * q + 3] = v[3];
             }
         const int tp = t + dt;
         if (tp >= 0 && tp < T) {
-            const float* cq = cblk + (size_t)tp * cstep;
+            const float* cq = cwave + (size_t)tp * cstep;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(cq + q * 256);
+                const f32x4 v = *reinterpret_cast<const f32x4*>((cq + q * 256) + frag_off);
                 cp[4 * q] = v[0]; cp[4 * q + 1] = v[1]; cp[4 * q + 2] = v[2]; cp[4 * q + 3] = v[3];
             }
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) cp[r] = 0.f;
         }
-        const float* dp = dyb + (size_t)t * Bp * DH;
+        const float* dp = dywave + (size_t)t * Bp * DH;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dy[r] = dp[(size_t)acc_row(r, lane) * DH];
+        for (int r = 0; r < 16; ++r) dy[r] = (dp + ((r & 3) + 8 * (r >> 2)) * DH)[dy_off];
     };
     {
-        const float* cq = cblk + (size_t)t_first * cstep;
+        const float* cq = cwave + (size_t)t_first * cstep;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(cq + q * 256);
+            const f32x4 v = *reinterpret_cast<const f32x4*>((cq + q * 256) + frag_off);
             ct[4 * q] = v[0]; ct[4 * q + 1] = v[1]; ct[4 * q + 2] = v[2]; ct[4 * q + 3] = v[3];
         }
     }
@@ -267,7 +309,7 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_h128_kernel(
 
     for (int step = 0; step < T; ++step) {
         const int t = t_first + dt * step;
-        float* dgw = dgs + 32 * w + l31;
+        float* dgw = dgs + 32 * w + l31 + 4 * hi * DG_LD;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float ig = gt[0][r], fg = gt[1][r], gg = gt[2][r], og = gt[3][r];
@@ -275,11 +317,11 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_h128_kernel(
             const float tc = fast_tanh(ct[r]);
             const float dc = dcarry[r] + dh * og * (1.f - tc * tc);
             dcarry[r] = dc * fg;
-            float* p = dgw + acc_row(r, lane) * DG_LD;
-            p[0 * H] = dc * gg * ig * (1.f - ig);
-            p[1 * H] = dc * cp[r] * fg * (1.f - fg);
-            p[2 * H] = dc * ig * (1.f - gg * gg);
-            p[3 * H] = dh * tc * og * (1.f - og);
+            float* p = dgw + ((r & 3) + 8 * (r >> 2)) * DG_LD;
+            const float v0 = dc * gg * ig * (1.f - ig), v1 = dc * cp[r] * fg * (1.f - fg);
+            const float v2 = dc * ig * (1.f - gg * gg), v3 = dh * tc * og * (1.f - og);
+            p[0 * H] = v0; p[1 * H] = v1; p[2 * H] = v2; p[3 * H] = v3;
+            dbsum[0] += v0; dbsum[1] += v1; dbsum[2] += v2; dbsum[3] += v3;
         }
         ct = cp;
         __syncthreads();
@@ -289,7 +331,7 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_h128_kernel(
         for (int r = 0; r < 16; ++r) dhrec[r] = 0.f;
         const float* arow = dgs + l31 * DG_LD + 16 * hi;
 #pragma unroll
-        for (int nb = 0; nb < 16; ++nb) {
+        for (int nb = 0; nb < 12; ++nb) {
             f32x4 a[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const f32x4*>(arow + 32 * nb + 4 * q);
@@ -298,22 +340,53 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_h128_kernel(
 #pragma unroll
                 for (int e = 0; e < 4; ++e) dhrec = mfma32(a[q][e], wt[nb][4 * q + e], dhrec);
         }
-        // ---- dgates tile -> dP (row-major [T*Bp][D*4H]), 2 KB contiguous per row
-        float* dpb = dP + ((size_t)t * Bp + bt * 32) * D4H + d * 4 * H;
+        {
+            const float* wl = wls + (size_t)w * 4 * 16 * 64 + lane;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int idx = tid + 256 * i, row = idx >> 7, c4 = (idx & 127) * 4;
-            *reinterpret_cast<f32x4*>(dpb + (size_t)row * D4H + c4) =
-                *reinterpret_cast<const f32x4*>(dgs + row * DG_LD + c4);
+            for (int nb = 12; nb < 16; ++nb) {
+                f32x4 a[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const f32x4*>(arow + 32 * nb + 4 * q);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        dhrec = mfma32(a[q][e], wl[((nb - 12) * 16 + 4 * q + e) * 64], dhrec);
+            }
+        }
+        // ---- dgates tile -> dP (row-major [T*Bp][D*4H]), one full row segment per 128 threads
+        const float* src = dgs + (tid >> 7) * DG_LD + (tid & 127) * 4;
+        if (DP_BF16) {
+            __bf16* dpb = reinterpret_cast<__bf16*>(dPv) + ((size_t)t * Bp + bt * 32) * D4H + d * 4 * H;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(src + 2 * i * DG_LD);
+                bf16x4_t hv = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                *reinterpret_cast<bf16x4_t*>((dpb + (size_t)(2 * i) * D4H) + dp_off) = hv;
+            }
+        } else {
+            float* dpb = reinterpret_cast<float*>(dPv) + ((size_t)t * Bp + bt * 32) * D4H + d * 4 * H;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                *reinterpret_cast<f32x4*>((dpb + (size_t)(2 * i) * D4H) + dp_off) =
+                    *reinterpret_cast<const f32x4*>(src + 2 * i * DG_LD);
         }
         __syncthreads();
+    }
+    if (dbias) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float v = dbsum[g] + __shfl_xor(dbsum[g], 32, 64);
+            if (hi == 0) atomicAdd(dbias + (size_t)d * 4 * H + g * H + 32 * w + l31, v);
+        }
     }
 }
 
 // Generic BPTT (any H): G row-major activated gates, Csave [D][T][Bp][H].
+template <bool DP_BF16>
 __global__ __launch_bounds__(256) void lstm_rec_bwd_generic_kernel(
     const float* __restrict__ G, const float* __restrict__ Csave, const float* __restrict__ Whh,
-    const float* __restrict__ dY, float* __restrict__ dP, int T, int Bp, int H) {
+    const float* __restrict__ dY, void* __restrict__ dPv, int T, int Bp, int H) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* dg = sm;                    // [RB][4H]
     float* dhrec = sm + RB * 4 * H;    // [RB][H]
@@ -340,8 +413,14 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_generic_kernel(
             const float v2 = dc * ig * (1.f - gg * gg), v3 = dh * tc * og * (1.f - og);
             float* o = dg + r * 4 * H;
             o[u] = v0; o[H + u] = v1; o[2 * H + u] = v2; o[3 * H + u] = v3;
-            float* prow = dP + ((size_t)t * Bp + b) * (D * 4 * H) + (size_t)d * 4 * H;
-            prow[u] = v0; prow[H + u] = v1; prow[2 * H + u] = v2; prow[3 * H + u] = v3;
+            const size_t po = ((size_t)t * Bp + b) * (D * 4 * H) + (size_t)d * 4 * H;
+            if (DP_BF16) {
+                __bf16* prow = reinterpret_cast<__bf16*>(dPv) + po;
+                prow[u] = (__bf16)v0; prow[H + u] = (__bf16)v1; prow[2 * H + u] = (__bf16)v2; prow[3 * H + u] = (__bf16)v3;
+            } else {
+                float* prow = reinterpret_cast<float*>(dPv) + po;
+                prow[u] = v0; prow[H + u] = v1; prow[2 * H + u] = v2; prow[3 * H + u] = v3;
+            }
         }
         __syncthreads();
         for (int idx = tid; idx < RB * H; idx += blockDim.x) {
@@ -380,20 +459,23 @@ extern "C" int lob_lstm_rec_fwd_f32(float* P, const float* Whh, float* Y, float*
 }
 
 extern "C" int lob_lstm_rec_bwd_f32(const float* G, const float* Csave, const float* Whh,
-                                    const float* dY, float* dP, int T, int Bp, int H, int D,
-                                    void* stream) {
+                                    const float* dY, void* dP, int dp_bf16, float* dbias,
+                                    int T, int Bp, int H, int D, void* stream) {
     if (!G || !Csave || !Whh || !dY || !dP || T <= 0 || Bp <= 0 || H <= 0 || (D != 1 && D != 2)) return LOB_E_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (H == 128) {
         if (Bp % 32) return LOB_E_SHAPE;
         if ((reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(Csave) |
              reinterpret_cast<uintptr_t>(dP)) & 15) return LOB_E_ALIGN;
-        hipLaunchKernelGGL(lstm_rec_bwd_h128_kernel, dim3(Bp / 32, D), dim3(256), 0, s, G, Csave, Whh, dY, dP, T, Bp);
+        if (dp_bf16) hipLaunchKernelGGL((lstm_rec_bwd_h128_kernel<true>), dim3(Bp / 32, D), dim3(256), 0, s, G, Csave, Whh, dY, dP, dbias, T, Bp);
+        else         hipLaunchKernelGGL((lstm_rec_bwd_h128_kernel<false>), dim3(Bp / 32, D), dim3(256), 0, s, G, Csave, Whh, dY, dP, dbias, T, Bp);
     } else {
+        if (dbias) return LOB_E_SHAPE;      // the generic path leaves the bias gradient to lob_colsum_f32
         const size_t smem = (size_t)6 * RB * H * sizeof(float);
         if (smem > 64 * 1024) return LOB_E_SHAPE;
-        hipLaunchKernelGGL(lstm_rec_bwd_generic_kernel, dim3((Bp + RB - 1) / RB, D), dim3(256), smem, s,
-                           G, Csave, Whh, dY, dP, T, Bp, H);
+        const dim3 grid((Bp + RB - 1) / RB, D);
+        if (dp_bf16) hipLaunchKernelGGL((lstm_rec_bwd_generic_kernel<true>), grid, dim3(256), smem, s, G, Csave, Whh, dY, dP, T, Bp, H);
+        else         hipLaunchKernelGGL((lstm_rec_bwd_generic_kernel<false>), grid, dim3(256), smem, s, G, Csave, Whh, dY, dP, T, Bp, H);
     }
     LOB_CHECK_LAUNCH();
     return 0;

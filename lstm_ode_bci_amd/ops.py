@@ -35,9 +35,15 @@ def ceil32(n):
     return (n + 31) // 32 * 32
 
 
-def gemm_nt(a, w, bias=None, act=ACT_NONE, out=None, accumulate=False):
-    """out[M,N] (+)= act(a[M,K] @ w[N,K]^T + bias)."""
-    _chk(a, "a"); _chk(w, "w"); _chk(bias, "bias")
+def _bf16_ok(a, K, lda):
+    return K % 8 == 0 and lda % 8 == 0 and a.data_ptr() % 16 == 0
+
+
+def gemm_nt(a, w, bias=None, act=ACT_NONE, out=None, accumulate=False, mixed=False):
+    """out[M,N] (+)= act(a[M,K] @ w[N,K]^T + bias).  mixed=True (or a bf16 `a`): bf16 MFMA inputs,
+    fp32 accumulate/output; falls back to the exact-fp32 kernel for shapes the bf16 kernel refuses."""
+    a_bf16 = a.dtype == torch.bfloat16
+    _chk(a, "a", a.dtype if a_bf16 else torch.float32); _chk(w, "w"); _chk(bias, "bias")
     M, K = a.shape
     N = w.shape[0]
     assert w.shape[1] == K
@@ -46,29 +52,54 @@ def gemm_nt(a, w, bias=None, act=ACT_NONE, out=None, accumulate=False):
     _chk(out, "out")
     if accumulate:
         act = act | 0x100
+    if (mixed or a_bf16) and _bf16_ok(a, K, K) and w.data_ptr() % 16 == 0:
+        rc = _lib.lib().lob_gemm_nt_bf16(_ptr(a), 1 if a_bf16 else 0, K, _ptr(w), K, _ptr(bias), _ptr(out), N,
+                                         M, N, K, act, _stream())
+        _lib.check(rc, "lob_gemm_nt_bf16")
+        return out
+    if a_bf16:
+        raise _lib.LobError("gemm_nt: bf16 operand with a shape the bf16 kernel does not support")
     rc = _lib.lib().lob_gemm_nt_f32(_ptr(a), K, _ptr(w), K, _ptr(bias), _ptr(out), N, M, N, K, act, _stream())
     _lib.check(rc, "lob_gemm_nt_f32")
     return out
 
 
-def gemm_tn(a, b, out):
-    """out[M,N] += a[Kc,M]^T @ b[Kc,N]; a, b may be column slices of wider row-major tensors."""
+def gemm_tn(a, b, out, mixed=False):
+    """out[M,N] += a[Kc,M]^T @ b[Kc,N]; a, b may be column slices of wider row-major tensors
+    (fp32 or bf16 storage).  mixed=True or any bf16 operand -> bf16 MFMA, fp32 accumulate."""
     Kc, M = a.shape
     N = b.shape[1]
     assert b.shape[0] == Kc and a.stride(1) == 1 and b.stride(1) == 1
     _chk(out, "out")
+    a16, b16 = a.dtype == torch.bfloat16, b.dtype == torch.bfloat16
+    am, bm = (8 if a16 else 4), (8 if b16 else 4)
+    ok16 = (M % am == 0 and a.stride(0) % am == 0 and N % bm == 0 and b.stride(0) % bm == 0
+            and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0)
+    if (a16 or b16) and not ok16:
+        raise _lib.LobError("gemm_tn: bf16 operand with a shape/alignment the bf16 kernel does not support")
+    if (mixed and ok16) or a16 or b16:
+        rc = _lib.lib().lob_gemm_tn_bf16(_ptr(a), int(a16), a.stride(0), _ptr(b), int(b16), b.stride(0),
+                                         _ptr(out), out.stride(0), M, N, Kc, _stream())
+        _lib.check(rc, "lob_gemm_tn_bf16")
+        return out
     rc = _lib.lib().lob_gemm_tn_f32(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), out.stride(0),
                                     M, N, Kc, _stream())
     _lib.check(rc, "lob_gemm_tn_f32")
     return out
 
 
-def gate_gemm_x(x, wih, bias, T, Bp, H, D, frag):
+def gate_gemm_x(x, wih, bias, T, Bp, H, D, frag, mixed=False):
     """P = x[T*Bp,K] @ wih[D*4H,K]^T + bias, fragment order when frag."""
     _chk(x, "x"); _chk(wih, "wih"); _chk(bias, "bias")
     K = x.shape[1]
     assert x.shape[0] == T * Bp and wih.shape == (D * 4 * H, K)
+    if mixed and not frag:
+        return gemm_nt(x, wih, bias, mixed=True)
     P = torch.empty((T * Bp, D * 4 * H), device=x.device, dtype=torch.float32)
+    if mixed and _bf16_ok(x, K, K):
+        rc = _lib.lib().lob_gate_gemm_x_bf16(_ptr(x), K, _ptr(wih), _ptr(bias), _ptr(P), T, Bp, H, D, K, _stream())
+        _lib.check(rc, "lob_gate_gemm_x_bf16")
+        return P
     rc = _lib.lib().lob_gate_gemm_x_f32(_ptr(x), K, _ptr(wih), _ptr(bias), _ptr(P), T, Bp, H, D, K,
                                         1 if frag else 0, _stream())
     _lib.check(rc, "lob_gate_gemm_x_f32")
@@ -159,14 +190,19 @@ def ode_rk4(base_rates, n_points, t0, t1, substeps, *, probs=None, alpha=0.0, y0
 # ---------------------------------------------------------------------------------------------
 # backward-side wrappers
 # ---------------------------------------------------------------------------------------------
-def lstm_rec_bwd(G, Cs, whh, dY, T, Bp, H, D):
-    """BPTT through one layer; returns dP[T*Bp, D*4H] (row-major)."""
+def lstm_rec_bwd(G, Cs, whh, dY, T, Bp, H, D, dp_bf16=False):
+    """BPTT through one layer; returns (dP[T*Bp, D*4H] row-major fp32|bf16, dbias[D*4H])."""
     _chk(G, "G"); _chk(Cs, "Csave"); _chk(whh, "whh"); _chk(dY, "dY")
     assert dY.shape == (T * Bp, D * H)
-    dP = torch.empty((T * Bp, D * 4 * H), device=G.device, dtype=torch.float32)
-    rc = _lib.lib().lob_lstm_rec_bwd_f32(_ptr(G), _ptr(Cs), _ptr(whh), _ptr(dY), _ptr(dP), T, Bp, H, D, _stream())
+    dP = torch.empty((T * Bp, D * 4 * H), device=G.device, dtype=torch.bfloat16 if dp_bf16 else torch.float32)
+    fused_bias = (H == 128)
+    dbias = torch.zeros((D * 4 * H,), device=G.device, dtype=torch.float32)
+    rc = _lib.lib().lob_lstm_rec_bwd_f32(_ptr(G), _ptr(Cs), _ptr(whh), _ptr(dY), _ptr(dP), int(dp_bf16),
+                                         _ptr(dbias) if fused_bias else _ptr(None), T, Bp, H, D, _stream())
     _lib.check(rc, "lob_lstm_rec_bwd_f32")
-    return dP
+    if not fused_bias:
+        colsum(dP, dbias)
+    return dP, dbias
 
 
 def colsum(a, out=None):
@@ -175,8 +211,9 @@ def colsum(a, out=None):
     assert a.stride(1) == 1
     if out is None:
         out = torch.zeros((N,), device=a.device, dtype=torch.float32)
-    rc = _lib.lib().lob_colsum_f32(_ptr(a), a.stride(0), M, N, _ptr(out), _stream())
-    _lib.check(rc, "lob_colsum_f32")
+    fn = _lib.lib().lob_colsum_bf16 if a.dtype == torch.bfloat16 else _lib.lib().lob_colsum_f32
+    rc = fn(_ptr(a), a.stride(0), M, N, _ptr(out), _stream())
+    _lib.check(rc, "lob_colsum")
     return out
 
 

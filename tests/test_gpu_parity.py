@@ -386,7 +386,7 @@ def test_train_mode_dropout(dev):
     assert abs(keep - 0.6) < 5e-3 and abs(dr.max().item() - 1 / 0.6) < 1e-6
     # finite-difference check of the train-mode backward under a FIXED seed (dropout included)
     from lstm_ode_bci_amd.autograd import _LobModelFn, _collect
-    cfg = (3, 2, 128, (0.2, 0.4, 0.4), 99)
+    cfg = (3, 2, 128, (0.2, 0.4, 0.4), 99, False)
     xs = torch.from_numpy(x[:4]).to(dev)
     ps = _collect(m)
     w = ps[-2]                                        # classifier.6.weight
@@ -404,3 +404,93 @@ def test_train_mode_dropout(dev):
         lm = f().item()
         w[0, 3] += 1e-2
     assert abs((lp - lm) / 2e-2 - ga) < 2e-3 * max(1.0, abs(ga))
+
+
+# ------------------------------------------------------------------------------------------
+# mixed precision (BASELINE.json configs[2]: bf16 gate-GEMMs + fp32 recurrence).
+# Tolerances: logits <= 5e-3 abs, gradients <= 2e-2 of max|ref| per tensor.
+# ------------------------------------------------------------------------------------------
+def _bf16_round(a):
+    return torch.from_numpy(a).to(torch.bfloat16).double()
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (1000, 1024, 256), (4096, 256, 1024), (130, 130, 72)])
+def test_gemm_nt_bf16(dev, M, N, K):
+    from lstm_ode_bci_amd import ops
+    rng = np.random.default_rng(M + K)
+    a = rng.standard_normal((M, K), dtype=np.float32)
+    w = rng.standard_normal((N, K), dtype=np.float32)
+    b = rng.standard_normal((N,), dtype=np.float32)
+    ref = _bf16_round(a) @ _bf16_round(w).T + torch.from_numpy(b).double()
+    out = ops.gemm_nt(torch.from_numpy(a).to(dev), torch.from_numpy(w).to(dev), torch.from_numpy(b).to(dev), mixed=True)
+    assert (out.cpu().double() - ref).abs().max().item() < 1e-5 * K ** 0.5 * 4
+    out2 = ops.gemm_nt(torch.from_numpy(a).to(dev).to(torch.bfloat16), torch.from_numpy(w).to(dev),
+                       torch.from_numpy(b).to(dev))
+    assert (out2.cpu().double() - ref).abs().max().item() < 1e-5 * K ** 0.5 * 4
+    acc = out.clone()
+    ops.gemm_nt(torch.from_numpy(a).to(dev), torch.from_numpy(w).to(dev), None, out=acc, accumulate=True, mixed=True)
+    assert (acc.cpu().double() - (2 * ref - torch.from_numpy(b).double())).abs().max().item() < 1e-4 * K ** 0.5
+
+
+@pytest.mark.parametrize("M,N,Kc", [(128, 128, 4096), (1024, 256, 20000), (512, 128, 70001), (136, 72, 999)])
+def test_gemm_tn_bf16(dev, M, N, Kc):
+    from lstm_ode_bci_amd import ops
+    rng = np.random.default_rng(M + N + 1)
+    a = rng.standard_normal((Kc, M), dtype=np.float32)
+    b = rng.standard_normal((Kc, N), dtype=np.float32)
+    ref = _bf16_round(a).T @ _bf16_round(b)
+    tol = 4e-5 * Kc ** 0.5
+    for a16 in (False, True):
+        for b16 in (False, True):
+            ta = torch.from_numpy(a).to(dev)
+            tb = torch.from_numpy(b).to(dev)
+            if a16:
+                ta = ta.to(torch.bfloat16)
+            if b16:
+                tb = tb.to(torch.bfloat16)
+            out = torch.zeros((M, N), device=dev)
+            ops.gemm_tn(ta, tb, out, mixed=True)
+            assert (out.cpu().double() - ref).abs().max().item() < tol, (a16, b16)
+    # column-sliced operands with a row offset, as the dW_hh call uses them
+    if M >= 256:
+        ta = torch.from_numpy(a).to(dev).to(torch.bfloat16)
+        tb = torch.from_numpy(b).to(dev)
+        out = torch.zeros((128, 64), device=dev)
+        ops.gemm_tn(ta[32:, 128:256], tb[:Kc - 32, 64:128], out)
+        ref2 = _bf16_round(a)[32:, 128:256].T @ _bf16_round(b)[:Kc - 32, 64:128]
+        assert (out.cpu().double() - ref2).abs().max().item() < tol
+    cs = ops.colsum(torch.from_numpy(a).to(dev).to(torch.bfloat16)).cpu().double()
+    assert (cs - _bf16_round(a).sum(0)).abs().max().item() < tol
+
+
+def test_mixed_precision_forward_backward(dev):
+    from oracle import torch_cpu_path as TP
+    sd = syn.make_state_dict(61, 128, 3, 2, True)
+    x, y = syn.make_windows(40, seed=8)
+    m = _model(sd, 61, 128, 3, True, dev)
+    ref = TP.build(sd, 61, 128)
+    rl, rgp, rgx = TP.loss_and_grads(ref, torch.from_numpy(x), torch.from_numpy(y))
+    with torch.no_grad():
+        rlog = ref(torch.from_numpy(x)).numpy()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        with torch.no_grad():
+            logits, attn = m(torch.from_numpy(x).to(dev), return_attention=True)
+        assert logits.dtype == torch.float32
+        assert np.abs(logits.cpu().numpy() - rlog).max() < 5e-3
+        m.zero_grad(set_to_none=True)
+        xg = torch.from_numpy(x).to(dev).requires_grad_(True)
+        loss = torch.nn.functional.cross_entropy(m(xg).float(), torch.from_numpy(y).to(dev))
+    loss.backward()
+    assert abs(float(loss) - rl) < 5e-3
+    worst = 0.0
+    for k, p in m.named_parameters():
+        err = np.abs(p.grad.cpu().numpy() - rgp[k]).max() / max(np.abs(rgp[k]).max(), 1e-12)
+        worst = max(worst, err)
+        assert err < 2e-2 or np.abs(rgp[k]).max() < 1e-7, (k, err)   # attention.2.bias: exactly 0 (cancels in softmax)
+    assert np.abs(xg.grad.cpu().numpy() - rgx).max() / np.abs(rgx).max() < 2e-2
+    print("mixed: logits err %.2e, worst rel grad err %.2e" % (np.abs(logits.cpu().numpy() - rlog).max(), worst))
+    # the attribute switch selects the same path without autocast
+    m.gate_gemm_dtype = "bf16"
+    with torch.no_grad():
+        l2 = m(torch.from_numpy(x).to(dev))
+    assert torch.equal(l2, logits)
