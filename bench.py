@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 T, C, H, L, D = 256, 61, 128, 3, 2
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 GATE_FLOP_FWD = 2 ** 29            # per window, SURVEY.md §8d
+HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
 
 
 def parse():
@@ -65,14 +66,18 @@ def build_model(dev):
     return m.to(dev), sd
 
 
-def kernel_roofline(dev, B):
-    """Per-launch durations of the two MFMA kernels, HIP events on the launch stream."""
+def kernel_roofline(dev, B, mode, precision):
+    """Per-launch durations of the hot kernels of THIS workload, HIP events on the launch stream
+    (torch's current stream is the stream every lob_* call is launched on).  Returns
+    {name: {sec, flop, bytes, per_step}}; `bytes` = algorithmic HBM bytes of one launch."""
     from lstm_ode_bci_amd import ops
     Bp = ops.ceil32(B)
     g = torch.Generator(device="cpu").manual_seed(1)
+    mixed = precision == "mixed"
+    train = mode == "train"
     out = {}
 
-    def timeit(fn, n=5):
+    def timeit(fn, n=4):
         fn()
         torch.cuda.synchronize()
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
@@ -83,20 +88,68 @@ def kernel_roofline(dev, B):
         torch.cuda.synchronize()
         return float(np.mean([s.elapsed_time(e) for s, e in evs])) * 1e-3
 
-    for K in (H, D * H):
-        x = torch.randn((T * Bp, K), generator=g).to(dev)
-        wih = (torch.rand((D * 4 * H, K), generator=g) * 0.17 - 0.085).to(dev)
-        bias = torch.zeros(D * 4 * H, device=dev)
-        sec = timeit(lambda: ops.gate_gemm_x(x, wih, bias, T, Bp, H, D, True))
-        fl = 2.0 * T * Bp * D * 4 * H * K
-        out[f"gate_gemm_x_K{K}"] = {"sec": sec, "flop": fl, "tflops": fl / sec / 1e12}
-    P = ops.gate_gemm_x(x, wih, bias, T, Bp, H, D, True)
+    rows, N = T * Bp, D * 4 * H
+    K = D * H
+    x = torch.randn((rows, K), generator=g).to(dev)
+    wih = (torch.rand((N, K), generator=g) * 0.17 - 0.085).to(dev)
+    bias = torch.zeros(N, device=dev)
     whh = (torch.rand((D, 4 * H, H), generator=g) * 0.17 - 0.085).to(dev)
-    sec = timeit(lambda: ops.lstm_rec_fwd(P, whh, T, Bp, H, D, False), n=3)
-    fl = 2.0 * T * Bp * D * 4 * H * H
-    out["lstm_rec_fwd"] = {"sec": sec, "flop": fl, "tflops": fl / sec / 1e12}
-    del P, x
+    sec = timeit(lambda: ops.gate_gemm_x(x, wih, bias, T, Bp, H, D, True, mixed=mixed))
+    out["gate_gemm_x(K=256)"] = {"sec": sec, "flop": 2.0 * rows * N * K, "bytes": 4.0 * rows * (K + N) + 4.0 * N * K,
+                                 "per_step": L - 1, "mfma": "bf16" if mixed else "f32"}
+    P = ops.gate_gemm_x(x, wih, bias, T, Bp, H, D, True, mixed=mixed)
+    if train:
+        Pk = P.clone()
+
+        def rec_fwd():
+            Pk.copy_(P)                       # the save-mode kernel overwrites P with the activated gates
+            return ops.lstm_rec_fwd(Pk, whh, T, Bp, H, D, True, mixed=mixed)
+        t_copy = timeit(lambda: Pk.copy_(P))
+        sec = timeit(rec_fwd, n=3) - t_copy
+        Y, Cs = rec_fwd()
+        out["lstm_rec_fwd(save)"] = {"sec": sec, "flop": 2.0 * rows * N * H, "per_step": L,
+                                     "mfma": "bf16" if mixed else "f32",
+                                     "bytes": 4.0 * rows * (2 * N + 2 * K)}
+        dY = torch.randn((rows, K), generator=g).to(dev) * 1e-3
+        sec = timeit(lambda: ops.lstm_rec_bwd(Pk, Cs, whh, dY, T, Bp, H, D, dp_bf16=mixed), n=3)
+        out["lstm_rec_bwd"] = {"sec": sec, "flop": 2.0 * rows * N * H, "per_step": L,
+                               "mfma": "bf16" if mixed else "f32",
+                               "bytes": 4.0 * rows * (N + 2 * K) + (2.0 if mixed else 4.0) * rows * N}
+        dP, _ = ops.lstm_rec_bwd(Pk, Cs, whh, dY, T, Bp, H, D, dp_bf16=mixed)
+        dw = torch.zeros((N, K), device=dev)
+        sec = timeit(lambda: ops.gemm_tn(dP, x, dw, mixed=mixed))
+        out["gemm_tn(dW_ih)"] = {"sec": sec, "flop": 2.0 * rows * N * K, "per_step": L - 1,
+                                 "mfma": "bf16" if mixed else "f32",
+                                 "bytes": (2.0 if mixed else 4.0) * rows * N + 4.0 * rows * K}
+        wt = wih.t().contiguous()
+        sec = timeit(lambda: ops.gemm_nt(dP, wt, mixed=mixed))
+        out["gemm_nt(dX)"] = {"sec": sec, "flop": 2.0 * rows * N * K, "per_step": L - 1,
+                              "mfma": "bf16" if mixed else "f32",
+                              "bytes": (2.0 if mixed else 4.0) * rows * N + 4.0 * rows * K}
+    else:
+        sec = timeit(lambda: ops.lstm_rec_fwd(P, whh, T, Bp, H, D, False, mixed=mixed), n=3)
+        out["lstm_rec_fwd"] = {"sec": sec, "flop": 2.0 * rows * N * H, "per_step": L,
+                               "mfma": "bf16" if mixed else "f32",
+                               "bytes": 4.0 * rows * (N + K)}
     return out
+
+
+def roofline_of(kr):
+    """The dominant kernel (largest time per step) priced against the roofline that bounds it."""
+    dom = max(kr, key=lambda k: kr[k]["sec"] * kr[k]["per_step"])
+    v = kr[dom]
+    allk = {k: {"ms": round(x["sec"] * 1e3, 3), "tflops": round(x["flop"] / x["sec"] / 1e12, 1),
+                "GBps": round(x["bytes"] / x["sec"] / 1e9, 0), "launches_per_step": x["per_step"], "mfma": x["mfma"]}
+            for k, x in kr.items()}
+    if v["mfma"] == "f32":
+        a = v["flop"] / v["sec"] / 1e12
+        return {"bound": "mfma", "kernel": dom, "achieved": a, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": a / FP32_MFMA_PEAK_TFLOPS, "traffic": None, "flop_per_launch": v["flop"],
+                "sec_per_launch": v["sec"], "all": allk}
+    a = v["bytes"] / v["sec"] / 1e9              # bf16 GEMMs at K <= 1024 sit under the HBM roof
+    return {"bound": "hbm", "kernel": dom, "achieved": a, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": a / HBM_PEAK_GBPS, "traffic": None, "bytes_per_launch": v["bytes"],
+            "sec_per_launch": v["sec"], "all": allk}
 
 
 def cpu_baseline(mode, sd):
@@ -203,14 +256,14 @@ def main():
 
     if rank == 0:
         value = world * B * a.steps / dt
-        kr = kernel_roofline(dev, B)
-        gsec = kr[f"gate_gemm_x_K{H}"]["sec"] + (L - 1) * kr[f"gate_gemm_x_K{D * H}"]["sec"]
-        rsec = L * kr["lstm_rec_fwd"]["sec"]
-        dom = f"gate_gemm_x_K{D * H}" if gsec >= rsec else "lstm_rec_fwd"
-        roof = {"bound": "mfma", "kernel": dom, "achieved": kr[dom]["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": kr[dom]["tflops"] / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                "flop_per_launch": kr[dom]["flop"], "sec_per_launch": kr[dom]["sec"],
-                "all": {k: {"tflops": round(v["tflops"], 2), "ms": round(v["sec"] * 1e3, 3)} for k, v in kr.items()}}
+        kr = kernel_roofline(dev, B, mode, precision)
+        roof = roofline_of(kr)
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # HBM bytes per launch from rocprofv3 --pmc
+        if os.path.exists(tpath):
+            try:
+                roof["traffic"] = json.load(open(tpath)).get(f"{roof['kernel']}|{precision}|B{B}")
+            except Exception:
+                pass
         flop_per_window = GATE_FLOP_FWD * (3 if mode == "train" else 1)
         res = {
             "metric": {"train": "eeg_windows_per_sec_fwd_bwd", "fwd": "eeg_windows_per_sec_fwd",

@@ -118,6 +118,14 @@ int lob_gate_gemm_x_bf16(const float* X, int ldx, const float* Wih, const float*
 int lob_gemm_tn_bf16(const void* A, int a_bf16, int lda, const void* B, int b_bf16, int ldb,
                      float* C, int ldc, int M, int N, int Kc, void* stream);
 
+/* Recurrent kernels with the hidden-state gate GEMM on bf16 MFMA (H == 128 only; everything
+ * stored and carried through time stays fp32).  Same arguments as lob_lstm_rec_fwd_f32 /
+ * lob_lstm_rec_bwd_f32; dP is always bf16 here.                                            */
+int lob_lstm_rec_fwd_bf16(float* P, const float* Whh, float* Y, float* Csave,
+                          int T, int Bp, int H, int D, int save, void* stream);
+int lob_lstm_rec_bwd_bf16(const float* G, const float* Csave, const float* Whh, const float* dY,
+                          void* dP, float* dbias, int T, int Bp, int H, int D, void* stream);
+
 /* Element-wise activation and its backward (dx = dy * act'(pre)); classifier GELUs
  * (04_lstm_model.py:198, 201) in training mode.                                       */
 int lob_act_f32(const float* in, float* out, int64_t n, int act, void* stream);

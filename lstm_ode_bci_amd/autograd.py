@@ -66,7 +66,7 @@ def _forward_impl(x, ps, cfg, save):
         whh = torch.stack([d[1] for d in dirs], 0)
         bias = torch.cat([d[2] + d[3] for d in dirs], 0)
         P = ops.gate_gemm_x(inp, wih, bias, T, Bp, H, D, frag, mixed=mixed)
-        Y, Cs = ops.lstm_rec_fwd(P, whh, T, Bp, H, D, save)
+        Y, Cs = ops.lstm_rec_fwd(P, whh, T, Bp, H, D, save, mixed=mixed)
         nxt = Y
         if layer + 1 < L and p_lstm > 0:
             nxt = ops.dropout(Y, p_lstm, _seed(seed, 10 + layer))

@@ -19,9 +19,13 @@
 
 namespace {
 
+#ifndef LOB_SAVE_WLDS
+#define LOB_SAVE_WLDS 0
+#endif
+constexpr bool SAVE_WLDS = LOB_SAVE_WLDS;
 constexpr int HS_LD = 132;   // LDS row stride of the h tile (floats): 33 x 16 B -> conflict-free b128
 
-template <bool SAVE>
+template <bool SAVE, bool WLDS>
 __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_h128_kernel(
     float* __restrict__ P, const float* __restrict__ Whh, float* __restrict__ Y,
     float* __restrict__ Csave, int T, int Bp) {
@@ -30,7 +34,8 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_h128_kernel(
     // k-block 3 of the W_hh slice lives in LDS ([wave][gate][16 steps][64 lanes], lane-contiguous =
     // conflict-free ds_read_b32): 192 + 64 = the 256 values per lane, 64 VGPRs freed for the
     // P prefetch and the cell update (no scratch spills).
-    __shared__ float wls[4 * 4 * 16 * 64];
+    __shared__ float wls[WLDS ? 4 * 4 * 16 * 64 : 64];
+    constexpr int KBR = WLDS ? 3 : 4;          // k-blocks of W_hh held in registers
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave index, provably uniform
@@ -38,22 +43,24 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_h128_kernel(
     const int l31 = lane & 31, hi = lane >> 5;
 
     // ---- W_hh slice -> registers.  B operand of step (kb, q, e): W[n][k = 32kb + 16hi + 4q + e]
-    f32x4 wr[4][3][4];
+    f32x4 wr[4][KBR][4];
     {
         const float* wbase = Whh + (size_t)d * 4 * H * H;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float* row = wbase + (size_t)(g * H + 32 * w + l31) * H + 16 * hi;
 #pragma unroll
-            for (int kb = 0; kb < 3; ++kb)
+            for (int kb = 0; kb < KBR; ++kb)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     wr[g][kb][q] = *reinterpret_cast<const f32x4*>(row + 32 * kb + 4 * q);
+            if (WLDS) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(row + 96 + 4 * q);
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(row + 96 + 4 * q);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) wls[((w * 4 + g) * 16 + 4 * q + e) * 64 + lane] = v[e];
+                    for (int e = 0; e < 4; ++e) wls[((w * 4 + g) * 16 + 4 * q + e) * 64 + lane] = v[e];
+                }
             }
         }
     }
@@ -105,7 +112,7 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_h128_kernel(
         // ---- z += h_{t-1} * W_hh^T
         const float* hrow = hs + cur * 32 * HS_LD + l31 * HS_LD + 16 * hi;
 #pragma unroll
-        for (int kb = 0; kb < 3; ++kb) {
+        for (int kb = 0; kb < KBR; ++kb) {
             f32x4 a[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const f32x4*>(hrow + 32 * kb + 4 * q);
@@ -117,7 +124,7 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_h128_kernel(
                     for (int g = 0; g < 4; ++g)
                         acc[g] = mfma32(a[q][e], wr[g][kb][q][e], acc[g]);
         }
-        {
+        if (WLDS) {
             f32x4 a[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const f32x4*>(hrow + 96 + 4 * q);
@@ -445,8 +452,8 @@ extern "C" int lob_lstm_rec_fwd_f32(float* P, const float* Whh, float* Y, float*
         if ((reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(Whh) |
              reinterpret_cast<uintptr_t>(Csave)) & 15) return LOB_E_ALIGN;
         const dim3 grid(Bp / 32, D), block(256);
-        if (save) hipLaunchKernelGGL((lstm_rec_fwd_h128_kernel<true>), grid, block, 0, s, P, Whh, Y, Csave, T, Bp);
-        else      hipLaunchKernelGGL((lstm_rec_fwd_h128_kernel<false>), grid, block, 0, s, P, Whh, Y, Csave, T, Bp);
+        if (save) hipLaunchKernelGGL((lstm_rec_fwd_h128_kernel<true, SAVE_WLDS>), grid, block, 0, s, P, Whh, Y, Csave, T, Bp);
+        else      hipLaunchKernelGGL((lstm_rec_fwd_h128_kernel<false, false>), grid, block, 0, s, P, Whh, Y, Csave, T, Bp);
     } else {
         const dim3 grid((Bp + RB - 1) / RB, D), block(256);
         const size_t smem = (size_t)3 * RB * H * sizeof(float);

@@ -106,15 +106,16 @@ def gate_gemm_x(x, wih, bias, T, Bp, H, D, frag, mixed=False):
     return P
 
 
-def lstm_rec_fwd(P, whh, T, Bp, H, D, save):
-    """Runs the persistent recurrent kernel; returns (Y[T*Bp, D*H], Csave or None)."""
+def lstm_rec_fwd(P, whh, T, Bp, H, D, save, mixed=False):
+    """Runs the persistent recurrent kernel; returns (Y[T*Bp, D*H], Csave or None).
+    mixed: h W_hh^T on bf16 MFMA (H == 128), everything else fp32."""
     _chk(P, "P"); _chk(whh, "whh")
     assert whh.shape == (D, 4 * H, H)
     Y = torch.empty((T * Bp, D * H), device=P.device, dtype=torch.float32)
     Cs = torch.empty((D * T * Bp * H,), device=P.device, dtype=torch.float32) if save else None
-    rc = _lib.lib().lob_lstm_rec_fwd_f32(_ptr(P), _ptr(whh), _ptr(Y), _ptr(Cs), T, Bp, H, D,
-                                         1 if save else 0, _stream())
-    _lib.check(rc, "lob_lstm_rec_fwd_f32")
+    fn = _lib.lib().lob_lstm_rec_fwd_bf16 if (mixed and H == 128) else _lib.lib().lob_lstm_rec_fwd_f32
+    rc = fn(_ptr(P), _ptr(whh), _ptr(Y), _ptr(Cs), T, Bp, H, D, 1 if save else 0, _stream())
+    _lib.check(rc, "lob_lstm_rec_fwd")
     return Y, Cs
 
 
@@ -197,9 +198,13 @@ def lstm_rec_bwd(G, Cs, whh, dY, T, Bp, H, D, dp_bf16=False):
     dP = torch.empty((T * Bp, D * 4 * H), device=G.device, dtype=torch.bfloat16 if dp_bf16 else torch.float32)
     fused_bias = (H == 128)
     dbias = torch.zeros((D * 4 * H,), device=G.device, dtype=torch.float32)
-    rc = _lib.lib().lob_lstm_rec_bwd_f32(_ptr(G), _ptr(Cs), _ptr(whh), _ptr(dY), _ptr(dP), int(dp_bf16),
-                                         _ptr(dbias) if fused_bias else _ptr(None), T, Bp, H, D, _stream())
-    _lib.check(rc, "lob_lstm_rec_bwd_f32")
+    if dp_bf16 and H == 128:
+        rc = _lib.lib().lob_lstm_rec_bwd_bf16(_ptr(G), _ptr(Cs), _ptr(whh), _ptr(dY), _ptr(dP), _ptr(dbias),
+                                              T, Bp, H, D, _stream())
+    else:
+        rc = _lib.lib().lob_lstm_rec_bwd_f32(_ptr(G), _ptr(Cs), _ptr(whh), _ptr(dY), _ptr(dP), int(dp_bf16),
+                                             _ptr(dbias) if fused_bias else _ptr(None), T, Bp, H, D, _stream())
+    _lib.check(rc, "lob_lstm_rec_bwd")
     if not fused_bias:
         colsum(dP, dbias)
     return dP, dbias
