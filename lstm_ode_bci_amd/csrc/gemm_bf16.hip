@@ -11,6 +11,7 @@
 // Tiles: 128x128 output per 256-thread workgroup (4 waves as 2x2, 2x2 32x32 accumulators each),
 // contraction in steps of 64 through double-buffered LDS; LDS rows are 64 bf16 + 16 B pad =
 // 144 B = 9 x 16-B slots (odd), so a wave's ds_read_b128 fragment reads are conflict-free.
+#include <stdlib.h>
 #include "lob_common.h"
 
 namespace {
@@ -19,8 +20,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
-constexpr int TM = 128, TN_ = 128, TK = 64;
-constexpr int LDB = 72;                 // LDS row stride in bf16 elements (144 B)
+constexpr int TM = 128, TN_ = 128;
 
 __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -32,34 +32,40 @@ struct NTArgs {
     int T, Bp, H, D;     // fragment epilogue
 };
 
-// ---- staging: [rows][64 k] tile, source rows are K-contiguous ----------------------------
-// fp32 source: thread -> row = tid/16 + 16 i (i<8), 4 floats at k = (tid%16)*4
+// ---- staging: [128 rows][TKT k] tile, source rows are K-contiguous -------------------------
+// LDS rows are TKT bf16 + 16 B pad (TKT=64: 144 B = 9 slots, TKT=32: 80 B = 5 slots; odd -> the
+// ds_read_b128 fragment reads of a wave are conflict-free).
+template <int TKT>
 __device__ __forceinline__ void ld_rows_f32(const float* __restrict__ G, int ld, int row0, int rows,
-                                            int k0, int K, int tid, f32x4 (&r)[8]) {
-    const int rr = tid >> 4, c4 = (tid & 15) * 4;
+                                            int k0, int K, int tid, f32x4 (&r)[TKT / 8]) {
+    constexpr int TPR = TKT / 4, RPP = 256 / TPR, NP = 128 / RPP;
+    const int rr = tid / TPR, c4 = (tid % TPR) * 4;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = row0 + rr + 16 * i, k = k0 + c4;
+    for (int i = 0; i < NP; ++i) {
+        const int row = row0 + rr + RPP * i, k = k0 + c4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (row < rows && k < K) v = *reinterpret_cast<const f32x4*>(G + (size_t)row * ld + k);
         r[i] = v;
     }
 }
-__device__ __forceinline__ void st_rows_f32(__bf16* S, int tid, const f32x4 (&r)[8]) {
-    const int rr = tid >> 4, c4 = (tid & 15) * 4;
+template <int TKT>
+__device__ __forceinline__ void st_rows_f32(__bf16* S, int tid, const f32x4 (&r)[TKT / 8]) {
+    constexpr int TPR = TKT / 4, RPP = 256 / TPR, NP = 128 / RPP, LD = TKT + 8;
+    const int rr = tid / TPR, c4 = (tid % TPR) * 4;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NP; ++i) {
         bf16x4 h = {(__bf16)r[i][0], (__bf16)r[i][1], (__bf16)r[i][2], (__bf16)r[i][3]};
-        *reinterpret_cast<bf16x4*>(S + (rr + 16 * i) * LDB + c4) = h;
+        *reinterpret_cast<bf16x4*>(S + (rr + RPP * i) * LD + c4) = h;
     }
 }
-// bf16 source: thread -> row = tid/8 + 32 i (i<4), 8 bf16 at k = (tid%8)*8
+template <int TKT>
 __device__ __forceinline__ void ld_rows_bf16(const __bf16* __restrict__ G, int ld, int row0, int rows,
-                                             int k0, int K, int tid, bf16x8 (&r)[4]) {
-    const int rr = tid >> 3, c8 = (tid & 7) * 8;
+                                             int k0, int K, int tid, bf16x8 (&r)[TKT / 16]) {
+    constexpr int TPR = TKT / 8, RPP = 256 / TPR, NP = 128 / RPP;
+    const int rr = tid / TPR, c8 = (tid % TPR) * 8;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = row0 + rr + 32 * i, k = k0 + c8;
+    for (int i = 0; i < NP; ++i) {
+        const int row = row0 + rr + RPP * i, k = k0 + c8;
         bf16x8 v;
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = (__bf16)0.f;
@@ -67,22 +73,26 @@ __device__ __forceinline__ void ld_rows_bf16(const __bf16* __restrict__ G, int l
         r[i] = v;
     }
 }
-__device__ __forceinline__ void st_rows_bf16(__bf16* S, int tid, const bf16x8 (&r)[4]) {
-    const int rr = tid >> 3, c8 = (tid & 7) * 8;
+template <int TKT>
+__device__ __forceinline__ void st_rows_bf16(__bf16* S, int tid, const bf16x8 (&r)[TKT / 16]) {
+    constexpr int TPR = TKT / 8, RPP = 256 / TPR, NP = 128 / RPP, LD = TKT + 8;
+    const int rr = tid / TPR, c8 = (tid % TPR) * 8;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<bf16x8*>(S + (rr + 32 * i) * LDB + c8) = r[i];
+    for (int i = 0; i < NP; ++i) *reinterpret_cast<bf16x8*>(S + (rr + RPP * i) * LD + c8) = r[i];
 }
 
+template <int TKT>
 __device__ __forceinline__ void mma_tile(const __bf16* As, const __bf16* Bs, int wr, int wc, int lane,
                                          f32x16 (&acc)[2][2]) {
-    const __bf16* ap = As + (64 * wr + (lane & 31)) * LDB + 8 * (lane >> 5);
-    const __bf16* bp = Bs + (64 * wc + (lane & 31)) * LDB + 8 * (lane >> 5);
+    constexpr int LD = TKT + 8;
+    const __bf16* ap = As + (64 * wr + (lane & 31)) * LD + 8 * (lane >> 5);
+    const __bf16* bp = Bs + (64 * wc + (lane & 31)) * LD + 8 * (lane >> 5);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < TKT / 16; ++s) {
         const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ap + 16 * s);
-        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ap + 32 * LDB + 16 * s);
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ap + 32 * LD + 16 * s);
         const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(bp + 16 * s);
-        const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(bp + 32 * LDB + 16 * s);
+        const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(bp + 32 * LD + 16 * s);
         acc[0][0] = mfma_bf16(a0, b0, acc[0][0]);
         acc[0][1] = mfma_bf16(a0, b1, acc[0][1]);
         acc[1][0] = mfma_bf16(a1, b0, acc[1][0]);
@@ -90,15 +100,22 @@ __device__ __forceinline__ void mma_tile(const __bf16* As, const __bf16* Bs, int
     }
 }
 
-template <bool A_BF16, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(NTArgs g) {
-    __shared__ __attribute__((aligned(16))) __bf16 lds[2 * 2 * TM * LDB];
+template <bool A_BF16, int EPI, int TKT>
+__global__ __launch_bounds__(256, TKT == 32 ? 3 : 2) void gemm_nt_bf16_kernel(NTArgs g) {
+    constexpr int LD = TKT + 8;
+    __shared__ __attribute__((aligned(16))) __bf16 lds[2 * 2 * TM * LD];
     __bf16* As = lds;
-    __bf16* Ws = lds + 2 * TM * LDB;
+    __bf16* Ws = lds + 2 * TM * LD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int ntn = (g.N + TN_ - 1) / TN_;
-    const int m0 = (blockIdx.x / ntn) * TM, n0 = (blockIdx.x % ntn) * TN_;
+    // XCD-aware tile order: blocks are dealt round-robin over the 8 XCDs, so give XCD x the row
+    // panels mt = x (mod 8) and let consecutive blocks of one XCD sweep the N tiles of ONE row panel:
+    // the A panel is then pulled through the fabric once (into one L2) instead of once per XCD.
+    const int ntn = (g.N + TN_ - 1) / TN_, ntm = (g.M + TM - 1) / TM;
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int mt = (jb / ntn) * 8 + xcd;
+    if (mt >= ntm) return;
+    const int m0 = mt * TM, n0 = (jb % ntn) * TN_;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -108,27 +125,26 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(NTArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    f32x4 ra[8], rw[8];
-    bf16x8 rab[4];
-    const int nk = (g.K + TK - 1) / TK;
-    if (A_BF16) ld_rows_bf16(reinterpret_cast<const __bf16*>(g.A), g.lda, m0, g.M, 0, g.K, tid, rab);
-    else        ld_rows_f32(reinterpret_cast<const float*>(g.A), g.lda, m0, g.M, 0, g.K, tid, ra);
-    ld_rows_f32(g.W, g.ldw, n0, g.N, 0, g.K, tid, rw);
-    if (A_BF16) st_rows_bf16(As, tid, rab); else st_rows_f32(As, tid, ra);
-    st_rows_f32(Ws, tid, rw);
+    f32x4 ra[TKT / 8], rw[TKT / 8];
+    bf16x8 rab[TKT / 16];
+    const int nk = (g.K + TKT - 1) / TKT;
+    auto load = [&](int k0) {
+        if (A_BF16) ld_rows_bf16<TKT>(reinterpret_cast<const __bf16*>(g.A), g.lda, m0, g.M, k0, g.K, tid, rab);
+        else        ld_rows_f32<TKT>(reinterpret_cast<const float*>(g.A), g.lda, m0, g.M, k0, g.K, tid, ra);
+        ld_rows_f32<TKT>(g.W, g.ldw, n0, g.N, k0, g.K, tid, rw);
+    };
+    auto store = [&](int b) {
+        if (A_BF16) st_rows_bf16<TKT>(As + b * TM * LD, tid, rab); else st_rows_f32<TKT>(As + b * TM * LD, tid, ra);
+        st_rows_f32<TKT>(Ws + b * TM * LD, tid, rw);
+    };
+    load(0);
+    store(0);
     __syncthreads();
     int buf = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) {
-            if (A_BF16) ld_rows_bf16(reinterpret_cast<const __bf16*>(g.A), g.lda, m0, g.M, (kt + 1) * TK, g.K, tid, rab);
-            else        ld_rows_f32(reinterpret_cast<const float*>(g.A), g.lda, m0, g.M, (kt + 1) * TK, g.K, tid, ra);
-            ld_rows_f32(g.W, g.ldw, n0, g.N, (kt + 1) * TK, g.K, tid, rw);
-        }
-        mma_tile(As + buf * TM * LDB, Ws + buf * TM * LDB, wr, wc, lane, acc);
-        if (kt + 1 < nk) {
-            if (A_BF16) st_rows_bf16(As + (buf ^ 1) * TM * LDB, tid, rab); else st_rows_f32(As + (buf ^ 1) * TM * LDB, tid, ra);
-            st_rows_f32(Ws + (buf ^ 1) * TM * LDB, tid, rw);
-        }
+        if (kt + 1 < nk) load((kt + 1) * TKT);
+        mma_tile<TKT>(As + buf * TM * LD, Ws + buf * TM * LD, wr, wc, lane, acc);
+        if (kt + 1 < nk) store(buf ^ 1);
         __syncthreads();
         buf ^= 1;
     }
@@ -335,6 +351,12 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const __bf16* __restri
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// contraction depth per LDS stage of the NT kernel (tuning knob; LOB_NT_TK=32|64)
+inline int nt_tk() {
+    static const int v = [] { const char* e = getenv("LOB_NT_TK"); return (e && atoi(e) == 64) ? 64 : 32; }();
+    return v;
+}
+
 }  // namespace
 
 // A: fp32 (a_bf16 = 0) or bf16 (a_bf16 = 1) row-major [M][lda]; W fp32 [N][ldw]; C fp32.
@@ -345,9 +367,15 @@ extern "C" int lob_gemm_nt_bf16(const void* A, int a_bf16, int lda, const float*
     if ((act & 0xff) > LOB_ACT_GELU || act < 0) return LOB_E_ARG;
     if (!al16(A) || !al16(W) || (K % 8) || (lda % 8) || (ldw % 4)) return LOB_E_ALIGN;
     NTArgs g{A, W, bias, C, lda, ldw, ldc, M, N, K, act & 0xff, (act >> 8) & 1, 0, 0, 0, 0};
-    const dim3 grid((unsigned)(((M + TM - 1) / TM) * ((N + TN_ - 1) / TN_))), block(256);
-    if (a_bf16) hipLaunchKernelGGL((gemm_nt_bf16_kernel<true, 0>), grid, block, 0, (hipStream_t)stream, g);
-    else        hipLaunchKernelGGL((gemm_nt_bf16_kernel<false, 0>), grid, block, 0, (hipStream_t)stream, g);
+    const dim3 grid((unsigned)((((M + TM - 1) / TM + 7) / 8) * 8 * ((N + TN_ - 1) / TN_))), block(256);
+    const bool tk32 = nt_tk() == 32;
+    if (a_bf16) {
+        if (tk32) hipLaunchKernelGGL((gemm_nt_bf16_kernel<true, 0, 32>), grid, block, 0, (hipStream_t)stream, g);
+        else      hipLaunchKernelGGL((gemm_nt_bf16_kernel<true, 0, 64>), grid, block, 0, (hipStream_t)stream, g);
+    } else {
+        if (tk32) hipLaunchKernelGGL((gemm_nt_bf16_kernel<false, 0, 32>), grid, block, 0, (hipStream_t)stream, g);
+        else      hipLaunchKernelGGL((gemm_nt_bf16_kernel<false, 0, 64>), grid, block, 0, (hipStream_t)stream, g);
+    }
     LOB_CHECK_LAUNCH();
     return 0;
 }
@@ -359,8 +387,9 @@ extern "C" int lob_gate_gemm_x_bf16(const float* X, int ldx, const float* Wih, c
     if (!al16(X) || !al16(Wih) || !al16(P) || (K % 8) || (ldx % 8)) return LOB_E_ALIGN;
     const int N = D * 4 * H, M = T * Bp;
     NTArgs g{X, Wih, bias, P, ldx, K, N, M, N, K, LOB_ACT_NONE, 0, T, Bp, H, D};
-    const dim3 grid((unsigned)(((M + TM - 1) / TM) * ((N + TN_ - 1) / TN_))), block(256);
-    hipLaunchKernelGGL((gemm_nt_bf16_kernel<false, 1>), grid, block, 0, (hipStream_t)stream, g);
+    const dim3 grid((unsigned)((((M + TM - 1) / TM + 7) / 8) * 8 * ((N + TN_ - 1) / TN_))), block(256);
+    if (nt_tk() == 32) hipLaunchKernelGGL((gemm_nt_bf16_kernel<false, 1, 32>), grid, block, 0, (hipStream_t)stream, g);
+    else               hipLaunchKernelGGL((gemm_nt_bf16_kernel<false, 1, 64>), grid, block, 0, (hipStream_t)stream, g);
     LOB_CHECK_LAUNCH();
     return 0;
 }

@@ -63,8 +63,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT g) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int ntn = (g.N + BN - 1) / BN;
-    const int m0 = (blockIdx.x / ntn) * BM, n0 = (blockIdx.x % ntn) * BN;
+    // XCD-aware tile order (see gemm_bf16.hip): one row panel's N tiles run back to back on one XCD
+    const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM;
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int mt = (jb / ntn) * 8 + xcd;
+    if (mt >= ntm) return;
+    const int m0 = mt * BM, n0 = (jb % ntn) * BN;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -290,7 +294,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 int launch_nt(const GemmNT& g, int epi, hipStream_t s) {
     const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
-    const dim3 grid((unsigned)(ntm * ntn)), block(256);
+    const dim3 grid((unsigned)(((ntm + 7) / 8) * 8 * ntn)), block(256);
     const bool vec = aligned16(g.A) && aligned16(g.W) && (g.lda % 4 == 0) && (g.ldw % 4 == 0) && (g.K % 4 == 0);
     if (epi == 0) {
         if (vec) hipLaunchKernelGGL((gemm_nt_kernel<true, 0>), grid, block, 0, s, g);
