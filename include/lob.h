@@ -194,9 +194,16 @@ int lob_softmax_rows_f32(const float* in, float* out, int rows, int cols, void* 
  * final_state [B][3] f64 (may be NULL), pred [B] int64 (may be NULL).
  * base_rates: HOST pointer to 6 doubles in the order k_ap,k_af,k_pa,k_pf,k_fa,k_fp.
  * ---------------------------------------------------------------------------------- */
+#define LOB_ODE_RAW 1   /* 08_forecasting.py:132-153 variant: no clamp in the rhs, y0 used as given,
+                         * no clip / renormalise of the output (predict_trajectory, 08:149-153)  */
 int lob_ode_rk4_f64(const float* probs, const double* y0_in, const double* base_rates,
                     double alpha, int n_points, double t0, double t1, int substeps,
-                    double* traj, double* final_state, int64_t* pred, int B, void* stream);
+                    double* traj, double* final_state, int64_t* pred, int B, int flags,
+                    void* stream);
+
+/* y0[b] = prob_to_ode_state(P(closed)) (08_forecasting.py:215-234): A = 1-p; (F,P) = (.6p,.4p) if
+ * p > .5 else (.3p,.3p); normalised.  probs [B][2] f32 -> y0 [B][3] f64.                   */
+int lob_prob_to_state_f64(const float* probs, double* y0, int B, void* stream);
 
 #ifdef __cplusplus
 }

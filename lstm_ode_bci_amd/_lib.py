@@ -47,7 +47,8 @@ _SIGS = {
                                C.c_int, C.c_void_p], C.c_int),
     "lob_softmax_rows_f32": ([_f32p, _f32p, C.c_int, C.c_int, C.c_void_p], C.c_int),
     "lob_ode_rk4_f64": ([_f32p, C.c_void_p, C.POINTER(C.c_double), C.c_double, C.c_int, C.c_double, C.c_double,
-                         C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p], C.c_int),
+                         C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p], C.c_int),
+    "lob_prob_to_state_f64": ([_f32p, C.c_void_p, C.c_int, C.c_void_p], C.c_int),
 }
 
 

@@ -15,24 +15,28 @@ struct OdeArgs {
     const float* probs; const double* y0_in;
     double k_ap, k_af, k_pa, k_pf, k_fa, k_fp, alpha;
     int n_points, substeps; double t0, t1;
-    double* traj; double* final_state; int64_t* pred; int B;
+    double* traj; double* final_state; int64_t* pred; int B; int flags;
 };
 
+template <bool RAW>
 __device__ __forceinline__ void rhs(const double (&k)[6], double a, double p, double f,
                                     double& da, double& dp, double& df) {
-    a = fmax(a, 0.0); p = fmax(p, 0.0); f = fmax(f, 0.0);
+    if (!RAW) { a = fmax(a, 0.0); p = fmax(p, 0.0); f = fmax(f, 0.0); }
     // k = {k_ap, k_af, k_pa, k_pf, k_fa, k_fp}; same operation order as the reference rhs
     da = -k[0] * a - k[1] * a + k[2] * p + k[4] * f;
     dp = k[0] * a - k[2] * p - k[3] * p + k[5] * f;
     df = k[1] * a + k[3] * p - k[4] * f - k[5] * f;
 }
 
+template <bool RAW>
 __device__ __forceinline__ void post(double a, double p, double f, double (&o)[3]) {
+    if (RAW) { o[0] = a; o[1] = p; o[2] = f; return; }
     a = fmin(fmax(a, 0.0), 1.0); p = fmin(fmax(p, 0.0), 1.0); f = fmin(fmax(f, 0.0), 1.0);
     const double s = a + p + f;
     o[0] = a / s; o[1] = p / s; o[2] = f / s;
 }
 
+template <bool RAW>
 __global__ __launch_bounds__(64) void ode_rk4_kernel(OdeArgs g) {
     __shared__ double stage[64 * CH * 3];
     const int lane = threadIdx.x;
@@ -60,8 +64,7 @@ __global__ __launch_bounds__(64) void ode_rk4_kernel(OdeArgs g) {
         } else {
             a = g.y0_in[3 * (size_t)b + 0]; p = g.y0_in[3 * (size_t)b + 1]; f = g.y0_in[3 * (size_t)b + 2];
         }
-        const double s = a + p + f;
-        a /= s; p /= s; f /= s;
+        if (!RAW) { const double s = a + p + f; a /= s; p /= s; f /= s; }
     }
     const int n = g.n_points;
     const double h = n > 1 ? (g.t1 - g.t0) / (double)(n - 1) / (double)g.substeps : 0.0;
@@ -73,17 +76,17 @@ __global__ __launch_bounds__(64) void ode_rk4_kernel(OdeArgs g) {
             if (s0 + j > 0) {
                 for (int ss = 0; ss < g.substeps; ++ss) {
                     double k1a, k1p, k1f, k2a, k2p, k2f, k3a, k3p, k3f, k4a, k4p, k4f;
-                    rhs(k, a, p, f, k1a, k1p, k1f);
-                    rhs(k, a + 0.5 * h * k1a, p + 0.5 * h * k1p, f + 0.5 * h * k1f, k2a, k2p, k2f);
-                    rhs(k, a + 0.5 * h * k2a, p + 0.5 * h * k2p, f + 0.5 * h * k2f, k3a, k3p, k3f);
-                    rhs(k, a + h * k3a, p + h * k3p, f + h * k3f, k4a, k4p, k4f);
+                    rhs<RAW>(k, a, p, f, k1a, k1p, k1f);
+                    rhs<RAW>(k, a + 0.5 * h * k1a, p + 0.5 * h * k1p, f + 0.5 * h * k1f, k2a, k2p, k2f);
+                    rhs<RAW>(k, a + 0.5 * h * k2a, p + 0.5 * h * k2p, f + 0.5 * h * k2f, k3a, k3p, k3f);
+                    rhs<RAW>(k, a + h * k3a, p + h * k3p, f + h * k3f, k4a, k4p, k4f);
                     a += h / 6.0 * (k1a + 2.0 * k2a + 2.0 * k3a + k4a);
                     p += h / 6.0 * (k1p + 2.0 * k2p + 2.0 * k3p + k4p);
                     f += h / 6.0 * (k1f + 2.0 * k2f + 2.0 * k3f + k4f);
                 }
             }
             if (g.traj) {
-                post(a, p, f, o);
+                post<RAW>(a, p, f, o);
                 double* st = stage + (lane * CH + j) * 3;
                 st[0] = o[0]; st[1] = o[1]; st[2] = o[2];
             }
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(64) void ode_rk4_kernel(OdeArgs g) {
         }
     }
     if (live) {
-        post(a, p, f, o);
+        post<RAW>(a, p, f, o);
         if (g.final_state) {
             g.final_state[3 * (size_t)b + 0] = o[0]; g.final_state[3 * (size_t)b + 1] = o[1];
             g.final_state[3 * (size_t)b + 2] = o[2];
@@ -110,17 +113,40 @@ __global__ __launch_bounds__(64) void ode_rk4_kernel(OdeArgs g) {
     }
 }
 
+// y0 = prob_to_ode_state(P(closed)) of 08_forecasting.py:215-234, one window per thread.
+__global__ void prob_to_state_kernel(const float* __restrict__ probs, double* __restrict__ y0, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double pc = (double)probs[2 * (size_t)b + 1];
+    const double A = 1.0 - pc;
+    double F, P;
+    if (probs[2 * (size_t)b + 1] > 0.5f) { F = pc * 0.6; P = pc * 0.4; } else { F = pc * 0.3; P = pc * 0.3; }
+    const double tot = A + P + F;
+    y0[3 * (size_t)b + 0] = A / tot; y0[3 * (size_t)b + 1] = P / tot; y0[3 * (size_t)b + 2] = F / tot;
+}
+
 }  // namespace
 
 extern "C" int lob_ode_rk4_f64(const float* probs, const double* y0_in, const double* base_rates,
                                double alpha, int n_points, double t0, double t1, int substeps,
-                               double* traj, double* final_state, int64_t* pred, int B, void* stream) {
+                               double* traj, double* final_state, int64_t* pred, int B, int flags,
+                               void* stream) {
     if (!base_rates || B <= 0 || n_points <= 0 || substeps <= 0) return LOB_E_ARG;
     if (!probs && !y0_in) return LOB_E_ARG;
     if (!traj && !final_state && !pred) return LOB_E_ARG;
     OdeArgs g{probs, y0_in, base_rates[0], base_rates[1], base_rates[2], base_rates[3], base_rates[4],
-              base_rates[5], alpha, n_points, substeps, t0, t1, traj, final_state, pred, B};
-    hipLaunchKernelGGL(ode_rk4_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, g);
+              base_rates[5], alpha, n_points, substeps, t0, t1, traj, final_state, pred, B, flags};
+    if (flags & LOB_ODE_RAW)
+        hipLaunchKernelGGL(ode_rk4_kernel<true>, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, g);
+    else
+        hipLaunchKernelGGL(ode_rk4_kernel<false>, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, g);
+    LOB_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int lob_prob_to_state_f64(const float* probs, double* y0, int B, void* stream) {
+    if (!probs || !y0 || B <= 0) return LOB_E_ARG;
+    hipLaunchKernelGGL(prob_to_state_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, probs, y0, B);
     LOB_CHECK_LAUNCH();
     return 0;
 }

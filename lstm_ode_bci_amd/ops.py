@@ -168,8 +168,17 @@ def softmax_rows(x):
     return out
 
 
+def prob_to_state(probs):
+    """y0 (B,3) f64 = prob_to_ode_state(P(closed)) (08_forecasting.py:215-234)."""
+    _chk(probs, "probs")
+    y0 = torch.empty((probs.shape[0], 3), device=probs.device, dtype=torch.float64)
+    rc = _lib.lib().lob_prob_to_state_f64(_ptr(probs), _ptr(y0), probs.shape[0], _stream())
+    _lib.check(rc, "lob_prob_to_state_f64")
+    return y0
+
+
 def ode_rk4(base_rates, n_points, t0, t1, substeps, *, probs=None, alpha=0.0, y0=None,
-            want_traj=True, want_final=False, want_pred=True):
+            want_traj=True, want_final=False, want_pred=True, raw=False):
     """Batched ODE solve.  probs (B,2) f32 -> coupled mode; y0 (B,3) f64 -> plain solve."""
     src = probs if probs is not None else y0
     B = src.shape[0]
@@ -183,7 +192,8 @@ def ode_rk4(base_rates, n_points, t0, t1, substeps, *, probs=None, alpha=0.0, y0
     pred = torch.empty((B,), device=dev, dtype=torch.int64) if want_pred else None
     rates = (C.c_double * 6)(*[float(r) for r in base_rates])
     rc = _lib.lib().lob_ode_rk4_f64(_ptr(probs), _ptr(y0), rates, float(alpha), int(n_points), float(t0),
-                                    float(t1), int(substeps), _ptr(traj), _ptr(final), _ptr(pred), B, _stream())
+                                    float(t1), int(substeps), _ptr(traj), _ptr(final), _ptr(pred), B, 1 if raw else 0,
+                                    _stream())
     _lib.check(rc, "lob_ode_rk4_f64")
     return traj, final, pred
 

@@ -237,3 +237,52 @@ def predict_from_probs(probs, base, alpha, forecast_steps, solver=solve_odeint):
         trajs.append(traj)
         preds.append(1 if traj[-1][2] > 0.5 else 0)
     return np.array(trajs), np.array(preds)
+
+
+# --------------------------------------------------------------------------- #
+# other consumers of the path: 08_forecasting.py, 10_three_state_probabilities.py
+# --------------------------------------------------------------------------- #
+def prob_to_ode_state(prob_closed):
+    """08_forecasting.py:215-234."""
+    A = 1.0 - prob_closed
+    if prob_closed > 0.5:
+        F, P = prob_closed * 0.6, prob_closed * 0.4
+    else:
+        F, P = prob_closed * 0.3, prob_closed * 0.3
+    total = A + P + F
+    return np.array([A / total, P / total, F / total])
+
+
+def raw_rhs(y, t, p):
+    """08_forecasting.py:132-146 (no clamp)."""
+    A, P, F = y
+    return [-p["k_ap"] * A - p["k_af"] * A + p["k_pa"] * P + p["k_fa"] * F,
+            p["k_ap"] * A - p["k_pa"] * P - p["k_pf"] * P + p["k_fp"] * F,
+            p["k_af"] * A + p["k_pf"] * P - p["k_fa"] * F - p["k_fp"] * F]
+
+
+def forecast_raw(initial_state, p, n_steps, dt=1.0):
+    """08_forecasting.py:149-153: raw odeint trajectory, n_steps+1 points, no post-processing."""
+    from scipy.integrate import odeint
+    t = np.linspace(0, n_steps * dt, n_steps + 1)
+    return odeint(raw_rhs, initial_state, t, args=(p,))
+
+
+def multistep_forecast(probs, p, horizons=(5, 10, 20)):
+    """08_forecasting.py:252-289."""
+    max_h = max(horizons)
+    res = {h: {"predictions": [], "actuals": []} for h in horizons}
+    for i in range(len(probs) - max_h):
+        traj = forecast_raw(prob_to_ode_state(probs[i, 1]), p, max_h)
+        for h in horizons:
+            res[h]["predictions"].append(np.clip(traj[h, 2] + traj[h, 1] * 0.5, 0, 1))
+            res[h]["actuals"].append(probs[i + h, 1])
+    return {h: {k: np.array(v) for k, v in r.items()} for h, r in res.items()}
+
+
+def three_state_from_probs(probs, base):
+    """Step 2 of 10_three_state_probabilities.py:239-290 (alpha = 0.5, 20 points over [0,20])."""
+    traj, _ = predict_from_probs(probs, base, 0.5, 20)
+    final = traj[:, -1]
+    pred = np.where(final[:, 2] > 0.5, 2, np.where(final[:, 0] > 0.5, 0, 1))
+    return final, pred

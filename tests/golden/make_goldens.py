@@ -207,6 +207,38 @@ def g4_coupled(g6):
     print("g4 probs", out["probs_default"][:4].ravel(), "pred", out["pred_fitted"][:8])
 
 
+def g5_consumers(g6, g8, g10):
+    """08_forecasting.py / 10_three_state_probabilities.py consumers on the G4 model and windows."""
+    C, H, T, N = 61, 128, 256, 32
+    d4 = np.load(os.path.join(HERE, "g4_coupled.npz"))
+    sd = syn.make_state_dict(C, H, 3, 2, True)
+    sd["classifier.6.weight"] = sd["classifier.6.weight"] * d4["cls6_scale"]
+    sd["classifier.6.bias"] = d4["cls6_bias"]
+    x, _ = syn.make_windows(N, T, C, seed=11)
+    out = {}
+    m10 = ref_model(g10, sd, C, H, 3, True)
+    for pname, rates in (("default", syn.DEFAULT_RATES), ("fitted", syn.FITTED_RATES)):
+        ode = g10["CognitiveStateODE"](dict(rates))
+        lp, three, pred = g10["get_three_state_probabilities"](m10, ode, x, batch_size=16)
+        out[f"three_lstm_probs_{pname}"] = lp
+        out[f"three_state_{pname}"] = three
+        out[f"three_pred_{pname}"] = pred
+    # 08: multistep_forecast on a probability series (the reference prints, so silence it)
+    import contextlib, io
+    probs = syn.make_probs(64, seed=3)
+    out["fc_probs"] = probs
+    for pname, rates in (("default", syn.DEFAULT_RATES), ("fitted", syn.FITTED_RATES)):
+        with contextlib.redirect_stdout(io.StringIO()):
+            res = g8["multistep_forecast"](probs, dict(rates), horizons=[5, 10, 20])
+        for h in (5, 10, 20):
+            out[f"fc_pred_{pname}_h{h}"] = res[h]["predictions"]
+            out[f"fc_act_{pname}_h{h}"] = res[h]["actuals"]
+        out[f"fc_traj_{pname}"] = g8["predict_trajectory"](g8["prob_to_ode_state"](probs[5, 1]), dict(rates), 20)
+    out["fc_state_grid"] = np.array([g8["prob_to_ode_state"](np.float32(p)) for p in np.linspace(0, 1, 21)])
+    np.savez_compressed(os.path.join(HERE, "g5_consumers.npz"), **out)
+    print("g5 three_pred", out["three_pred_fitted"][:12], "fc", out["fc_pred_fitted_h20"][:3])
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     g4 = load_ref("04_lstm_model.py")
@@ -216,3 +248,4 @@ if __name__ == "__main__":
     g2_full(g4)
     g3_ode(g5, g6)
     g4_coupled(g6)
+    g5_consumers(g6, load_ref("08_forecasting.py"), load_ref("10_three_state_probabilities.py"))

@@ -38,4 +38,4 @@ def test_argument_errors_without_a_gpu():
     assert L.lob_gemm_nt_f32(None, 1, None, 1, None, None, 1, 1, 1, 1, 0, None) == -1
     assert L.lob_softmax_rows_f32(None, None, 0, 0, None) == -1
     rates = (ctypes.c_double * 6)(*[0.1] * 6)
-    assert L.lob_ode_rk4_f64(None, None, rates, 0.5, 10, 0.0, 10.0, 16, None, None, None, 4, None) == -1
+    assert L.lob_ode_rk4_f64(None, None, rates, 0.5, 10, 0.0, 10.0, 16, None, None, None, 4, 0, None) == -1

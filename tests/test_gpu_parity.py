@@ -494,3 +494,37 @@ def test_mixed_precision_forward_backward(dev):
     with torch.no_grad():
         l2 = m(torch.from_numpy(x).to(dev))
     assert torch.equal(l2, logits)
+
+
+# ------------------------------------------------------------------------------------------
+# §8f consumers: 10_three_state_probabilities.py and 08_forecasting.py as batched device calls
+# ------------------------------------------------------------------------------------------
+def test_consumers_vs_reference(dev):
+    from lstm_ode_bci_amd import CognitiveStateODE, consumers
+    d = np.load(os.path.join(GOLDEN, "g5_consumers.npz"))
+    d4 = np.load(os.path.join(GOLDEN, "g4_coupled.npz"))
+    sd = syn.make_state_dict(61, 128, 3, 2, True)
+    sd["classifier.6.weight"] = sd["classifier.6.weight"] * d4["cls6_scale"]
+    sd["classifier.6.bias"] = d4["cls6_bias"]
+    x, _ = syn.make_windows(32, seed=11)
+    m = _model(sd, 61, 128, 3, True, dev)
+    for pname, rates in (("default", syn.DEFAULT_RATES), ("fitted", syn.FITTED_RATES)):
+        ode = CognitiveStateODE(dict(rates))
+        lp, three, pred = consumers.get_three_state_probabilities(m, ode, x, batch_size=16)
+        assert lp.shape == (32, 2) and three.shape == (32, 3) and three.dtype == np.float64
+        assert np.abs(lp - d[f"three_lstm_probs_{pname}"]).max() < 2e-3          # logits scaled x400
+        stable = (np.abs(d[f"three_lstm_probs_{pname}"] - 0.6).min(1) > 5e-3) & \
+                 (np.abs(d[f"three_lstm_probs_{pname}"] - 0.4).min(1) > 5e-3)
+        assert np.abs(three[stable] - d[f"three_state_{pname}"][stable]).max() < 2e-3
+        far = (np.abs(d[f"three_state_{pname}"] - 0.5).min(1) > 5e-3) & stable
+        assert np.array_equal(pred[far], d[f"three_pred_{pname}"][far])
+        assert ode.params == dict(rates)
+        # 08: multistep forecast from a probability series -- exact inputs, so tight tolerance
+        res = consumers.multistep_forecast(d["fc_probs"], dict(rates), horizons=[5, 10, 20])
+        for h in (5, 10, 20):
+            assert np.abs(res[h]["predictions"] - d[f"fc_pred_{pname}_h{h}"]).max() < 1e-6
+            assert np.array_equal(res[h]["actuals"], d[f"fc_act_{pname}_h{h}"])
+        tr = consumers.predict_trajectory(consumers.prob_to_ode_state(d["fc_probs"][5, 1]), dict(rates), 20)
+        assert tr.shape == (21, 3) and np.abs(tr - d[f"fc_traj_{pname}"]).max() < 1e-6
+    pr = consumers.get_lstm_probabilities(m, x, batch_size=8)
+    assert np.abs(pr - d["three_lstm_probs_default"]).max() < 2e-3

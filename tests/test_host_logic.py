@@ -98,3 +98,44 @@ def test_shard_bounds_cover_exactly():
                 assert b == c and b >= a
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_artifacts_round_trip_reference_formats(tmp_path):
+    """A checkpoint written in the reference's format (04:921-933) by a plain torch module with
+    the reference's layer stack loads strictly into the drop-in model; ode_model.pkl round-trips."""
+    import pickle
+    from lstm_ode_bci_amd import artifacts
+    from oracle import torch_cpu_path as TP
+    sd = syn.make_state_dict(61, 32, 2, 2, True)
+    ref_like = TP.build(sd, 61, 32, 2, 2, True)
+    cfg = {"input_size": 61, "hidden_size": 32, "num_layers": 2, "num_classes": 2, "dropout": 0.4,
+           "bidirectional": True, "num_heads": 4}
+    torch.save({"model_state_dict": ref_like.state_dict(), "model_config": cfg, "history": {"train_loss": [1.0]}},
+               tmp_path / artifacts.LSTM_FILE)
+    with open(tmp_path / artifacts.ODE_FILE, "wb") as f:
+        pickle.dump({"params": dict(syn.FITTED_RATES), "model_class": "CognitiveStateODE"}, f)
+    lstm, ode = artifacts.load_models(str(tmp_path), device="cpu")
+    assert isinstance(lstm, EnhancedLSTMModel) and not lstm.training and ode.params == syn.FITTED_RATES
+    for k, v in ref_like.state_dict().items():
+        assert torch.equal(lstm.state_dict()[k], v)
+    # and back: what we save, the reference-format reader (plain torch + pickle) can load strictly
+    artifacts.save_lstm_checkpoint(lstm, tmp_path / "out.pt", cfg, history={"val_f1": [0.5]})
+    ck = torch.load(tmp_path / "out.pt", weights_only=False)
+    assert set(ck) == {"model_state_dict", "model_config", "history"} and ck["model_config"] == cfg
+    TP.TorchCpuModel(61, 32, 2, 2, 0.4, True).load_state_dict(ck["model_state_dict"], strict=True)
+    artifacts.save_ode_model(ode, tmp_path / "ode2.pkl")
+    assert pickle.load(open(tmp_path / "ode2.pkl", "rb")) == {"params": dict(syn.FITTED_RATES),
+                                                               "model_class": "CognitiveStateODE"}
+    assert artifacts.model_config_of(lstm, 61) == cfg
+
+
+def test_consumer_signatures():
+    from lstm_ode_bci_amd import consumers
+    assert list(inspect.signature(consumers.get_three_state_probabilities).parameters) == \
+        ["lstm_model", "ode_model", "X", "batch_size"]
+    assert list(inspect.signature(consumers.multistep_forecast).parameters) == ["probs", "ode_params", "horizons"]
+    assert list(inspect.signature(consumers.predict_trajectory).parameters)[:4] == \
+        ["initial_state", "params", "n_steps", "dt"]
+    grid = np.load(os.path.join(GOLDEN, "g5_consumers.npz"))["fc_state_grid"]
+    got = np.array([consumers.prob_to_ode_state(np.float32(p)) for p in np.linspace(0, 1, 21)])
+    assert np.array_equal(got, grid)

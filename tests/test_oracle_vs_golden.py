@@ -126,3 +126,19 @@ def test_coupled_predict_batch():
         assert np.array_equal(traj, d["traj_" + pname])
         assert np.array_equal(pred, d["pred_" + pname])
     assert d["pred_fitted_a1"].sum() > 0 and (d["pred_fitted_a1"] == 0).sum() > 0
+
+
+def test_consumers_08_and_10():
+    d = np.load(os.path.join(GOLDEN, "g5_consumers.npz"))
+    for pname, rates in (("default", syn.DEFAULT_RATES), ("fitted", syn.FITTED_RATES)):
+        final, pred = R.three_state_from_probs(d[f"three_lstm_probs_{pname}"], rates)
+        assert np.array_equal(final, d[f"three_state_{pname}"])
+        assert np.array_equal(pred, d[f"three_pred_{pname}"])
+        res = R.multistep_forecast(d["fc_probs"], rates)
+        for h in (5, 10, 20):
+            assert np.array_equal(res[h]["predictions"], d[f"fc_pred_{pname}_h{h}"])
+            assert np.array_equal(res[h]["actuals"], d[f"fc_act_{pname}_h{h}"])
+        assert np.array_equal(R.forecast_raw(R.prob_to_ode_state(d["fc_probs"][5, 1]), rates, 20), d[f"fc_traj_{pname}"])
+    grid = np.array([R.prob_to_ode_state(np.float32(p)) for p in np.linspace(0, 1, 21)])
+    assert np.array_equal(grid, d["fc_state_grid"])
+    assert set(np.unique(d["three_pred_fitted"])) >= {0, 1}
