@@ -83,6 +83,11 @@ int lob_gate_gemm_x_f32(const float* X, int ldx, const float* Wih, const float* 
 int lob_lstm_rec_fwd_f32(float* P, const float* Whh, float* Y, float* Csave,
                          int T, int Bp, int H, int D, int save, void* stream);
 
+/* 1 if the recurrent kernels for hidden size H use the fragment layout (H = 32, 64, 128, 256:
+ * MFMA kernels; W_hh register-resident at 128, streamed from L2 otherwise), 0 for the generic
+ * row-major VALU path.  Pass this as `frag` to lob_gate_gemm_x_f32.                        */
+int lob_lstm_uses_fragment_layout(int H);
+
 /* Backward of the above (BPTT through time), one persistent kernel, both directions:
  *   G      activated gates saved by the forward (save = 1), same layout as P; READ-ONLY
  *   Csave  cell states saved by the forward; READ-ONLY (backward is re-entrant, 07:254)

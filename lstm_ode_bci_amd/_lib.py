@@ -13,6 +13,7 @@ _lib = None
 _f32p = C.c_void_p
 _SIGS = {
     "lob_version": ([], C.c_int),
+    "lob_lstm_uses_fragment_layout": ([C.c_int], C.c_int),
     "lob_gemm_nt_f32": ([_f32p, C.c_int, _f32p, C.c_int, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int,
                          C.c_int, C.c_void_p], C.c_int),
     "lob_gemm_tn_f32": ([_f32p, C.c_int, _f32p, C.c_int, _f32p, C.c_int, C.c_int, C.c_int, C.c_int,

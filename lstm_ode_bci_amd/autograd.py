@@ -47,7 +47,7 @@ def _forward_impl(x, ps, cfg, save):
     B, T, C = x.shape
     Bp = ceil32(B)
     W = H * D
-    frag = (H == 128)
+    frag = ops.uses_frag(H)
     x2d = x.reshape(B * T, C)
     it = iter(ps)
     proj_w, proj_b, ln0_g, ln0_b = next(it), next(it), next(it), next(it)

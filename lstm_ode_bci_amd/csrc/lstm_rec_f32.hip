@@ -17,6 +17,12 @@
 // it exists so that every (H, num_layers, bidirectional) the reference accepts runs.
 #include "lob_common.h"
 
+// H = 32 / 64 / 256: W_hh streamed from L2 (lstm_rec_stream.hip)
+int lob_stream_supports(int H);
+int lob_stream_fwd(float* P, const float* Whh, float* Y, float* Csave, int T, int Bp, int H, int D, int save, hipStream_t s);
+int lob_stream_bwd(const float* G, const float* Cs, const float* Whh, const float* dY, void* dP, int bf, float* dbias,
+                   int T, int Bp, int H, int D, hipStream_t s);
+
 namespace {
 
 #ifndef LOB_SAVE_WLDS
@@ -454,6 +460,10 @@ extern "C" int lob_lstm_rec_fwd_f32(float* P, const float* Whh, float* Y, float*
         const dim3 grid(Bp / 32, D), block(256);
         if (save) hipLaunchKernelGGL((lstm_rec_fwd_h128_kernel<true, SAVE_WLDS>), grid, block, 0, s, P, Whh, Y, Csave, T, Bp);
         else      hipLaunchKernelGGL((lstm_rec_fwd_h128_kernel<false, false>), grid, block, 0, s, P, Whh, Y, Csave, T, Bp);
+    } else if (lob_stream_supports(H) && Bp % 32 == 0) {
+        if ((reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(Whh) |
+             reinterpret_cast<uintptr_t>(Csave)) & 15) return LOB_E_ALIGN;
+        return lob_stream_fwd(P, Whh, Y, Csave, T, Bp, H, D, save, s);
     } else {
         const dim3 grid((Bp + RB - 1) / RB, D), block(256);
         const size_t smem = (size_t)3 * RB * H * sizeof(float);
@@ -476,6 +486,10 @@ extern "C" int lob_lstm_rec_bwd_f32(const float* G, const float* Csave, const fl
              reinterpret_cast<uintptr_t>(dP)) & 15) return LOB_E_ALIGN;
         if (dp_bf16) hipLaunchKernelGGL((lstm_rec_bwd_h128_kernel<true>), dim3(Bp / 32, D), dim3(256), 0, s, G, Csave, Whh, dY, dP, dbias, T, Bp);
         else         hipLaunchKernelGGL((lstm_rec_bwd_h128_kernel<false>), dim3(Bp / 32, D), dim3(256), 0, s, G, Csave, Whh, dY, dP, dbias, T, Bp);
+    } else if (lob_stream_supports(H) && Bp % 32 == 0) {
+        if ((reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(Csave) |
+             reinterpret_cast<uintptr_t>(dP)) & 15) return LOB_E_ALIGN;
+        return lob_stream_bwd(G, Csave, Whh, dY, dP, dp_bf16, dbias, T, Bp, H, D, s);
     } else {
         if (dbias) return LOB_E_SHAPE;      // the generic path leaves the bias gradient to lob_colsum_f32
         const size_t smem = (size_t)6 * RB * H * sizeof(float);
@@ -487,3 +501,7 @@ extern "C" int lob_lstm_rec_bwd_f32(const float* G, const float* Csave, const fl
     LOB_CHECK_LAUNCH();
     return 0;
 }
+
+// 1 when the recurrent kernels for this H consume / produce the accumulator-fragment layout
+// (P from lob_gate_gemm_x_* with frag = 1, fused bias gradient), 0 for the row-major generic path.
+extern "C" int lob_lstm_uses_fragment_layout(int H) { return (H == 128 || lob_stream_supports(H)) ? 1 : 0; }

@@ -31,6 +31,10 @@ def _chk(t, name, dtype=torch.float32):
         raise _lib.LobError(f"{name}: expected a contiguous tensor")
 
 
+def uses_frag(H):
+    return bool(_lib.lib().lob_lstm_uses_fragment_layout(int(H)))
+
+
 def ceil32(n):
     return (n + 31) // 32 * 32
 
@@ -206,7 +210,7 @@ def lstm_rec_bwd(G, Cs, whh, dY, T, Bp, H, D, dp_bf16=False):
     _chk(G, "G"); _chk(Cs, "Csave"); _chk(whh, "whh"); _chk(dY, "dY")
     assert dY.shape == (T * Bp, D * H)
     dP = torch.empty((T * Bp, D * 4 * H), device=G.device, dtype=torch.bfloat16 if dp_bf16 else torch.float32)
-    fused_bias = (H == 128)
+    fused_bias = uses_frag(H)
     dbias = torch.zeros((D * 4 * H,), device=G.device, dtype=torch.float32)
     if dp_bf16 and H == 128:
         rc = _lib.lib().lob_lstm_rec_bwd_bf16(_ptr(G), _ptr(Cs), _ptr(whh), _ptr(dY), _ptr(dP), _ptr(dbias),

@@ -88,7 +88,7 @@ def test_layernorm_remap_and_gelu(dev):
         assert np.abs(o2 - R.layer_norm(x2.astype(np.float64), g2, b2)).max() < 2e-6
 
 
-@pytest.mark.parametrize("H,D,B", [(128, 2, 40), (128, 1, 32), (8, 2, 3), (32, 2, 5), (64, 1, 9)])
+@pytest.mark.parametrize("H,D,B", [(128, 2, 40), (128, 1, 32), (8, 2, 3), (32, 2, 5), (64, 1, 9), (256, 2, 33), (96, 2, 7)])
 def test_lstm_layer_vs_oracle(dev, H, D, B):
     """gate GEMM + persistent recurrent kernel (fast H=128 path and generic path) vs the numpy
     restatement of one layer."""
@@ -107,7 +107,7 @@ def test_lstm_layer_vs_oracle(dev, H, D, B):
     whh = torch.from_numpy(np.stack([w[1] for w in ws], 0)).to(dev)
     bias = torch.from_numpy(np.concatenate([w[2] + w[3] for w in ws], 0)).to(dev)
     for save in (False, True):
-        P = ops.gate_gemm_x(torch.from_numpy(xt.reshape(T * Bp, K)).to(dev), wih, bias, T, Bp, H, D, H == 128)
+        P = ops.gate_gemm_x(torch.from_numpy(xt.reshape(T * Bp, K)).to(dev), wih, bias, T, Bp, H, D, ops.uses_frag(H))
         Y, Cs = ops.lstm_rec_fwd(P, whh, T, Bp, H, D, save)
         y = Y.cpu().numpy().reshape(T, Bp, D * H)[:, :B].transpose(1, 0, 2)
         ref = np.concatenate([R.lstm_direction(x.astype(np.float64), *[w.astype(np.float64) for w in ws[d]], d == 1)
@@ -528,3 +528,30 @@ def test_consumers_vs_reference(dev):
         assert tr.shape == (21, 3) and np.abs(tr - d[f"fc_traj_{pname}"]).max() < 1e-6
     pr = consumers.get_lstm_probabilities(m, x, batch_size=8)
     assert np.abs(pr - d["three_lstm_probs_default"]).max() < 2e-3
+
+
+@pytest.mark.parametrize("H,L,bi", [(256, 3, True), (64, 2, True), (32, 1, False)])
+def test_streaming_kernels_forward_backward_vs_oracle(dev, H, L, bi):
+    """H = 256 (the reference's real checkpoints) / 64 / 32: MFMA kernels with W_hh streamed from L2."""
+    from oracle import torch_cpu_path as TP
+    from lstm_ode_bci_amd import ops
+    assert ops.uses_frag(H)
+    sd = syn.make_state_dict(61, H, L, 2, bi, seed=77)
+    x, y = syn.make_windows(37, 48, 61, seed=6)
+    m = _model(sd, 61, H, L, bi, dev)
+    ref = TP.build(sd, 61, H, L, 2, bi)
+    rl, rgp, rgx = TP.loss_and_grads(ref, torch.from_numpy(x), torch.from_numpy(y))
+    loss, gp, gx = _grads(m, x, y, dev)
+    assert abs(loss - rl) < 1e-5
+    assert _close(gx, rgx)
+    for k in rgp:
+        assert _close(gp[k], rgp[k]), (k, np.abs(gp[k] - rgp[k]).max(), np.abs(rgp[k]).max())
+    with torch.autocast("cuda", dtype=torch.bfloat16):      # mixed mode: bf16 GEMMs around the fp32 stream kernels
+        m.zero_grad(set_to_none=True)
+        xg = torch.from_numpy(x).to(dev).requires_grad_(True)
+        l2 = torch.nn.functional.cross_entropy(m(xg).float(), torch.from_numpy(y).to(dev))
+    l2.backward()
+    assert abs(float(l2) - rl) < 5e-3
+    for k, p in m.named_parameters():
+        if np.abs(rgp[k]).max() > 1e-7:
+            assert np.abs(p.grad.cpu().numpy() - rgp[k]).max() / np.abs(rgp[k]).max() < 2e-2, k
