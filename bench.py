@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--mode", default=None, choices=["train", "fwd", "coupled"])
     ap.add_argument("--batch", type=int, default=4096, help="windows per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--hidden", type=int, default=128, help="hidden size (128 = BASELINE configs; 256 = real checkpoints)")
     ap.add_argument("--forecast-steps", type=int, default=300)
     ap.add_argument("--precision", default=None, choices=["fp32", "mixed"],
                     help="mixed = bf16 MFMA inputs for the gate GEMMs under autocast, fp32 recurrence/accumulate "
@@ -180,7 +181,11 @@ def cpu_baseline(mode, sd):
 
 
 def main():
+    global H, GATE_FLOP_FWD
     a = parse()
+    if a.hidden != H:
+        GATE_FLOP_FWD = GATE_FLOP_FWD * (a.hidden // 128) ** 2 if a.hidden % 128 == 0 else int(GATE_FLOP_FWD * (a.hidden / 128) ** 2)
+        H = a.hidden
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

@@ -28,7 +28,7 @@ __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
 
 struct NTArgs {
     const void* A; const float* W; const float* bias; float* C;
-    int lda, ldw, ldc, M, N, K, act, accumulate;
+    int lda, ldw, ldc, M, N, K, act, accumulate, dbg;
     int T, Bp, H, D;     // fragment epilogue
 };
 
@@ -100,6 +100,16 @@ __device__ __forceinline__ void mma_tile(const __bf16* As, const __bf16* Bs, int
     }
 }
 
+// PERSISTENT workgroups: the grid is one wave of resident workgroups (3 per CU at TKT = 32), each
+// walking its own sequence of output tiles.  Two things a one-tile-per-workgroup grid cannot do:
+// the first operand tile of the NEXT output tile is requested before the epilogue of the current
+// one (its HBM latency hides behind 64 KB of stores), and a workgroup slot is never idle while
+// stores drain at wave exit.  Measured on the K=256 gate GEMM: loads and stores were additive
+// (0.67 ms compute + 0.6 loads + 0.75 stores); overlapped they approach the HBM floor.
+//
+// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so XCD x owns the row
+// panels mt = x (mod 8) and sweeps the N tiles of one panel back to back: an A panel is pulled
+// through the fabric once, into one L2.
 template <bool A_BF16, int EPI, int TKT>
 __global__ __launch_bounds__(256, TKT == 32 ? 3 : 2) void gemm_nt_bf16_kernel(NTArgs g) {
     constexpr int LD = TKT + 8;
@@ -108,27 +118,15 @@ __global__ __launch_bounds__(256, TKT == 32 ? 3 : 2) void gemm_nt_bf16_kernel(NT
     __bf16* Ws = lds + 2 * TM * LD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    // XCD-aware tile order: blocks are dealt round-robin over the 8 XCDs, so give XCD x the row
-    // panels mt = x (mod 8) and let consecutive blocks of one XCD sweep the N tiles of ONE row panel:
-    // the A panel is then pulled through the fabric once (into one L2) instead of once per XCD.
     const int ntn = (g.N + TN_ - 1) / TN_, ntm = (g.M + TM - 1) / TM;
-    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-    const int mt = (jb / ntn) * 8 + xcd;
-    if (mt >= ntm) return;
-    const int m0 = mt * TM, n0 = (jb % ntn) * TN_;
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+    const int panels = (ntm - xcd + 7) / 8;            // row panels owned by this XCD
+    const int ntile = panels * ntn;                    // tiles of this XCD, panel-major
+    const int nk = (g.K + TKT - 1) / TKT;
 
     f32x4 ra[TKT / 8], rw[TKT / 8];
     bf16x8 rab[TKT / 16];
-    const int nk = (g.K + TKT - 1) / TKT;
-    auto load = [&](int k0) {
+    auto load = [&](int m0, int n0, int k0) {
         if (A_BF16) ld_rows_bf16<TKT>(reinterpret_cast<const __bf16*>(g.A), g.lda, m0, g.M, k0, g.K, tid, rab);
         else        ld_rows_f32<TKT>(reinterpret_cast<const float*>(g.A), g.lda, m0, g.M, k0, g.K, tid, ra);
         ld_rows_f32<TKT>(g.W, g.ldw, n0, g.N, k0, g.K, tid, rw);
@@ -137,58 +135,84 @@ __global__ __launch_bounds__(256, TKT == 32 ? 3 : 2) void gemm_nt_bf16_kernel(NT
         if (A_BF16) st_rows_bf16<TKT>(As + b * TM * LD, tid, rab); else st_rows_f32<TKT>(As + b * TM * LD, tid, ra);
         st_rows_f32<TKT>(Ws + b * TM * LD, tid, rw);
     };
-    load(0);
-    store(0);
-    __syncthreads();
-    int buf = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) load((kt + 1) * TKT);
-        mma_tile<TKT>(As + buf * TM * LD, Ws + buf * TM * LD, wr, wc, lane, acc);
-        if (kt + 1 < nk) store(buf ^ 1);
-        __syncthreads();
-        buf ^= 1;
-    }
 
-    if (EPI == 0) {
+    int it = slot;
+    if (it >= ntile) return;
+    int m0 = ((it / ntn) * 8 + xcd) * TM, n0 = (it % ntn) * TN_;
+    load(m0, n0, 0);
+    while (true) {
+        f32x16 acc[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = n0 + 64 * wc + 32 * j + (lane & 31);
-                if (col >= g.N) continue;
-                const float bv = g.bias ? g.bias[col] : 0.f;
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + 64 * wr + 32 * i + acc_row(r, lane);
-                    if (row < g.M) {
-                        float* dst = g.C + (size_t)row * g.ldc + col;
-                        const float val = apply_act(acc[i][j][r] + bv, g.act);
-                        *dst = g.accumulate ? *dst + val : val;
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        store(0);
+        __syncthreads();
+        int buf = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk && !(g.dbg & 2)) load(m0, n0, (kt + 1) * TKT);
+            mma_tile<TKT>(As + buf * TM * LD, Ws + buf * TM * LD, wr, wc, lane, acc);
+            if (kt + 1 < nk) store(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+        // request the next tile's first operand tiles BEFORE this tile's stores
+        const int nit = it + nslot;
+        const bool more = nit < ntile;
+        const int cm0 = m0, cn0 = n0;
+        if (more) {
+            m0 = ((nit / ntn) * 8 + xcd) * TM; n0 = (nit % ntn) * TN_;
+            load(m0, n0, 0);
+        }
+        if (!(g.dbg & 1)) {
+            if (EPI == 0) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int col = cn0 + 64 * wc + 32 * j + (lane & 31);
+                        if (col >= g.N) continue;
+                        const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = cm0 + 64 * wr + 32 * i + acc_row(r, lane);
+                            if (row < g.M) {
+                                float* dst = g.C + (size_t)row * g.ldc + col;
+                                const float val = apply_act(acc[i][j][r] + bv, g.act);
+                                *dst = g.accumulate ? *dst + val : val;
+                            }
+                        }
+                    }
+            } else {
+                const int NBT = g.Bp >> 5, NW = g.H >> 5, H4 = 4 * g.H;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int mrow = cm0 + 64 * wr + 32 * i;
+                    if (mrow >= g.M) continue;
+                    const int t = mrow / g.Bp, bt = (mrow % g.Bp) >> 5;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int ncol = cn0 + 64 * wc + 32 * j;
+                        if (ncol >= g.N) continue;
+                        const int d = ncol / H4, gg = (ncol % H4) / g.H, w = (ncol % g.H) >> 5;
+                        const float bv = g.bias ? g.bias[ncol + (lane & 31)] : 0.f;
+                        float* dst = g.C + ((((size_t)(d * g.T + t) * NBT + bt) * NW + w) * 4 + gg) * 1024 + lane * 4;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            f32x4 v = {acc[i][j][4 * q + 0] + bv, acc[i][j][4 * q + 1] + bv,
+                                       acc[i][j][4 * q + 2] + bv, acc[i][j][4 * q + 3] + bv};
+                            *reinterpret_cast<f32x4*>(dst + q * 256) = v;
+                        }
                     }
                 }
             }
-    } else {
-        const int NBT = g.Bp >> 5, NW = g.H >> 5, H4 = 4 * g.H;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int mrow = m0 + 64 * wr + 32 * i;
-            if (mrow >= g.M) continue;
-            const int t = mrow / g.Bp, bt = (mrow % g.Bp) >> 5;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int ncol = n0 + 64 * wc + 32 * j;
-                if (ncol >= g.N) continue;
-                const int d = ncol / H4, gg = (ncol % H4) / g.H, w = (ncol % g.H) >> 5;
-                const float bv = g.bias ? g.bias[ncol + (lane & 31)] : 0.f;
-                float* dst = g.C + ((((size_t)(d * g.T + t) * NBT + bt) * NW + w) * 4 + gg) * 1024 + lane * 4;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x4 v = {acc[i][j][4 * q + 0] + bv, acc[i][j][4 * q + 1] + bv,
-                               acc[i][j][4 * q + 2] + bv, acc[i][j][4 * q + 3] + bv};
-                    *reinterpret_cast<f32x4*>(dst + q * 256) = v;
-                }
-            }
+        } else if (acc[0][0][0] + acc[1][1][5] == 12345.678f) {
+            g.C[0] = 1.f;     // timing experiments: keep the accumulators alive
         }
+        if (!more) break;
+        it = nit;
     }
 }
 
@@ -351,6 +375,20 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const __bf16* __restri
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+inline int dbg_flags() {
+    static const int v = [] { const char* e = getenv("LOB_DBG"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
+// persistent grid of the NT kernel: one resident wave of workgroups (multiple of 8 for the XCD map)
+inline int nt_grid(int M, int N) {
+    const long tiles = (long)((M + TM - 1) / TM) * ((N + TN_ - 1) / TN_);
+    static const int per_cu = [] { const char* e = getenv("LOB_NT_WGS"); return e ? atoi(e) : 3; }();
+    long gsz = 256L * per_cu;
+    if (gsz > tiles) gsz = ((tiles + 7) / 8) * 8;
+    return (int)gsz;
+}
+
 // contraction depth per LDS stage of the NT kernel (tuning knob; LOB_NT_TK=32|64)
 inline int nt_tk() {
     static const int v = [] { const char* e = getenv("LOB_NT_TK"); return (e && atoi(e) == 64) ? 64 : 32; }();
@@ -366,8 +404,8 @@ extern "C" int lob_gemm_nt_bf16(const void* A, int a_bf16, int lda, const float*
     if (lda < K || ldw < K || ldc < N) return LOB_E_SHAPE;
     if ((act & 0xff) > LOB_ACT_GELU || act < 0) return LOB_E_ARG;
     if (!al16(A) || !al16(W) || (K % 8) || (lda % 8) || (ldw % 4)) return LOB_E_ALIGN;
-    NTArgs g{A, W, bias, C, lda, ldw, ldc, M, N, K, act & 0xff, (act >> 8) & 1, 0, 0, 0, 0};
-    const dim3 grid((unsigned)((((M + TM - 1) / TM + 7) / 8) * 8 * ((N + TN_ - 1) / TN_))), block(256);
+    NTArgs g{A, W, bias, C, lda, ldw, ldc, M, N, K, act & 0xff, (act >> 8) & 1, dbg_flags(), 0, 0, 0, 0};
+    const dim3 grid((unsigned)nt_grid(M, N)), block(256);
     const bool tk32 = nt_tk() == 32;
     if (a_bf16) {
         if (tk32) hipLaunchKernelGGL((gemm_nt_bf16_kernel<true, 0, 32>), grid, block, 0, (hipStream_t)stream, g);
@@ -386,8 +424,8 @@ extern "C" int lob_gate_gemm_x_bf16(const float* X, int ldx, const float* Wih, c
     if (ldx < K || (H % 32) || (Bp % 32)) return LOB_E_SHAPE;
     if (!al16(X) || !al16(Wih) || !al16(P) || (K % 8) || (ldx % 8)) return LOB_E_ALIGN;
     const int N = D * 4 * H, M = T * Bp;
-    NTArgs g{X, Wih, bias, P, ldx, K, N, M, N, K, LOB_ACT_NONE, 0, T, Bp, H, D};
-    const dim3 grid((unsigned)((((M + TM - 1) / TM + 7) / 8) * 8 * ((N + TN_ - 1) / TN_))), block(256);
+    NTArgs g{X, Wih, bias, P, ldx, K, N, M, N, K, LOB_ACT_NONE, 0, dbg_flags(), T, Bp, H, D};
+    const dim3 grid((unsigned)nt_grid(M, N)), block(256);
     if (nt_tk() == 32) hipLaunchKernelGGL((gemm_nt_bf16_kernel<false, 1, 32>), grid, block, 0, (hipStream_t)stream, g);
     else               hipLaunchKernelGGL((gemm_nt_bf16_kernel<false, 1, 64>), grid, block, 0, (hipStream_t)stream, g);
     LOB_CHECK_LAUNCH();

@@ -15,7 +15,7 @@ template <int HH, bool SAVE>
 __global__ __launch_bounds__(HH * 2, (HH > 128) ? 2 : 1) void lstm_rec_fwd_stream_kernel(
     float* __restrict__ P, const float* __restrict__ Whh, float* __restrict__ Y,
     float* __restrict__ Csave, int T, int Bp) {
-    constexpr int NW = HH / 32, HLD = HH + 4;
+    constexpr int NW = HH / 32, HLD = HH + 4, KB_UNROLL = (NW > 4 ? 1 : NW);
     __shared__ __attribute__((aligned(16))) float hs[2 * 32 * HLD];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(HH * 2, (HH > 128) ? 2 : 1) void lstm_rec_fwd_strea
         const float* hrow = hs + cur * 32 * HLD + l31 * HLD + 16 * hi;
         // one k-block (16 float4 of W per lane) in flight at a time at H = 256: the register budget is
         // 256 per wave (2 waves per SIMD), and the partner wave's MFMAs cover the L2 latency
-#pragma unroll(NW > 4 ? 1 : NW)
+#pragma unroll KB_UNROLL
         for (int kb = 0; kb < NW; ++kb) {
             f32x4 a[4];
 #pragma unroll
@@ -126,7 +126,7 @@ template <int HH, bool DP_BF16>
 __global__ __launch_bounds__(HH * 2, (HH > 128) ? 2 : 1) void lstm_rec_bwd_stream_kernel(
     const float* __restrict__ G, const float* __restrict__ Csave, const float* __restrict__ Whh,
     const float* __restrict__ dY, void* __restrict__ dPv, float* __restrict__ dbias, int T, int Bp) {
-    constexpr int NW = HH / 32, DGLD = 4 * HH + 4;
+    constexpr int NW = HH / 32, DGLD = 4 * HH + 4, NB_UNROLL = (NW > 4 ? 1 : 4);
     __shared__ __attribute__((aligned(16))) float dgs[32 * DGLD];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(HH * 2, (HH > 128) ? 2 : 1) void lstm_rec_bwd_strea
 #pragma unroll
         for (int r = 0; r < 16; ++r) dhrec[r] = 0.f;
         const float* arow = dgs + l31 * DGLD + 16 * hi;
-#pragma unroll(NW > 4 ? 1 : 4)
+#pragma unroll NB_UNROLL
         for (int nb = 0; nb < 4 * NW; ++nb) {
             f32x4 a[4];
 #pragma unroll

@@ -206,6 +206,129 @@ __global__ __launch_bounds__(256) void layernorm_act_bwd_kernel(
     }
 }
 
+
+// Vectorised variants for width = 64 * VPL (VPL = 2, 4, 8: widths 128, 256, 512): lane l owns the
+// VPL contiguous columns [l*VPL, (l+1)*VPL), so a row is ONE 8/16/32-byte load per lane (a wave reads
+// the whole row as one contiguous 512 B..2 KB burst) instead of VPL strided dword loads.
+template <int VPL>
+__device__ __forceinline__ void ldv(const float* p, float (&v)[VPL]) {
+    if (VPL == 2) { const float2 t = *reinterpret_cast<const float2*>(p); v[0] = t.x; v[1] = t.y; }
+    else {
+#pragma unroll
+        for (int i = 0; i < VPL / 4; ++i) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(p + 4 * i);
+            v[4 * i] = t[0]; v[4 * i + 1] = t[1]; v[4 * i + 2] = t[2]; v[4 * i + 3] = t[3];
+        }
+    }
+}
+template <int VPL>
+__device__ __forceinline__ void stv(float* p, const float (&v)[VPL]) {
+    if (VPL == 2) { *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]); }
+    else {
+#pragma unroll
+        for (int i = 0; i < VPL / 4; ++i) {
+            f32x4 t = {v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+            *reinterpret_cast<f32x4*>(p + 4 * i) = t;
+        }
+    }
+}
+
+template <int VPL>
+__global__ __launch_bounds__(256) void layernorm_act_vec_kernel(
+    const float* __restrict__ in, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ out, int rows, float eps, int act,
+    int remap_T, int remap_B, int remap_Bp, float drop_p, uint64_t seed) {
+    constexpr int width = 64 * VPL;
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    float gm[VPL], bt[VPL];
+    ldv<VPL>(gamma + lane * VPL, gm);
+    ldv<VPL>(beta + lane * VPL, bt);
+    const float invw = 1.0f / (float)width;
+    for (int row = wave; row < rows; row += nwaves) {
+        float v[VPL];
+        ldv<VPL>(in + (size_t)row * width + lane * VPL, v);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) s += v[i];
+        const float mean = wave_sum(s) * invw;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) { const float dl = v[i] - mean; q += dl * dl; }
+        const float rstd = rsqrtf(wave_sum(q) * invw + eps);
+        int orow = row;
+        if (remap_T > 0) { const int b = row / remap_T, t = row % remap_T; orow = t * remap_Bp + b; }
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            float o = (v[i] - mean) * rstd * gm[i] + bt[i];
+            o = apply_act(o, act);
+            if (drop_p > 0.f) o *= lob_dropout_scale(seed, (uint64_t)orow * width + lane * VPL + i, drop_p);
+            v[i] = o;
+        }
+        stv<VPL>(out + (size_t)orow * width + lane * VPL, v);
+    }
+}
+
+template <int VPL>
+__global__ __launch_bounds__(256) void layernorm_act_bwd_vec_kernel(
+    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
+    int rows, float eps, int act, int remap_T, int remap_B, int remap_Bp, float drop_p, uint64_t seed) {
+    constexpr int width = 64 * VPL;
+    __shared__ float red[2][4][width];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    float gm[VPL], bt[VPL], dga[VPL], dba[VPL];
+    ldv<VPL>(gamma + lane * VPL, gm);
+    ldv<VPL>(beta + lane * VPL, bt);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) { dga[i] = 0.f; dba[i] = 0.f; }
+    const float invw = 1.0f / (float)width;
+    for (int row = wave; row < rows; row += nwaves) {
+        int orow = row;
+        if (remap_T > 0) { const int b = row / remap_T, t = row % remap_T; orow = t * remap_Bp + b; }
+        float v[VPL], go[VPL];
+        ldv<VPL>(x + (size_t)row * width + lane * VPL, v);
+        ldv<VPL>(dy + (size_t)orow * width + lane * VPL, go);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) s += v[i];
+        const float mean = wave_sum(s) * invw;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) { const float dl = v[i] - mean; q += dl * dl; }
+        const float rstd = rsqrtf(wave_sum(q) * invw + eps);
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const float xh = (v[i] - mean) * rstd;
+            float g = go[i];
+            if (drop_p > 0.f) g *= lob_dropout_scale(seed, (uint64_t)orow * width + lane * VPL + i, drop_p);
+            if (act == LOB_ACT_GELU) g *= gelu_grad(xh * gm[i] + bt[i]);
+            dga[i] += g * xh;
+            dba[i] += g;
+            const float dxh = g * gm[i];
+            v[i] = xh; go[i] = dxh;
+            m1 += dxh; m2 += dxh * xh;
+        }
+        m1 = wave_sum(m1) * invw;
+        m2 = wave_sum(m2) * invw;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) v[i] = rstd * (go[i] - m1 - v[i] * m2);
+        stv<VPL>(dx + (size_t)row * width + lane * VPL, v);
+    }
+    // block-level reduction of the affine gradients, then ONE atomic per column per block
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) { red[0][wib][lane * VPL + i] = dga[i]; red[1][wib][lane * VPL + i] = dba[i]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < width; c += 256) {
+        atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+        atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+    }
+}
+
 // Backward of attn_pool_fwd_kernel, one workgroup per window.
 //   dV[t,b,:]    = a[t] * dctx[b,:]                      (the W1 path is added by a GEMM afterwards)
 //   ds[t]        = a[t] * (da[t] - sum_t a da),  da[t] = dctx . V[t,b,:]
@@ -281,8 +404,17 @@ extern "C" int lob_layernorm_act_f32(const float* in, const float* gamma, const 
     const int waves_per_block = 4;
     int blocks = (rows + waves_per_block - 1) / waves_per_block;
     if (blocks > 256 * 16) blocks = 256 * 16;
+    const bool al = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) |
+                      reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) == 0;
+#define LOB_LN_VEC(V) hipLaunchKernelGGL((layernorm_act_vec_kernel<V>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, \
+                       in, gamma, beta, out, rows, eps, act, remap_T, remap_B, remap_Bp, drop_p, seed)
+    if (al && width == 128) LOB_LN_VEC(2);
+    else if (al && width == 256) LOB_LN_VEC(4);
+    else if (al && width == 512) LOB_LN_VEC(8);
+    else
     hipLaunchKernelGGL(layernorm_act_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        in, gamma, beta, out, rows, width, eps, act, remap_T, remap_B, remap_Bp, drop_p, seed);
+#undef LOB_LN_VEC
     LOB_CHECK_LAUNCH();
     return 0;
 }
@@ -333,6 +465,17 @@ extern "C" int lob_layernorm_act_bwd_f32(const float* x, const float* gamma, con
     if (drop_p < 0.f || drop_p >= 1.f) return LOB_E_ARG;
     if (remap_T > 0 && (remap_B <= 0 || remap_Bp < remap_B || rows != remap_T * remap_B)) return LOB_E_SHAPE;
     int blocks = (rows + 3) / 4;
+    const bool al = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx) |
+                      reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) == 0;
+    if (al && (width == 128 || width == 256 || width == 512)) {
+        if (blocks > 256 * 8) blocks = 256 * 8;
+#define LOB_LNB_VEC(V) hipLaunchKernelGGL((layernorm_act_bwd_vec_kernel<V>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, \
+                       x, gamma, beta, dy, dx, dgamma, dbeta, rows, eps, act, remap_T, remap_B, remap_Bp, drop_p, seed)
+        if (width == 128) LOB_LNB_VEC(2); else if (width == 256) LOB_LNB_VEC(4); else LOB_LNB_VEC(8);
+#undef LOB_LNB_VEC
+        LOB_CHECK_LAUNCH();
+        return 0;
+    }
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(layernorm_act_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, dy,
                        dx, dgamma, dbeta, rows, width, eps, act, remap_T, remap_B, remap_Bp, drop_p, seed);
