@@ -107,14 +107,14 @@ def kernel_roofline(dev, B, mode, precision):
             return ops.lstm_rec_fwd(Pk, whh, T, Bp, H, D, True, mixed=mixed)
         t_copy = timeit(lambda: Pk.copy_(P))
         sec = timeit(rec_fwd, n=3) - t_copy
-        Y, Cs = rec_fwd()
+        Y, Cs, _ = rec_fwd()
         out["lstm_rec_fwd(save)"] = {"sec": sec, "flop": 2.0 * rows * N * H, "per_step": L,
-                                     "mfma": "bf16" if mixed else "f32",
+                                     "mfma": "bf16" if (mixed and H == 128) else "f32",
                                      "bytes": 4.0 * rows * (2 * N + 2 * K)}
         dY = torch.randn((rows, K), generator=g).to(dev) * 1e-3
         sec = timeit(lambda: ops.lstm_rec_bwd(Pk, Cs, whh, dY, T, Bp, H, D, dp_bf16=mixed), n=3)
         out["lstm_rec_bwd"] = {"sec": sec, "flop": 2.0 * rows * N * H, "per_step": L,
-                               "mfma": "bf16" if mixed else "f32",
+                               "mfma": "bf16" if (mixed and H == 128) else "f32",
                                "bytes": 4.0 * rows * (N + 2 * K) + (2.0 if mixed else 4.0) * rows * N}
         dP, _ = ops.lstm_rec_bwd(Pk, Cs, whh, dY, T, Bp, H, D, dp_bf16=mixed)
         dw = torch.zeros((N, K), device=dev)
@@ -130,7 +130,7 @@ def kernel_roofline(dev, B, mode, precision):
     else:
         sec = timeit(lambda: ops.lstm_rec_fwd(P, whh, T, Bp, H, D, False, mixed=mixed), n=3)
         out["lstm_rec_fwd"] = {"sec": sec, "flop": 2.0 * rows * N * H, "per_step": L,
-                               "mfma": "bf16" if mixed else "f32",
+                               "mfma": "bf16" if (mixed and H == 128) else "f32",
                                "bytes": 4.0 * rows * (N + K)}
     return out
 

@@ -117,8 +117,12 @@ int lob_colsum_bf16(const void* A, int lda, int M, int N, float* out, void* stre
  * and 16-byte aligned bases are required (LOB_E_ALIGN otherwise: use the fp32 entry point).
  * ---------------------------------------------------------------------------------- */
 int lob_gemm_nt_bf16(const void* A, int a_bf16, int lda, const float* W, int ldw, const float* bias,
-                     float* C, int ldc, int M, int N, int K, int act, void* stream);
-int lob_gate_gemm_x_bf16(const float* X, int ldx, const float* Wih, const float* bias,
+                     float* C, int ldc, int M, int N, int K, int act, float drop_p, uint64_t seed,
+                     void* stream);
+/*   drop_p > 0: the result is multiplied by the nn.Dropout mask of element (row*ldc + col) (same
+ *   counter-based hash as lob_dropout_f32): fuses the backward of nn.LSTM's inter-layer dropout
+ *   (04_lstm_model.py:186) into dX = dP W_ih.                                                */
+int lob_gate_gemm_x_bf16(const void* X, int x_bf16, int ldx, const float* Wih, const float* bias,
                          float* P, int T, int Bp, int H, int D, int K, void* stream);
 int lob_gemm_tn_bf16(const void* A, int a_bf16, int lda, const void* B, int b_bf16, int ldb,
                      float* C, int ldc, int M, int N, int Kc, void* stream);
@@ -127,7 +131,10 @@ int lob_gemm_tn_bf16(const void* A, int a_bf16, int lda, const void* B, int b_bf
  * stored and carried through time stays fp32).  Same arguments as lob_lstm_rec_fwd_f32 /
  * lob_lstm_rec_bwd_f32; dP is always bf16 here.                                            */
 int lob_lstm_rec_fwd_bf16(float* P, const float* Whh, float* Y, float* Csave,
+                          void* Yd, float drop_p, uint64_t seed,
                           int T, int Bp, int H, int D, int save, void* stream);
+/*   Yd != NULL: additionally writes Yd = bf16(dropout(Y; drop_p, seed)), element index = position in
+ *   Y -- nn.LSTM's inter-layer dropout fused into the producer; the next layer's bf16 GEMMs read it. */
 int lob_lstm_rec_bwd_bf16(const float* G, const float* Csave, const float* Whh, const float* dY,
                           void* dP, float* dbias, int T, int Bp, int H, int D, void* stream);
 

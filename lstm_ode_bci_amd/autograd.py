@@ -66,12 +66,17 @@ def _forward_impl(x, ps, cfg, save):
         whh = torch.stack([d[1] for d in dirs], 0)
         bias = torch.cat([d[2] + d[3] for d in dirs], 0)
         P = ops.gate_gemm_x(inp, wih, bias, T, Bp, H, D, frag, mixed=mixed)
-        Y, Cs = ops.lstm_rec_fwd(P, whh, T, Bp, H, D, save, mixed=mixed)
+        drop_here = layer + 1 < L and p_lstm > 0
+        fuse = drop_here and ops.can_fuse_dropout(H, mixed)
+        Y, Cs, Yd = ops.lstm_rec_fwd(P, whh, T, Bp, H, D, save, mixed=mixed,
+                                     drop_p=p_lstm if fuse else 0.0, seed=_seed(seed, 10 + layer))
         nxt = Y
-        if layer + 1 < L and p_lstm > 0:
+        if fuse:
+            nxt = Yd                                  # bf16, dropped: read by the next layer's bf16 GEMMs
+        elif drop_here:
             nxt = ops.dropout(Y, p_lstm, _seed(seed, 10 + layer))
         if save:
-            sv["layers"].append({"inp": inp, "G": P, "C": Cs, "Y": Y, "wih": wih, "whh": whh})
+            sv["layers"].append({"inp": inp, "G": P, "C": Cs, "Y": Y, "wih": wih, "whh": whh, "fused_drop": fuse})
         inp = nxt
     ln_g, ln_b = next(it), next(it)
     a0w, a0b, a2w, a2b = next(it), next(it), next(it), next(it)

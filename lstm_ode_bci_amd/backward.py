@@ -63,7 +63,7 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad):
     # ---- LSTM stack, last layer first (04:211)
     for layer in reversed(range(L)):
         lay = sv["layers"][layer]
-        if layer + 1 < L and p_lstm > 0:
+        if layer + 1 < L and p_lstm > 0 and not lay["fused_drop"]:
             dY = ops.dropout(dY, p_lstm, _seed(seed, 10 + layer))
         dP, dbias = ops.lstm_rec_bwd(lay["G"], lay["C"], lay["whh"], dY, T, Bp, H, D, dp_bf16=mixed)
         inp, Y, wih = lay["inp"], lay["Y"], lay["wih"]
@@ -83,7 +83,11 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad):
             g[base + 4 * d + 1] = dwhh
             g[base + 4 * d + 2] = dbias[d * 4 * H:(d + 1) * 4 * H]
             g[base + 4 * d + 3] = dbias[d * 4 * H:(d + 1) * 4 * H]
-        dY = ops.gemm_nt(dP, _t(wih), mixed=mixed)
+        # dX of this layer = dY of the layer below; when that layer's output dropout was fused into its
+        # producer, its backward (the same mask) is fused into this GEMM's epilogue
+        below_fused = layer > 0 and sv["layers"][layer - 1]["fused_drop"]
+        dY = ops.gemm_nt(dP, _t(wih), mixed=mixed, drop_p=p_lstm if below_fused else 0.0,
+                         seed=_seed(seed, 10 + layer - 1))
         del dP
 
     # ---- input projection: Linear -> LayerNorm -> GELU -> Dropout (04:173-178)

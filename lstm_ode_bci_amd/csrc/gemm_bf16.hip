@@ -30,6 +30,7 @@ struct NTArgs {
     const void* A; const float* W; const float* bias; float* C;
     int lda, ldw, ldc, M, N, K, act, accumulate, dbg;
     int T, Bp, H, D;     // fragment epilogue
+    float drop_p; uint64_t seed;   // row-major epilogue: C *= dropout mask of element (row*ldc + col)
 };
 
 // ---- staging: [128 rows][TKT k] tile, source rows are K-contiguous -------------------------
@@ -180,7 +181,8 @@ __global__ __launch_bounds__(256, TKT == 32 ? 3 : 2) void gemm_nt_bf16_kernel(NT
                             const int row = cm0 + 64 * wr + 32 * i + acc_row(r, lane);
                             if (row < g.M) {
                                 float* dst = g.C + (size_t)row * g.ldc + col;
-                                const float val = apply_act(acc[i][j][r] + bv, g.act);
+                                float val = apply_act(acc[i][j][r] + bv, g.act);
+                                if (g.drop_p > 0.f) val *= lob_dropout_scale(g.seed, (uint64_t)row * g.ldc + col, g.drop_p);
                                 *dst = g.accumulate ? *dst + val : val;
                             }
                         }
@@ -399,12 +401,14 @@ inline int nt_tk() {
 
 // A: fp32 (a_bf16 = 0) or bf16 (a_bf16 = 1) row-major [M][lda]; W fp32 [N][ldw]; C fp32.
 extern "C" int lob_gemm_nt_bf16(const void* A, int a_bf16, int lda, const float* W, int ldw, const float* bias,
-                                float* C, int ldc, int M, int N, int K, int act, void* stream) {
+                                float* C, int ldc, int M, int N, int K, int act, float drop_p, uint64_t seed,
+                                void* stream) {
     if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return LOB_E_ARG;
     if (lda < K || ldw < K || ldc < N) return LOB_E_SHAPE;
     if ((act & 0xff) > LOB_ACT_GELU || act < 0) return LOB_E_ARG;
     if (!al16(A) || !al16(W) || (K % 8) || (lda % 8) || (ldw % 4)) return LOB_E_ALIGN;
-    NTArgs g{A, W, bias, C, lda, ldw, ldc, M, N, K, act & 0xff, (act >> 8) & 1, dbg_flags(), 0, 0, 0, 0};
+    NTArgs g{A, W, bias, C, lda, ldw, ldc, M, N, K, act & 0xff, (act >> 8) & 1, dbg_flags(), 0, 0, 0, 0, drop_p, seed};
+    if (drop_p < 0.f || drop_p >= 1.f) return LOB_E_ARG;
     const dim3 grid((unsigned)nt_grid(M, N)), block(256);
     const bool tk32 = nt_tk() == 32;
     if (a_bf16) {
@@ -418,16 +422,21 @@ extern "C" int lob_gemm_nt_bf16(const void* A, int a_bf16, int lda, const float*
     return 0;
 }
 
-extern "C" int lob_gate_gemm_x_bf16(const float* X, int ldx, const float* Wih, const float* bias,
+extern "C" int lob_gate_gemm_x_bf16(const void* X, int x_bf16, int ldx, const float* Wih, const float* bias,
                                     float* P, int T, int Bp, int H, int D, int K, void* stream) {
     if (!X || !Wih || !P || T <= 0 || Bp <= 0 || H <= 0 || K <= 0 || (D != 1 && D != 2)) return LOB_E_ARG;
     if (ldx < K || (H % 32) || (Bp % 32)) return LOB_E_SHAPE;
     if (!al16(X) || !al16(Wih) || !al16(P) || (K % 8) || (ldx % 8)) return LOB_E_ALIGN;
     const int N = D * 4 * H, M = T * Bp;
-    NTArgs g{X, Wih, bias, P, ldx, K, N, M, N, K, LOB_ACT_NONE, 0, dbg_flags(), T, Bp, H, D};
+    NTArgs g{X, Wih, bias, P, ldx, K, N, M, N, K, LOB_ACT_NONE, 0, dbg_flags(), T, Bp, H, D, 0.f, 0};
     const dim3 grid((unsigned)nt_grid(M, N)), block(256);
-    if (nt_tk() == 32) hipLaunchKernelGGL((gemm_nt_bf16_kernel<false, 1, 32>), grid, block, 0, (hipStream_t)stream, g);
-    else               hipLaunchKernelGGL((gemm_nt_bf16_kernel<false, 1, 64>), grid, block, 0, (hipStream_t)stream, g);
+    if (x_bf16) {
+        if (nt_tk() == 32) hipLaunchKernelGGL((gemm_nt_bf16_kernel<true, 1, 32>), grid, block, 0, (hipStream_t)stream, g);
+        else               hipLaunchKernelGGL((gemm_nt_bf16_kernel<true, 1, 64>), grid, block, 0, (hipStream_t)stream, g);
+    } else {
+        if (nt_tk() == 32) hipLaunchKernelGGL((gemm_nt_bf16_kernel<false, 1, 32>), grid, block, 0, (hipStream_t)stream, g);
+        else               hipLaunchKernelGGL((gemm_nt_bf16_kernel<false, 1, 64>), grid, block, 0, (hipStream_t)stream, g);
+    }
     LOB_CHECK_LAUNCH();
     return 0;
 }

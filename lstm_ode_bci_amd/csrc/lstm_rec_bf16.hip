@@ -38,10 +38,10 @@ __device__ __forceinline__ void load_frag4(const float* p, unsigned off, f32x16 
         }
 }
 
-template <bool SAVE>
+template <bool SAVE, bool DROP>
 __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_h128_bf16_kernel(
     float* __restrict__ P, const float* __restrict__ Whh, float* __restrict__ Y,
-    float* __restrict__ Csave, int T, int Bp) {
+    float* __restrict__ Csave, __bf16* __restrict__ Yd, float drop_p, uint64_t seed, int T, int Bp) {
     __shared__ __attribute__((aligned(16))) __bf16 hs[2 * 32 * HB_LD];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_h128_bf16_kernel(
             for (int g = 0; g < 4; ++g) acc[g] = mfma_bf16(a, wr[g][ks], acc[g]);
         }
         __bf16* hnext = hs + (cur ^ 1) * 32 * HB_LD + 32 * w + l31 + 4 * hi * HB_LD;
-        float* yrow = Y + ((size_t)t * Bp + bt * 32) * (D * H) + d * H + 32 * w;
+        const size_t ybase = ((size_t)t * Bp + bt * 32) * (D * H) + d * H + 32 * w;
+        float* yrow = Y + ybase;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float ig = fast_sigmoid(acc[0][r]);
@@ -99,6 +100,10 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_h128_bf16_kernel(
             const int row = (r & 3) + 8 * (r >> 2);
             hnext[row * HB_LD] = (__bf16)h;
             (yrow + (size_t)row * (D * H))[y_off] = h;
+            if (DROP) {   // nn.LSTM's inter-layer dropout, fused: the next layer's GEMMs read this bf16 copy
+                const uint64_t idx = ybase + (uint64_t)row * (D * H) + y_off;
+                (Yd + ybase + (size_t)row * (D * H))[y_off] = (__bf16)(h * lob_dropout_scale(seed, idx, drop_p));
+            }
             if (SAVE) { acc[0][r] = ig; acc[1][r] = fg; acc[2][r] = gg; acc[3][r] = og; }
         }
         if (SAVE) {
@@ -238,16 +243,21 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_h128_bf16_kernel(
 }  // namespace
 
 extern "C" int lob_lstm_rec_fwd_bf16(float* P, const float* Whh, float* Y, float* Csave,
+                                     void* Yd, float drop_p, uint64_t seed,
                                      int T, int Bp, int Hh, int D, int save, void* stream) {
     if (!P || !Whh || !Y || T <= 0 || Bp <= 0 || (D != 1 && D != 2)) return LOB_E_ARG;
     if (save && !Csave) return LOB_E_ARG;
+    if (Yd && (drop_p <= 0.f || drop_p >= 1.f)) return LOB_E_ARG;
     if (Hh != 128 || (Bp % 32)) return LOB_E_SHAPE;
     if ((reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(Whh) |
          reinterpret_cast<uintptr_t>(Csave)) & 15) return LOB_E_ALIGN;
     const dim3 grid(Bp / 32, D), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (save) hipLaunchKernelGGL((lstm_rec_fwd_h128_bf16_kernel<true>), grid, block, 0, s, P, Whh, Y, Csave, T, Bp);
-    else      hipLaunchKernelGGL((lstm_rec_fwd_h128_bf16_kernel<false>), grid, block, 0, s, P, Whh, Y, Csave, T, Bp);
+    __bf16* yd = reinterpret_cast<__bf16*>(Yd);
+    if (save && yd)  hipLaunchKernelGGL((lstm_rec_fwd_h128_bf16_kernel<true, true>), grid, block, 0, s, P, Whh, Y, Csave, yd, drop_p, seed, T, Bp);
+    else if (save)   hipLaunchKernelGGL((lstm_rec_fwd_h128_bf16_kernel<true, false>), grid, block, 0, s, P, Whh, Y, Csave, yd, drop_p, seed, T, Bp);
+    else if (yd)     hipLaunchKernelGGL((lstm_rec_fwd_h128_bf16_kernel<false, true>), grid, block, 0, s, P, Whh, Y, Csave, yd, drop_p, seed, T, Bp);
+    else             hipLaunchKernelGGL((lstm_rec_fwd_h128_bf16_kernel<false, false>), grid, block, 0, s, P, Whh, Y, Csave, yd, drop_p, seed, T, Bp);
     LOB_CHECK_LAUNCH();
     return 0;
 }

@@ -43,7 +43,7 @@ def _bf16_ok(a, K, lda):
     return K % 8 == 0 and lda % 8 == 0 and a.data_ptr() % 16 == 0
 
 
-def gemm_nt(a, w, bias=None, act=ACT_NONE, out=None, accumulate=False, mixed=False):
+def gemm_nt(a, w, bias=None, act=ACT_NONE, out=None, accumulate=False, mixed=False, drop_p=0.0, seed=0):
     """out[M,N] (+)= act(a[M,K] @ w[N,K]^T + bias).  mixed=True (or a bf16 `a`): bf16 MFMA inputs,
     fp32 accumulate/output; falls back to the exact-fp32 kernel for shapes the bf16 kernel refuses."""
     a_bf16 = a.dtype == torch.bfloat16
@@ -58,9 +58,11 @@ def gemm_nt(a, w, bias=None, act=ACT_NONE, out=None, accumulate=False, mixed=Fal
         act = act | 0x100
     if (mixed or a_bf16) and _bf16_ok(a, K, K) and w.data_ptr() % 16 == 0:
         rc = _lib.lib().lob_gemm_nt_bf16(_ptr(a), 1 if a_bf16 else 0, K, _ptr(w), K, _ptr(bias), _ptr(out), N,
-                                         M, N, K, act, _stream())
+                                         M, N, K, act, float(drop_p), C.c_uint64(seed), _stream())
         _lib.check(rc, "lob_gemm_nt_bf16")
         return out
+    if drop_p > 0:
+        raise _lib.LobError("gemm_nt: the fused dropout epilogue exists on the bf16 kernel only")
     if a_bf16:
         raise _lib.LobError("gemm_nt: bf16 operand with a shape the bf16 kernel does not support")
     rc = _lib.lib().lob_gemm_nt_f32(_ptr(a), K, _ptr(w), K, _ptr(bias), _ptr(out), N, M, N, K, act, _stream())
@@ -94,33 +96,51 @@ def gemm_tn(a, b, out, mixed=False):
 
 def gate_gemm_x(x, wih, bias, T, Bp, H, D, frag, mixed=False):
     """P = x[T*Bp,K] @ wih[D*4H,K]^T + bias, fragment order when frag."""
-    _chk(x, "x"); _chk(wih, "wih"); _chk(bias, "bias")
+    x16 = x.dtype == torch.bfloat16
+    _chk(x, "x", x.dtype if x16 else torch.float32); _chk(wih, "wih"); _chk(bias, "bias")
     K = x.shape[1]
     assert x.shape[0] == T * Bp and wih.shape == (D * 4 * H, K)
-    if mixed and not frag:
+    if (mixed or x16) and not frag:
         return gemm_nt(x, wih, bias, mixed=True)
     P = torch.empty((T * Bp, D * 4 * H), device=x.device, dtype=torch.float32)
-    if mixed and _bf16_ok(x, K, K):
-        rc = _lib.lib().lob_gate_gemm_x_bf16(_ptr(x), K, _ptr(wih), _ptr(bias), _ptr(P), T, Bp, H, D, K, _stream())
+    if (mixed or x16) and _bf16_ok(x, K, K):
+        rc = _lib.lib().lob_gate_gemm_x_bf16(_ptr(x), int(x16), K, _ptr(wih), _ptr(bias), _ptr(P), T, Bp, H, D, K,
+                                             _stream())
         _lib.check(rc, "lob_gate_gemm_x_bf16")
         return P
+    if x16:
+        raise _lib.LobError("gate_gemm_x: bf16 input with a shape the bf16 kernel does not support")
     rc = _lib.lib().lob_gate_gemm_x_f32(_ptr(x), K, _ptr(wih), _ptr(bias), _ptr(P), T, Bp, H, D, K,
                                         1 if frag else 0, _stream())
     _lib.check(rc, "lob_gate_gemm_x_f32")
     return P
 
 
-def lstm_rec_fwd(P, whh, T, Bp, H, D, save, mixed=False):
-    """Runs the persistent recurrent kernel; returns (Y[T*Bp, D*H], Csave or None).
-    mixed: h W_hh^T on bf16 MFMA (H == 128), everything else fp32."""
+def can_fuse_dropout(H, mixed):
+    """The bf16-MFMA recurrent kernel (mixed mode, H == 128) can emit the dropped bf16 copy itself."""
+    return bool(mixed) and H == 128
+
+
+def lstm_rec_fwd(P, whh, T, Bp, H, D, save, mixed=False, drop_p=0.0, seed=0):
+    """Runs the persistent recurrent kernel; returns (Y[T*Bp, D*H], Csave or None, Yd or None).
+    mixed: h W_hh^T on bf16 MFMA (H == 128), everything else fp32.  drop_p > 0 (only with
+    can_fuse_dropout): also returns Yd = bf16(dropout(Y))."""
     _chk(P, "P"); _chk(whh, "whh")
     assert whh.shape == (D, 4 * H, H)
     Y = torch.empty((T * Bp, D * H), device=P.device, dtype=torch.float32)
     Cs = torch.empty((D * T * Bp * H,), device=P.device, dtype=torch.float32) if save else None
-    fn = _lib.lib().lob_lstm_rec_fwd_bf16 if (mixed and H == 128) else _lib.lib().lob_lstm_rec_fwd_f32
-    rc = fn(_ptr(P), _ptr(whh), _ptr(Y), _ptr(Cs), T, Bp, H, D, 1 if save else 0, _stream())
+    Yd = None
+    if mixed and H == 128:
+        if drop_p > 0:
+            Yd = torch.empty((T * Bp, D * H), device=P.device, dtype=torch.bfloat16)
+        rc = _lib.lib().lob_lstm_rec_fwd_bf16(_ptr(P), _ptr(whh), _ptr(Y), _ptr(Cs), _ptr(Yd), float(drop_p),
+                                              C.c_uint64(seed), T, Bp, H, D, 1 if save else 0, _stream())
+    else:
+        assert drop_p == 0
+        rc = _lib.lib().lob_lstm_rec_fwd_f32(_ptr(P), _ptr(whh), _ptr(Y), _ptr(Cs), T, Bp, H, D, 1 if save else 0,
+                                             _stream())
     _lib.check(rc, "lob_lstm_rec_fwd")
-    return Y, Cs
+    return Y, Cs, Yd
 
 
 def layernorm_act(x, gamma, beta, act=ACT_NONE, eps=1e-5, remap=None, drop_p=0.0, seed=0, out=None):

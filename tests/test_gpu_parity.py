@@ -108,7 +108,7 @@ def test_lstm_layer_vs_oracle(dev, H, D, B):
     bias = torch.from_numpy(np.concatenate([w[2] + w[3] for w in ws], 0)).to(dev)
     for save in (False, True):
         P = ops.gate_gemm_x(torch.from_numpy(xt.reshape(T * Bp, K)).to(dev), wih, bias, T, Bp, H, D, ops.uses_frag(H))
-        Y, Cs = ops.lstm_rec_fwd(P, whh, T, Bp, H, D, save)
+        Y, Cs, _ = ops.lstm_rec_fwd(P, whh, T, Bp, H, D, save)
         y = Y.cpu().numpy().reshape(T, Bp, D * H)[:, :B].transpose(1, 0, 2)
         ref = np.concatenate([R.lstm_direction(x.astype(np.float64), *[w.astype(np.float64) for w in ws[d]], d == 1)
                               for d in range(D)], -1)
@@ -555,3 +555,30 @@ def test_streaming_kernels_forward_backward_vs_oracle(dev, H, L, bi):
     for k, p in m.named_parameters():
         if np.abs(rgp[k]).max() > 1e-7:
             assert np.abs(p.grad.cpu().numpy() - rgp[k]).max() / np.abs(rgp[k]).max() < 2e-2, k
+
+
+def test_fused_dropout_equals_separate_kernels(dev, monkeypatch):
+    """Mixed mode fuses nn.LSTM's inter-layer dropout into the recurrent kernel (bf16 copy) and its
+    backward into the dX GEMM epilogue; the masks are the same counter-based hash, so the result must
+    equal the un-fused pipeline (dropout kernel -> GEMM) to rounding."""
+    from lstm_ode_bci_amd import ops
+    sd = syn.make_state_dict(61, 128, 3, 2, True)
+    x, y = syn.make_windows(40, 64, 61, seed=12)
+    m = _model(sd, 61, 128, 3, True, dev).train()
+
+    def run():
+        torch.manual_seed(5)
+        m.zero_grad(set_to_none=True)
+        xg = torch.from_numpy(x).to(dev).requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = torch.nn.functional.cross_entropy(m(xg).float(), torch.from_numpy(y).to(dev))
+        loss.backward()
+        return float(loss), {k: p.grad.clone() for k, p in m.named_parameters()}, xg.grad.clone()
+
+    lf, gf, xf = run()
+    monkeypatch.setattr(ops, "can_fuse_dropout", lambda H, mixed: False)
+    lu, gu, xu = run()
+    assert abs(lf - lu) < 1e-6
+    assert (xf - xu).abs().max().item() <= 1e-6 * max(1.0, xu.abs().max().item())
+    for k in gf:
+        assert (gf[k] - gu[k]).abs().max().item() <= 2e-5 * max(1e-6, gu[k].abs().max().item()) + 1e-9, k
