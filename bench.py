@@ -91,12 +91,15 @@ def kernel_roofline(dev, B, mode, precision):
 
     rows, N = T * Bp, D * 4 * H
     K = D * H
+    bf16_rec = mixed and H == 128                       # bf16-MFMA recurrent kernels exist at H = 128
+    pe = 2.0 if (bf16_rec and ops.PG_BF16) else 4.0     # bytes per stored pre-activation / saved gate
+    de = 2.0 if mixed else 4.0                          # bytes per dP element
     x = torch.randn((rows, K), generator=g).to(dev)
     wih = (torch.rand((N, K), generator=g) * 0.17 - 0.085).to(dev)
     bias = torch.zeros(N, device=dev)
     whh = (torch.rand((D, 4 * H, H), generator=g) * 0.17 - 0.085).to(dev)
     sec = timeit(lambda: ops.gate_gemm_x(x, wih, bias, T, Bp, H, D, True, mixed=mixed))
-    out["gate_gemm_x(K=256)"] = {"sec": sec, "flop": 2.0 * rows * N * K, "bytes": 4.0 * rows * (K + N) + 4.0 * N * K,
+    out["gate_gemm_x(K=256)"] = {"sec": sec, "flop": 2.0 * rows * N * K, "bytes": rows * (4.0 * K + pe * N) + 4.0 * N * K,
                                  "per_step": L - 1, "mfma": "bf16" if mixed else "f32"}
     P = ops.gate_gemm_x(x, wih, bias, T, Bp, H, D, True, mixed=mixed)
     if train:
@@ -109,29 +112,29 @@ def kernel_roofline(dev, B, mode, precision):
         sec = timeit(rec_fwd, n=3) - t_copy
         Y, Cs, _ = rec_fwd()
         out["lstm_rec_fwd(save)"] = {"sec": sec, "flop": 2.0 * rows * N * H, "per_step": L,
-                                     "mfma": "bf16" if (mixed and H == 128) else "f32",
-                                     "bytes": 4.0 * rows * (2 * N + 2 * K)}
+                                     "mfma": "bf16" if bf16_rec else "f32",
+                                     "bytes": rows * (2 * pe * N + 8.0 * K)}   # P in, gates out, c out, Y out
         dY = torch.randn((rows, K), generator=g).to(dev) * 1e-3
         sec = timeit(lambda: ops.lstm_rec_bwd(Pk, Cs, whh, dY, T, Bp, H, D, dp_bf16=mixed), n=3)
         out["lstm_rec_bwd"] = {"sec": sec, "flop": 2.0 * rows * N * H, "per_step": L,
-                               "mfma": "bf16" if (mixed and H == 128) else "f32",
-                               "bytes": 4.0 * rows * (N + 2 * K) + (2.0 if mixed else 4.0) * rows * N}
+                               "mfma": "bf16" if bf16_rec else "f32",
+                               "bytes": rows * (pe * N + 8.0 * K + de * N)}   # gates in, c in, dY in, dP out
         dP, _ = ops.lstm_rec_bwd(Pk, Cs, whh, dY, T, Bp, H, D, dp_bf16=mixed)
         dw = torch.zeros((N, K), device=dev)
         sec = timeit(lambda: ops.gemm_tn(dP, x, dw, mixed=mixed))
         out["gemm_tn(dW_ih)"] = {"sec": sec, "flop": 2.0 * rows * N * K, "per_step": L - 1,
                                  "mfma": "bf16" if mixed else "f32",
-                                 "bytes": (2.0 if mixed else 4.0) * rows * N + 4.0 * rows * K}
+                                 "bytes": de * rows * N + 4.0 * rows * K}
         wt = wih.t().contiguous()
         sec = timeit(lambda: ops.gemm_nt(dP, wt, mixed=mixed))
         out["gemm_nt(dX)"] = {"sec": sec, "flop": 2.0 * rows * N * K, "per_step": L - 1,
                               "mfma": "bf16" if mixed else "f32",
-                              "bytes": (2.0 if mixed else 4.0) * rows * N + 4.0 * rows * K}
+                              "bytes": de * rows * N + 4.0 * rows * K}
     else:
         sec = timeit(lambda: ops.lstm_rec_fwd(P, whh, T, Bp, H, D, False, mixed=mixed), n=3)
         out["lstm_rec_fwd"] = {"sec": sec, "flop": 2.0 * rows * N * H, "per_step": L,
-                               "mfma": "bf16" if (mixed and H == 128) else "f32",
-                               "bytes": 4.0 * rows * (N + K)}
+                               "mfma": "bf16" if bf16_rec else "f32",
+                               "bytes": rows * (pe * N + 4.0 * K)}
     return out
 
 

@@ -123,19 +123,22 @@ int lob_gemm_nt_bf16(const void* A, int a_bf16, int lda, const float* W, int ldw
  *   counter-based hash as lob_dropout_f32): fuses the backward of nn.LSTM's inter-layer dropout
  *   (04_lstm_model.py:186) into dX = dP W_ih.                                                */
 int lob_gate_gemm_x_bf16(const void* X, int x_bf16, int ldx, const float* Wih, const float* bias,
-                         float* P, int T, int Bp, int H, int D, int K, void* stream);
+                         void* P, int p_bf16, int T, int Bp, int H, int D, int K, void* stream);
+/*   p_bf16 = 1: the fragment-order pre-activations are STORED as bf16 (same element order, half the
+ *   bytes); the bf16 recurrent kernels take the matching pg_bf16 flag and also keep the activated gates
+ *   they save for BPTT in bf16.  Accumulation, cell state and everything else stay fp32.          */
 int lob_gemm_tn_bf16(const void* A, int a_bf16, int lda, const void* B, int b_bf16, int ldb,
                      float* C, int ldc, int M, int N, int Kc, void* stream);
 
 /* Recurrent kernels with the hidden-state gate GEMM on bf16 MFMA (H == 128 only; everything
  * stored and carried through time stays fp32).  Same arguments as lob_lstm_rec_fwd_f32 /
  * lob_lstm_rec_bwd_f32; dP is always bf16 here.                                            */
-int lob_lstm_rec_fwd_bf16(float* P, const float* Whh, float* Y, float* Csave,
+int lob_lstm_rec_fwd_bf16(void* P, int pg_bf16, const float* Whh, float* Y, float* Csave,
                           void* Yd, float drop_p, uint64_t seed,
                           int T, int Bp, int H, int D, int save, void* stream);
 /*   Yd != NULL: additionally writes Yd = bf16(dropout(Y; drop_p, seed)), element index = position in
  *   Y -- nn.LSTM's inter-layer dropout fused into the producer; the next layer's bf16 GEMMs read it. */
-int lob_lstm_rec_bwd_bf16(const float* G, const float* Csave, const float* Whh, const float* dY,
+int lob_lstm_rec_bwd_bf16(const void* G, int pg_bf16, const float* Csave, const float* Whh, const float* dY,
                           void* dP, float* dbias, int T, int Bp, int H, int D, void* stream);
 
 /* Element-wise activation and its backward (dx = dy * act'(pre)); classifier GELUs

@@ -30,6 +30,7 @@ struct NTArgs {
     const void* A; const float* W; const float* bias; float* C;
     int lda, ldw, ldc, M, N, K, act, accumulate, dbg;
     int T, Bp, H, D;     // fragment epilogue
+    int out_bf16;                  // fragment epilogue: P stored as bf16
     float drop_p; uint64_t seed;   // row-major epilogue: C *= dropout mask of element (row*ldc + col)
 };
 
@@ -200,12 +201,23 @@ __global__ __launch_bounds__(256, TKT == 32 ? 3 : 2) void gemm_nt_bf16_kernel(NT
                         if (ncol >= g.N) continue;
                         const int d = ncol / H4, gg = (ncol % H4) / g.H, w = (ncol % g.H) >> 5;
                         const float bv = g.bias ? g.bias[ncol + (lane & 31)] : 0.f;
-                        float* dst = g.C + ((((size_t)(d * g.T + t) * NBT + bt) * NW + w) * 4 + gg) * 1024 + lane * 4;
+                        const size_t fo = ((((size_t)(d * g.T + t) * NBT + bt) * NW + w) * 4 + gg) * 1024 + lane * 4;
+                        if (g.out_bf16) {
+                            __bf16* dst = reinterpret_cast<__bf16*>(g.C) + fo;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            f32x4 v = {acc[i][j][4 * q + 0] + bv, acc[i][j][4 * q + 1] + bv,
-                                       acc[i][j][4 * q + 2] + bv, acc[i][j][4 * q + 3] + bv};
-                            *reinterpret_cast<f32x4*>(dst + q * 256) = v;
+                            for (int q = 0; q < 4; ++q) {
+                                bf16x4 v = {(__bf16)(acc[i][j][4 * q + 0] + bv), (__bf16)(acc[i][j][4 * q + 1] + bv),
+                                            (__bf16)(acc[i][j][4 * q + 2] + bv), (__bf16)(acc[i][j][4 * q + 3] + bv)};
+                                *reinterpret_cast<bf16x4*>(dst + q * 256) = v;
+                            }
+                        } else {
+                            float* dst = g.C + fo;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                f32x4 v = {acc[i][j][4 * q + 0] + bv, acc[i][j][4 * q + 1] + bv,
+                                           acc[i][j][4 * q + 2] + bv, acc[i][j][4 * q + 3] + bv};
+                                *reinterpret_cast<f32x4*>(dst + q * 256) = v;
+                            }
                         }
                     }
                 }
@@ -407,7 +419,7 @@ extern "C" int lob_gemm_nt_bf16(const void* A, int a_bf16, int lda, const float*
     if (lda < K || ldw < K || ldc < N) return LOB_E_SHAPE;
     if ((act & 0xff) > LOB_ACT_GELU || act < 0) return LOB_E_ARG;
     if (!al16(A) || !al16(W) || (K % 8) || (lda % 8) || (ldw % 4)) return LOB_E_ALIGN;
-    NTArgs g{A, W, bias, C, lda, ldw, ldc, M, N, K, act & 0xff, (act >> 8) & 1, dbg_flags(), 0, 0, 0, 0, drop_p, seed};
+    NTArgs g{A, W, bias, C, lda, ldw, ldc, M, N, K, act & 0xff, (act >> 8) & 1, dbg_flags(), 0, 0, 0, 0, 0, drop_p, seed};
     if (drop_p < 0.f || drop_p >= 1.f) return LOB_E_ARG;
     const dim3 grid((unsigned)nt_grid(M, N)), block(256);
     const bool tk32 = nt_tk() == 32;
@@ -423,12 +435,12 @@ extern "C" int lob_gemm_nt_bf16(const void* A, int a_bf16, int lda, const float*
 }
 
 extern "C" int lob_gate_gemm_x_bf16(const void* X, int x_bf16, int ldx, const float* Wih, const float* bias,
-                                    float* P, int T, int Bp, int H, int D, int K, void* stream) {
+                                    void* P, int p_bf16, int T, int Bp, int H, int D, int K, void* stream) {
     if (!X || !Wih || !P || T <= 0 || Bp <= 0 || H <= 0 || K <= 0 || (D != 1 && D != 2)) return LOB_E_ARG;
     if (ldx < K || (H % 32) || (Bp % 32)) return LOB_E_SHAPE;
     if (!al16(X) || !al16(Wih) || !al16(P) || (K % 8) || (ldx % 8)) return LOB_E_ALIGN;
     const int N = D * 4 * H, M = T * Bp;
-    NTArgs g{X, Wih, bias, P, ldx, K, N, M, N, K, LOB_ACT_NONE, 0, dbg_flags(), T, Bp, H, D, 0.f, 0};
+    NTArgs g{X, Wih, bias, reinterpret_cast<float*>(P), ldx, K, N, M, N, K, LOB_ACT_NONE, 0, dbg_flags(), T, Bp, H, D, p_bf16, 0.f, 0};
     const dim3 grid((unsigned)nt_grid(M, N)), block(256);
     if (x_bf16) {
         if (nt_tk() == 32) hipLaunchKernelGGL((gemm_nt_bf16_kernel<true, 1, 32>), grid, block, 0, (hipStream_t)stream, g);

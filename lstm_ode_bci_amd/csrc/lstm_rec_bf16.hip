@@ -28,19 +28,70 @@ __device__ __forceinline__ bf16x8 cvt8(const float* p) {
     return r;
 }
 
-__device__ __forceinline__ void load_frag4(const float* p, unsigned off, f32x16 (&dst)[4]) {
+// Fragment blocks ([gate][q][lane][4] elements) hold fp32 or -- with bf16 P/G storage -- bf16: the same
+// element order, half the bytes (8-B accesses per lane, 512 B contiguous per wave-instruction).
+template <typename E>
+__device__ __forceinline__ void load_frag4(const E* p, unsigned off, f32x16 (&dst)[4]) {
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>((p + g * 1024 + q * 256) + off);
-            dst[g][4 * q] = v[0]; dst[g][4 * q + 1] = v[1]; dst[g][4 * q + 2] = v[2]; dst[g][4 * q + 3] = v[3];
+            if constexpr (sizeof(E) == 4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>((p + g * 1024 + q * 256) + off);
+                dst[g][4 * q] = v[0]; dst[g][4 * q + 1] = v[1]; dst[g][4 * q + 2] = v[2]; dst[g][4 * q + 3] = v[3];
+            } else {
+                const bf16x4 v = *reinterpret_cast<const bf16x4*>((p + g * 1024 + q * 256) + off);
+                dst[g][4 * q] = (float)v[0]; dst[g][4 * q + 1] = (float)v[1];
+                dst[g][4 * q + 2] = (float)v[2]; dst[g][4 * q + 3] = (float)v[3];
+            }
+        }
+}
+// Raw (unconverted) fragment block: prefetched two steps ahead and only converted to fp32 when it is
+// consumed -- a conversion at load time would force the wait for the data right at the prefetch.
+template <typename E> struct RawFrag;
+template <> struct RawFrag<float> { f32x4 v[16]; };
+template <> struct RawFrag<__bf16> { bf16x4 v[16]; };
+
+template <typename E>
+__device__ __forceinline__ void load_raw(const E* p, unsigned off, RawFrag<E>& r) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if constexpr (sizeof(E) == 4) r.v[4 * g + q] = *reinterpret_cast<const f32x4*>((p + g * 1024 + q * 256) + off);
+            else                          r.v[4 * g + q] = *reinterpret_cast<const bf16x4*>((p + g * 1024 + q * 256) + off);
+        }
+}
+template <typename E>
+__device__ __forceinline__ void raw_to_acc(const RawFrag<E>& r, f32x16 (&dst)[4]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[g][4 * q + e] = (float)r.v[4 * g + q][e];
+}
+
+template <typename E>
+__device__ __forceinline__ void store_frag4(E* p, unsigned off, const f32x16 (&src)[4]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if constexpr (sizeof(E) == 4) {
+                f32x4 v = {src[g][4 * q + 0], src[g][4 * q + 1], src[g][4 * q + 2], src[g][4 * q + 3]};
+                *reinterpret_cast<f32x4*>((p + g * 1024 + q * 256) + off) = v;
+            } else {
+                bf16x4 v = {(__bf16)src[g][4 * q + 0], (__bf16)src[g][4 * q + 1],
+                            (__bf16)src[g][4 * q + 2], (__bf16)src[g][4 * q + 3]};
+                *reinterpret_cast<bf16x4*>((p + g * 1024 + q * 256) + off) = v;
+            }
         }
 }
 
-template <bool SAVE, bool DROP>
+template <bool SAVE, bool DROP, typename PE>
 __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_h128_bf16_kernel(
-    float* __restrict__ P, const float* __restrict__ Whh, float* __restrict__ Y,
+    PE* __restrict__ P, const float* __restrict__ Whh, float* __restrict__ Y,
     float* __restrict__ Csave, __bf16* __restrict__ Yd, float drop_p, uint64_t seed, int T, int Bp) {
     __shared__ __attribute__((aligned(16))) __bf16 hs[2 * 32 * HB_LD];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -65,19 +116,23 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_h128_bf16_kernel(
     for (int r = 0; r < 16; ++r) c[r] = 0.f;
 
     const size_t pstep = (size_t)NBT * 16 * 1024, cstep = (size_t)NBT * 4096;
-    float* pblk = P + ((size_t)d * T * NBT + bt) * 16 * 1024 + (size_t)w * 4096;
+    PE* pblk = P + ((size_t)d * T * NBT + bt) * 16 * 1024 + (size_t)w * 4096;
     float* cblk = SAVE ? Csave + ((size_t)d * T * NBT + bt) * 4096 + (size_t)w * 1024 : nullptr;
     const unsigned frag_off = lane * 4;
     const unsigned y_off = (unsigned)(4 * hi * (D * H) + l31);
     const int t_first = d ? T - 1 : 0, dt = d ? -1 : 1;
 
-    f32x16 pa[4], pb[4];          // P two steps ahead: pa = step s, pb = step s+1
-    load_frag4(pblk + (size_t)t_first * pstep, frag_off, pa);
-    if (T > 1) load_frag4(pblk + (size_t)(t_first + dt) * pstep, frag_off, pb);
+    RawFrag<PE> pa, pb;           // P two steps ahead (raw): pa = step s, pb = step s+1
+    load_raw(pblk + (size_t)t_first * pstep, frag_off, pa);
+    if (T > 1) load_raw(pblk + (size_t)(t_first + dt) * pstep, frag_off, pb);
     __syncthreads();
 
-    auto one_step = [&](int step, f32x16 (&acc)[4], int cur) {
+    auto one_step = [&](int step, RawFrag<PE>& praw, int cur) {
         const int t = t_first + dt * step;
+        f32x16 acc[4];
+        raw_to_acc(praw, acc);
+        // refill this raw set with P of step + 2 (it is consumed two steps from now)
+        if (step + 2 < T) load_raw(pblk + (size_t)(t + 2 * dt) * pstep, frag_off, praw);
         // ---- z = P_t + h_{t-1} W_hh^T
         const __bf16* hrow = hs + cur * 32 * HB_LD + l31 * HB_LD + 8 * hi;
 #pragma unroll
@@ -107,14 +162,7 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_h128_bf16_kernel(
             if (SAVE) { acc[0][r] = ig; acc[1][r] = fg; acc[2][r] = gg; acc[3][r] = og; }
         }
         if (SAVE) {
-            float* p = pblk + (size_t)t * pstep;
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x4 v = {acc[g][4 * q + 0], acc[g][4 * q + 1], acc[g][4 * q + 2], acc[g][4 * q + 3]};
-                    *reinterpret_cast<f32x4*>((p + g * 1024 + q * 256) + frag_off) = v;
-                }
+            store_frag4(pblk + (size_t)t * pstep, frag_off, acc);
             float* cp = cblk + (size_t)t * cstep;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -122,8 +170,6 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_h128_bf16_kernel(
                 *reinterpret_cast<f32x4*>((cp + q * 256) + frag_off) = v;
             }
         }
-        // refill this register set with P of step + 2 (it is consumed two steps from now)
-        if (step + 2 < T) load_frag4(pblk + (size_t)(t + 2 * dt) * pstep, frag_off, acc);
         __syncthreads();
     };
 
@@ -137,8 +183,9 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_h128_bf16_kernel(
 // BPTT.  dgates are rounded to bf16 once: the LDS tile feeds the MFMA A operand AND is the dP
 // image copied to HBM (dP is bf16 in mixed mode).
 // ------------------------------------------------------------------------------------------
+template <typename PE>
 __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_h128_bf16_kernel(
-    const float* __restrict__ G, const float* __restrict__ Csave, const float* __restrict__ Whh,
+    const PE* __restrict__ G, const float* __restrict__ Csave, const float* __restrict__ Whh,
     const float* __restrict__ dY, __bf16* __restrict__ dP, float* __restrict__ dbias, int T, int Bp) {
     __shared__ __attribute__((aligned(16))) __bf16 dgs[32 * DGB_LD];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -159,7 +206,7 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_h128_bf16_kernel(
         }
     }
     const size_t gstep = (size_t)NBT * 16 * 1024, cstep = (size_t)NBT * 4096;
-    const float* gwave = G + ((size_t)d * T * NBT + bt) * 16 * 1024 + (size_t)w * 4096;
+    const PE* gwave = G + ((size_t)d * T * NBT + bt) * 16 * 1024 + (size_t)w * 4096;
     const float* cwave = Csave + ((size_t)d * T * NBT + bt) * 4096 + (size_t)w * 1024;
     const unsigned frag_off = lane * 4;
     const int DH = D * H, D4H = D * 4 * H;
@@ -187,8 +234,9 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_h128_bf16_kernel(
             for (int r = 0; r < 16; ++r) dst[r] = 0.f;
         }
     };
+    RawFrag<PE> graw;             // saved gates of the next step, raw until the cell backward consumes them
     auto load_step = [&](int t) {
-        load_frag4(gwave + (size_t)t * gstep, frag_off, gt);
+        load_raw(gwave + (size_t)t * gstep, frag_off, graw);
         load_c(t + dt, cp);
         const float* dp = dywave + (size_t)t * Bp * DH;
 #pragma unroll
@@ -199,6 +247,7 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_h128_bf16_kernel(
 
     for (int step = 0; step < T; ++step) {
         const int t = t_first + dt * step;
+        raw_to_acc(graw, gt);
         __bf16* dgw = dgs + 32 * w + l31 + 4 * hi * DGB_LD;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -242,7 +291,7 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_h128_bf16_kernel(
 
 }  // namespace
 
-extern "C" int lob_lstm_rec_fwd_bf16(float* P, const float* Whh, float* Y, float* Csave,
+extern "C" int lob_lstm_rec_fwd_bf16(void* P, int pg_bf16, const float* Whh, float* Y, float* Csave,
                                      void* Yd, float drop_p, uint64_t seed,
                                      int T, int Bp, int Hh, int D, int save, void* stream) {
     if (!P || !Whh || !Y || T <= 0 || Bp <= 0 || (D != 1 && D != 2)) return LOB_E_ARG;
@@ -254,22 +303,32 @@ extern "C" int lob_lstm_rec_fwd_bf16(float* P, const float* Whh, float* Y, float
     const dim3 grid(Bp / 32, D), block(256);
     hipStream_t s = (hipStream_t)stream;
     __bf16* yd = reinterpret_cast<__bf16*>(Yd);
-    if (save && yd)  hipLaunchKernelGGL((lstm_rec_fwd_h128_bf16_kernel<true, true>), grid, block, 0, s, P, Whh, Y, Csave, yd, drop_p, seed, T, Bp);
-    else if (save)   hipLaunchKernelGGL((lstm_rec_fwd_h128_bf16_kernel<true, false>), grid, block, 0, s, P, Whh, Y, Csave, yd, drop_p, seed, T, Bp);
-    else if (yd)     hipLaunchKernelGGL((lstm_rec_fwd_h128_bf16_kernel<false, true>), grid, block, 0, s, P, Whh, Y, Csave, yd, drop_p, seed, T, Bp);
-    else             hipLaunchKernelGGL((lstm_rec_fwd_h128_bf16_kernel<false, false>), grid, block, 0, s, P, Whh, Y, Csave, yd, drop_p, seed, T, Bp);
+#define LOB_FWD(SV, DR, PE) hipLaunchKernelGGL((lstm_rec_fwd_h128_bf16_kernel<SV, DR, PE>), grid, block, 0, s, \
+        reinterpret_cast<PE*>(P), Whh, Y, Csave, yd, drop_p, seed, T, Bp)
+    if (pg_bf16) {
+        if (save && yd) LOB_FWD(true, true, __bf16); else if (save) LOB_FWD(true, false, __bf16);
+        else if (yd) LOB_FWD(false, true, __bf16); else LOB_FWD(false, false, __bf16);
+    } else {
+        if (save && yd) LOB_FWD(true, true, float); else if (save) LOB_FWD(true, false, float);
+        else if (yd) LOB_FWD(false, true, float); else LOB_FWD(false, false, float);
+    }
+#undef LOB_FWD
     LOB_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int lob_lstm_rec_bwd_bf16(const float* G, const float* Csave, const float* Whh, const float* dY,
+extern "C" int lob_lstm_rec_bwd_bf16(const void* G, int pg_bf16, const float* Csave, const float* Whh, const float* dY,
                                      void* dP, float* dbias, int T, int Bp, int Hh, int D, void* stream) {
     if (!G || !Csave || !Whh || !dY || !dP || T <= 0 || Bp <= 0 || (D != 1 && D != 2)) return LOB_E_ARG;
     if (Hh != 128 || (Bp % 32)) return LOB_E_SHAPE;
     if ((reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(Csave) |
          reinterpret_cast<uintptr_t>(dP)) & 15) return LOB_E_ALIGN;
-    hipLaunchKernelGGL(lstm_rec_bwd_h128_bf16_kernel, dim3(Bp / 32, D), dim3(256), 0, (hipStream_t)stream,
-                       G, Csave, Whh, dY, reinterpret_cast<__bf16*>(dP), dbias, T, Bp);
+    if (pg_bf16)
+        hipLaunchKernelGGL((lstm_rec_bwd_h128_bf16_kernel<__bf16>), dim3(Bp / 32, D), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const __bf16*>(G), Csave, Whh, dY, reinterpret_cast<__bf16*>(dP), dbias, T, Bp);
+    else
+        hipLaunchKernelGGL((lstm_rec_bwd_h128_bf16_kernel<float>), dim3(Bp / 32, D), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const float*>(G), Csave, Whh, dY, reinterpret_cast<__bf16*>(dP), dbias, T, Bp);
     LOB_CHECK_LAUNCH();
     return 0;
 }

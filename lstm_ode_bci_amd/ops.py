@@ -94,20 +94,28 @@ def gemm_tn(a, b, out, mixed=False):
     return out
 
 
+#: mixed mode, H == 128: store the fragment-order pre-activations / saved gates as bf16 (half the HBM
+#: bytes of the two largest streams of the step).  Set to False to keep them fp32.
+PG_BF16 = True
+
+
 def gate_gemm_x(x, wih, bias, T, Bp, H, D, frag, mixed=False):
-    """P = x[T*Bp,K] @ wih[D*4H,K]^T + bias, fragment order when frag."""
+    """P = x[T*Bp,K] @ wih[D*4H,K]^T + bias, fragment order when frag.  In mixed mode at H == 128 P is
+    bf16 when ``ops.PG_BF16`` (it is only ever read by the bf16 recurrent kernel)."""
     x16 = x.dtype == torch.bfloat16
     _chk(x, "x", x.dtype if x16 else torch.float32); _chk(wih, "wih"); _chk(bias, "bias")
     K = x.shape[1]
     assert x.shape[0] == T * Bp and wih.shape == (D * 4 * H, K)
     if (mixed or x16) and not frag:
         return gemm_nt(x, wih, bias, mixed=True)
-    P = torch.empty((T * Bp, D * 4 * H), device=x.device, dtype=torch.float32)
     if (mixed or x16) and _bf16_ok(x, K, K):
-        rc = _lib.lib().lob_gate_gemm_x_bf16(_ptr(x), int(x16), K, _ptr(wih), _ptr(bias), _ptr(P), T, Bp, H, D, K,
-                                             _stream())
+        p16 = PG_BF16 and H == 128
+        P = torch.empty((T * Bp, D * 4 * H), device=x.device, dtype=torch.bfloat16 if p16 else torch.float32)
+        rc = _lib.lib().lob_gate_gemm_x_bf16(_ptr(x), int(x16), K, _ptr(wih), _ptr(bias), _ptr(P), int(p16),
+                                             T, Bp, H, D, K, _stream())
         _lib.check(rc, "lob_gate_gemm_x_bf16")
         return P
+    P = torch.empty((T * Bp, D * 4 * H), device=x.device, dtype=torch.float32)
     if x16:
         raise _lib.LobError("gate_gemm_x: bf16 input with a shape the bf16 kernel does not support")
     rc = _lib.lib().lob_gate_gemm_x_f32(_ptr(x), K, _ptr(wih), _ptr(bias), _ptr(P), T, Bp, H, D, K,
@@ -125,7 +133,8 @@ def lstm_rec_fwd(P, whh, T, Bp, H, D, save, mixed=False, drop_p=0.0, seed=0):
     """Runs the persistent recurrent kernel; returns (Y[T*Bp, D*H], Csave or None, Yd or None).
     mixed: h W_hh^T on bf16 MFMA (H == 128), everything else fp32.  drop_p > 0 (only with
     can_fuse_dropout): also returns Yd = bf16(dropout(Y))."""
-    _chk(P, "P"); _chk(whh, "whh")
+    p16 = P.dtype == torch.bfloat16
+    _chk(P, "P", P.dtype if p16 else torch.float32); _chk(whh, "whh")
     assert whh.shape == (D, 4 * H, H)
     Y = torch.empty((T * Bp, D * H), device=P.device, dtype=torch.float32)
     Cs = torch.empty((D * T * Bp * H,), device=P.device, dtype=torch.float32) if save else None
@@ -133,10 +142,11 @@ def lstm_rec_fwd(P, whh, T, Bp, H, D, save, mixed=False, drop_p=0.0, seed=0):
     if mixed and H == 128:
         if drop_p > 0:
             Yd = torch.empty((T * Bp, D * H), device=P.device, dtype=torch.bfloat16)
-        rc = _lib.lib().lob_lstm_rec_fwd_bf16(_ptr(P), _ptr(whh), _ptr(Y), _ptr(Cs), _ptr(Yd), float(drop_p),
-                                              C.c_uint64(seed), T, Bp, H, D, 1 if save else 0, _stream())
+        rc = _lib.lib().lob_lstm_rec_fwd_bf16(_ptr(P), int(p16), _ptr(whh), _ptr(Y), _ptr(Cs), _ptr(Yd),
+                                              float(drop_p), C.c_uint64(seed), T, Bp, H, D, 1 if save else 0,
+                                              _stream())
     else:
-        assert drop_p == 0
+        assert drop_p == 0 and not p16
         rc = _lib.lib().lob_lstm_rec_fwd_f32(_ptr(P), _ptr(whh), _ptr(Y), _ptr(Cs), T, Bp, H, D, 1 if save else 0,
                                              _stream())
     _lib.check(rc, "lob_lstm_rec_fwd")
@@ -227,14 +237,15 @@ def ode_rk4(base_rates, n_points, t0, t1, substeps, *, probs=None, alpha=0.0, y0
 # ---------------------------------------------------------------------------------------------
 def lstm_rec_bwd(G, Cs, whh, dY, T, Bp, H, D, dp_bf16=False):
     """BPTT through one layer; returns (dP[T*Bp, D*4H] row-major fp32|bf16, dbias[D*4H])."""
-    _chk(G, "G"); _chk(Cs, "Csave"); _chk(whh, "whh"); _chk(dY, "dY")
-    assert dY.shape == (T * Bp, D * H)
+    g16 = G.dtype == torch.bfloat16
+    _chk(G, "G", G.dtype if g16 else torch.float32); _chk(Cs, "Csave"); _chk(whh, "whh"); _chk(dY, "dY")
+    assert dY.shape == (T * Bp, D * H) and (not g16 or (dp_bf16 and H == 128))
     dP = torch.empty((T * Bp, D * 4 * H), device=G.device, dtype=torch.bfloat16 if dp_bf16 else torch.float32)
     fused_bias = uses_frag(H)
     dbias = torch.zeros((D * 4 * H,), device=G.device, dtype=torch.float32)
     if dp_bf16 and H == 128:
-        rc = _lib.lib().lob_lstm_rec_bwd_bf16(_ptr(G), _ptr(Cs), _ptr(whh), _ptr(dY), _ptr(dP), _ptr(dbias),
-                                              T, Bp, H, D, _stream())
+        rc = _lib.lib().lob_lstm_rec_bwd_bf16(_ptr(G), int(g16), _ptr(Cs), _ptr(whh), _ptr(dY), _ptr(dP),
+                                              _ptr(dbias), T, Bp, H, D, _stream())
     else:
         rc = _lib.lib().lob_lstm_rec_bwd_f32(_ptr(G), _ptr(Cs), _ptr(whh), _ptr(dY), _ptr(dP), int(dp_bf16),
                                              _ptr(dbias) if fused_bias else _ptr(None), T, Bp, H, D, _stream())
