@@ -116,13 +116,15 @@ int lob_colsum_bf16(const void* A, int lda, int M, int N, float* out, void* stre
  * (dP from lob_lstm_rec_bwd_f32), 0 for fp32 storage.  Shapes as the _f32 entry points; K % 8 == 0
  * and 16-byte aligned bases are required (LOB_E_ALIGN otherwise: use the fp32 entry point).
  * ---------------------------------------------------------------------------------- */
-int lob_gemm_nt_bf16(const void* A, int a_bf16, int lda, const float* W, int ldw, const float* bias,
-                     float* C, int ldc, int M, int N, int K, int act, float drop_p, uint64_t seed,
-                     void* stream);
+int lob_gemm_nt_bf16(const void* A, int a_bf16, int lda, const void* W, int w_bf16, int ldw,
+                     const float* bias, float* C, int ldc, int M, int N, int K, int act, float drop_p,
+                     uint64_t seed, void* stream);
+/*   a_bf16 = w_bf16 = 1 (both operands bf16 in HBM, no bias / activation, K % 32 == 0, K >= 128):
+ *   LDS-DMA kernel -- operand tiles go HBM -> LDS by global_load_lds, three k-tiles in flight.    */
 /*   drop_p > 0: the result is multiplied by the nn.Dropout mask of element (row*ldc + col) (same
  *   counter-based hash as lob_dropout_f32): fuses the backward of nn.LSTM's inter-layer dropout
  *   (04_lstm_model.py:186) into dX = dP W_ih.                                                */
-int lob_gate_gemm_x_bf16(const void* X, int x_bf16, int ldx, const float* Wih, const float* bias,
+int lob_gate_gemm_x_bf16(const void* X, int x_bf16, int ldx, const void* Wih, int w_bf16, const float* bias,
                          void* P, int p_bf16, int T, int Bp, int H, int D, int K, void* stream);
 /*   p_bf16 = 1: the fragment-order pre-activations are STORED as bf16 (same element order, half the
  *   bytes); the bf16 recurrent kernels take the matching pg_bf16 flag and also keep the activated gates

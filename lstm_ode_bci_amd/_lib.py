@@ -31,10 +31,10 @@ _SIGS = {
     "lob_lstm_rec_bwd_bf16": ([_f32p, C.c_int, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int,
                                C.c_void_p], C.c_int),
     "lob_colsum_bf16": ([_f32p, C.c_int, C.c_int, C.c_int, _f32p, C.c_void_p], C.c_int),
-    "lob_gemm_nt_bf16": ([_f32p, C.c_int, C.c_int, _f32p, C.c_int, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int,
-                          C.c_int, C.c_float, C.c_uint64, C.c_void_p], C.c_int),
-    "lob_gate_gemm_x_bf16": ([_f32p, C.c_int, C.c_int, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int,
-                              C.c_int, C.c_int, C.c_void_p], C.c_int),
+    "lob_gemm_nt_bf16": ([_f32p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, _f32p, _f32p, C.c_int, C.c_int, C.c_int,
+                          C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_void_p], C.c_int),
+    "lob_gate_gemm_x_bf16": ([_f32p, C.c_int, C.c_int, _f32p, C.c_int, _f32p, _f32p, C.c_int, C.c_int, C.c_int,
+                              C.c_int, C.c_int, C.c_int, C.c_void_p], C.c_int),
     "lob_gemm_tn_bf16": ([_f32p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.c_int, C.c_int,
                           C.c_void_p], C.c_int),
     "lob_colsum_f32": ([_f32p, C.c_int, C.c_int, C.c_int, _f32p, C.c_void_p], C.c_int),

@@ -65,14 +65,19 @@ def _forward_impl(x, ps, cfg, save):
         wih = torch.cat([d[0] for d in dirs], 0) if D > 1 else dirs[0][0]
         whh = torch.stack([d[1] for d in dirs], 0)
         bias = torch.cat([d[2] + d[3] for d in dirs], 0)
-        P = ops.gate_gemm_x(inp, wih, bias, T, Bp, H, D, frag, mixed=mixed)
+        # bf16 x bf16 operands (bf16 activations from the layer below + a bf16 copy of the weights) take
+        # the LDS-DMA GEMM; everything else the register-staged kernels
+        w_in = wih.to(torch.bfloat16) if (inp.dtype == torch.bfloat16 and ops.dma_ok(inp.shape[1])) else wih
+        P = ops.gate_gemm_x(inp, w_in, bias, T, Bp, H, D, frag, mixed=mixed)
         drop_here = layer + 1 < L and p_lstm > 0
-        fuse = drop_here and ops.can_fuse_dropout(H, mixed)
+        fusable = layer + 1 < L and ops.can_fuse_dropout(H, mixed)
+        fuse = drop_here and fusable
         Y, Cs, Yd = ops.lstm_rec_fwd(P, whh, T, Bp, H, D, save, mixed=mixed,
-                                     drop_p=p_lstm if fuse else 0.0, seed=_seed(seed, 10 + layer))
+                                     drop_p=p_lstm if fuse else 0.0, seed=_seed(seed, 10 + layer),
+                                     want_bf16=fusable)
         nxt = Y
-        if fuse:
-            nxt = Yd                                  # bf16, dropped: read by the next layer's bf16 GEMMs
+        if fusable:
+            nxt = Yd                  # bf16 (dropped in training): read by the next layer's bf16 GEMMs
         elif drop_here:
             nxt = ops.dropout(Y, p_lstm, _seed(seed, 10 + layer))
         if save:

@@ -230,6 +230,180 @@ __global__ __launch_bounds__(256, TKT == 32 ? 3 : 2) void gemm_nt_bf16_kernel(NT
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// LDS-DMA variant of the NT GEMM for bf16 operands in HBM (A = dP / dropped layer outputs, W =
+// bf16 copy of the weights).  The register-staged kernel above is latency-bound: one k-tile of
+// loads per workgroup in flight, measured 2.5-3 TB/s.  Here the operand tiles go HBM -> LDS with
+// global_load_lds_dwordx4 (no VGPRs, no conversion, no ds_write), a 4-slot ring keeps THREE k-tiles
+// per workgroup in flight across tile boundaries, waits are counted (s_waitcnt vmcnt(N), never 0 in
+// steady state) and the barrier is a raw s_barrier (a __syncthreads() would drain the DMA queue).
+//
+// LDS image of a slot: [128 rows][32 bf16] = 64-B rows, lane-linear as the DMA writes it (16 rows per
+// wave-instruction).  Unpadded 64-B rows would make the ds_read_b128 fragment reads 4-way conflicted,
+// so chunk c (16 B) of row r is stored at chunk slot c ^ ((r >> 2) & 3): the swizzle is applied on
+// the per-lane GLOBAL source address of the DMA and again on the fragment read (cdna guide rule 21).
+// ------------------------------------------------------------------------------------------
+constexpr int DS = 4;            // ring slots
+constexpr int DTK = 32;          // k per slot
+constexpr int DSLOT = 128 * DTK; // bf16 elements per operand per slot
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_cvoid;
+
+__device__ __forceinline__ void dma_rows16(const __bf16* G, int ld, int row0, int nrows, int k0, __bf16* lds_rows,
+                                           int lane) {
+    // one wave-instruction: 16 rows x 4 chunks of 16 B -> 1 KB of LDS starting at lds_rows (wave-uniform)
+    const int r = row0 + (lane >> 2), p = lane & 3;
+    const int c = p ^ ((r >> 2) & 3);
+    const int rr = r < nrows ? r : nrows - 1;                     // clamp: padded rows are never stored
+    const __bf16* src = G + (size_t)rr * ld + k0 + c * 8;
+    __builtin_amdgcn_global_load_lds((gbl_cvoid*)src, (lds_void*)lds_rows, 16, 0, 0);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(NTArgs g) {
+    __shared__ __attribute__((aligned(1024))) __bf16 ring[DS * 2 * DSLOT + 2048];     // 64 KB ring + 4 KB bias
+    float* bias_s = reinterpret_cast<float*>(ring + DS * 2 * DSLOT);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const __bf16* A = reinterpret_cast<const __bf16*>(g.A);
+    const __bf16* W = reinterpret_cast<const __bf16*>(g.W);
+    const int ntn = (g.N + TN_ - 1) / TN_, ntm = (g.M + TM - 1) / TM;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+    const int panels = (ntm - xcd + 7) / 8, ntile = panels * ntn;
+    const int nk = g.K / DTK;
+    if (slot >= ntile) return;
+    const int my_tiles = (ntile - slot + nslot - 1) / nslot;
+    const int total = my_tiles * nk;
+    if (EPI == 1) {       // bias via LDS: an ordinary global load inside the loop would make hipcc drain the DMA queue
+        for (int i = tid; i < g.N && i < 1024; i += 256) bias_s[i] = g.bias ? g.bias[i] : 0.f;
+        __syncthreads();
+    }
+
+    // producer cursor (runs DS-1 k-tiles ahead of the consumer, across tile boundaries)
+    int p_q = 0, p_it = slot, p_kt = 0;
+    auto issue = [&]() {
+        const int m0 = ((p_it / ntn) * 8 + xcd) * TM, n0 = (p_it % ntn) * TN_;
+        __bf16* as = ring + (p_q % DS) * 2 * DSLOT;
+        __bf16* ws = as + DSLOT;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int rb = (wave * 2 + j) * 16;
+            dma_rows16(A, g.lda, m0 + rb, g.M, p_kt * DTK, as + rb * DTK, lane);
+            dma_rows16(W, g.ldw, n0 + rb, g.N, p_kt * DTK, ws + rb * DTK, lane);
+        }
+        ++p_q;
+        if (++p_kt == nk) { p_kt = 0; p_it += nslot; }
+    };
+#pragma unroll 1
+    for (int i = 0; i < DS - 1 && i < total; ++i) issue();
+
+    int it = slot, kt = 0, since_epi = 99;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int q = 0; q < total; ++q) {
+        // ---- wait for slot q: all but the younger operations of THIS wave may still be in flight:
+        //      (DS-2) k-tiles x 4 DMAs, plus the 16 epilogue stores if they were issued after DMA(q)
+        if (q + DS - 1 > total) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (EPI == 1 && since_epi < DS - 1) {
+            asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        } else if (since_epi < DS - 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (p_q < total) issue();                       // refills the slot read in iteration q-1
+        ++since_epi;
+
+        const __bf16* as = ring + (q % DS) * 2 * DSLOT;
+        const __bf16* ws = as + DSLOT;
+        const int r31 = lane & 31, hi = lane >> 5, sw = (r31 >> 2) & 3;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int pc = ((2 * s + hi) ^ sw) * 8;
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(as + (64 * wr + r31) * DTK + pc);
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(as + (64 * wr + 32 + r31) * DTK + pc);
+            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(ws + (64 * wc + r31) * DTK + pc);
+            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(ws + (64 * wc + 32 + r31) * DTK + pc);
+            acc[0][0] = mfma_bf16(a0, b0, acc[0][0]);
+            acc[0][1] = mfma_bf16(a0, b1, acc[0][1]);
+            acc[1][0] = mfma_bf16(a1, b0, acc[1][0]);
+            acc[1][1] = mfma_bf16(a1, b1, acc[1][1]);
+        }
+        if (++kt < nk) continue;
+
+        // ---- epilogue of tile `it`
+        kt = 0;
+        const int cm0 = ((it / ntn) * 8 + xcd) * TM, cn0 = (it % ntn) * TN_;
+        it += nslot;
+        since_epi = 0;
+        if (EPI == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = cn0 + 64 * wc + 32 * j + (lane & 31);
+                    if (col < g.N) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = cm0 + 64 * wr + 32 * i + acc_row(r, lane);
+                            if (row < g.M) {
+                                float* dst = g.C + (size_t)row * g.ldc + col;
+                                float val = acc[i][j][r];
+                                if (g.drop_p > 0.f) val *= lob_dropout_scale(g.seed, (uint64_t)row * g.ldc + col, g.drop_p);
+                                *dst = val;      // no accumulate here: a read-modify-write would drain the DMA queue
+                            }
+                            acc[i][j][r] = 0.f;
+                        }
+                    }
+                }
+        } else {
+            const int NBT = g.Bp >> 5, NW = g.H >> 5, H4 = 4 * g.H;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int mrow = cm0 + 64 * wr + 32 * i;
+                const int t = mrow / g.Bp, bt = (mrow % g.Bp) >> 5;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int ncol = cn0 + 64 * wc + 32 * j;
+                    const int d = ncol / H4, gg = (ncol % H4) / g.H, w = (ncol % g.H) >> 5;
+                    const float bv = bias_s[ncol + (lane & 31)];
+                    const size_t fo = ((((size_t)(d * g.T + t) * NBT + bt) * NW + w) * 4 + gg) * 1024 + lane * 4;
+                    if (g.out_bf16) {
+                        __bf16* dst = reinterpret_cast<__bf16*>(g.C) + fo;
+#pragma unroll
+                        for (int qq = 0; qq < 4; ++qq) {
+                            bf16x4 v = {(__bf16)(acc[i][j][4 * qq + 0] + bv), (__bf16)(acc[i][j][4 * qq + 1] + bv),
+                                        (__bf16)(acc[i][j][4 * qq + 2] + bv), (__bf16)(acc[i][j][4 * qq + 3] + bv)};
+                            *reinterpret_cast<bf16x4*>(dst + qq * 256) = v;
+                        }
+                    } else {
+                        float* dst = g.C + fo;
+#pragma unroll
+                        for (int qq = 0; qq < 4; ++qq) {
+                            f32x4 v = {acc[i][j][4 * qq + 0] + bv, acc[i][j][4 * qq + 1] + bv,
+                                       acc[i][j][4 * qq + 2] + bv, acc[i][j][4 * qq + 3] + bv};
+                            *reinterpret_cast<f32x4*>(dst + qq * 256) = v;
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // C[M,N] += A[Kc,M]^T B[Kc,N]  (weight gradients), bf16 MFMA.  The contraction index is the ROW
 // index of both sources, i.e. both operands are "K-major".  The source tiles are copied into LDS
@@ -412,15 +586,34 @@ inline int nt_tk() {
 }  // namespace
 
 // A: fp32 (a_bf16 = 0) or bf16 (a_bf16 = 1) row-major [M][lda]; W fp32 [N][ldw]; C fp32.
-extern "C" int lob_gemm_nt_bf16(const void* A, int a_bf16, int lda, const float* W, int ldw, const float* bias,
-                                float* C, int ldc, int M, int N, int K, int act, float drop_p, uint64_t seed,
-                                void* stream) {
+inline bool nt_dma_enabled() {
+    static const bool v = [] { const char* e = getenv("LOB_NT_DMA"); return !(e && atoi(e) == 0); }();
+    return v;
+}
+inline int nt_dma_grid(int M, int N) {
+    const long tiles = (long)((M + TM - 1) / TM) * ((N + TN_ - 1) / TN_);
+    long gsz = 256L * 2;
+    if (gsz > tiles) gsz = ((tiles + 7) / 8) * 8;
+    return (int)gsz;
+}
+
+extern "C" int lob_gemm_nt_bf16(const void* A, int a_bf16, int lda, const void* W, int w_bf16, int ldw,
+                                const float* bias, float* C, int ldc, int M, int N, int K, int act, float drop_p,
+                                uint64_t seed, void* stream) {
     if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return LOB_E_ARG;
     if (lda < K || ldw < K || ldc < N) return LOB_E_SHAPE;
     if ((act & 0xff) > LOB_ACT_GELU || act < 0) return LOB_E_ARG;
     if (!al16(A) || !al16(W) || (K % 8) || (lda % 8) || (ldw % 4)) return LOB_E_ALIGN;
-    NTArgs g{A, W, bias, C, lda, ldw, ldc, M, N, K, act & 0xff, (act >> 8) & 1, dbg_flags(), 0, 0, 0, 0, 0, drop_p, seed};
+    NTArgs g{A, reinterpret_cast<const float*>(W), bias, C, lda, ldw, ldc, M, N, K, act & 0xff, (act >> 8) & 1,
+             dbg_flags(), 0, 0, 0, 0, 0, drop_p, seed};
     if (drop_p < 0.f || drop_p >= 1.f) return LOB_E_ARG;
+    if (w_bf16) {      // both operands bf16 in HBM: LDS-DMA kernel (no bias / activation in its row-major epilogue)
+        if (!a_bf16 || bias || act || (K % DTK) || K / DTK < DS || (ldw % 8)) return LOB_E_SHAPE;
+        hipLaunchKernelGGL((gemm_nt_dma_kernel<0>), dim3((unsigned)nt_dma_grid(M, N)), dim3(256), 0,
+                           (hipStream_t)stream, g);
+        LOB_CHECK_LAUNCH();
+        return 0;
+    }
     const dim3 grid((unsigned)nt_grid(M, N)), block(256);
     const bool tk32 = nt_tk() == 32;
     if (a_bf16) {
@@ -434,13 +627,21 @@ extern "C" int lob_gemm_nt_bf16(const void* A, int a_bf16, int lda, const float*
     return 0;
 }
 
-extern "C" int lob_gate_gemm_x_bf16(const void* X, int x_bf16, int ldx, const float* Wih, const float* bias,
+extern "C" int lob_gate_gemm_x_bf16(const void* X, int x_bf16, int ldx, const void* Wih, int w_bf16, const float* bias,
                                     void* P, int p_bf16, int T, int Bp, int H, int D, int K, void* stream) {
     if (!X || !Wih || !P || T <= 0 || Bp <= 0 || H <= 0 || K <= 0 || (D != 1 && D != 2)) return LOB_E_ARG;
     if (ldx < K || (H % 32) || (Bp % 32)) return LOB_E_SHAPE;
     if (!al16(X) || !al16(Wih) || !al16(P) || (K % 8) || (ldx % 8)) return LOB_E_ALIGN;
     const int N = D * 4 * H, M = T * Bp;
-    NTArgs g{X, Wih, bias, reinterpret_cast<float*>(P), ldx, K, N, M, N, K, LOB_ACT_NONE, 0, dbg_flags(), T, Bp, H, D, p_bf16, 0.f, 0};
+    NTArgs g{X, reinterpret_cast<const float*>(Wih), bias, reinterpret_cast<float*>(P), ldx, K, N, M, N, K, LOB_ACT_NONE, 0,
+             dbg_flags(), T, Bp, H, D, p_bf16, 0.f, 0};
+    if (w_bf16) {
+        if (!x_bf16 || (K % DTK) || K / DTK < DS || N > 1024 || (N % 128) || (M % 128)) return LOB_E_SHAPE;
+        hipLaunchKernelGGL((gemm_nt_dma_kernel<1>), dim3((unsigned)nt_dma_grid(M, N)), dim3(256), 0,
+                           (hipStream_t)stream, g);
+        LOB_CHECK_LAUNCH();
+        return 0;
+    }
     const dim3 grid((unsigned)nt_grid(M, N)), block(256);
     if (x_bf16) {
         if (nt_tk() == 32) hipLaunchKernelGGL((gemm_nt_bf16_kernel<true, 1, 32>), grid, block, 0, (hipStream_t)stream, g);

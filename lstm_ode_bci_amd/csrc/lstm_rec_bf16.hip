@@ -157,7 +157,8 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_h128_bf16_kernel(
             (yrow + (size_t)row * (D * H))[y_off] = h;
             if (DROP) {   // nn.LSTM's inter-layer dropout, fused: the next layer's GEMMs read this bf16 copy
                 const uint64_t idx = ybase + (uint64_t)row * (D * H) + y_off;
-                (Yd + ybase + (size_t)row * (D * H))[y_off] = (__bf16)(h * lob_dropout_scale(seed, idx, drop_p));
+                (Yd + ybase + (size_t)row * (D * H))[y_off] =
+                    (__bf16)(drop_p > 0.f ? h * lob_dropout_scale(seed, idx, drop_p) : h);
             }
             if (SAVE) { acc[0][r] = ig; acc[1][r] = fg; acc[2][r] = gg; acc[3][r] = og; }
         }
@@ -296,7 +297,7 @@ extern "C" int lob_lstm_rec_fwd_bf16(void* P, int pg_bf16, const float* Whh, flo
                                      int T, int Bp, int Hh, int D, int save, void* stream) {
     if (!P || !Whh || !Y || T <= 0 || Bp <= 0 || (D != 1 && D != 2)) return LOB_E_ARG;
     if (save && !Csave) return LOB_E_ARG;
-    if (Yd && (drop_p <= 0.f || drop_p >= 1.f)) return LOB_E_ARG;
+    if (Yd && (drop_p < 0.f || drop_p >= 1.f)) return LOB_E_ARG;      // drop_p = 0: plain bf16 copy
     if (Hh != 128 || (Bp % 32)) return LOB_E_SHAPE;
     if ((reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(Whh) |
          reinterpret_cast<uintptr_t>(Csave)) & 15) return LOB_E_ALIGN;

@@ -47,7 +47,9 @@ def gemm_nt(a, w, bias=None, act=ACT_NONE, out=None, accumulate=False, mixed=Fal
     """out[M,N] (+)= act(a[M,K] @ w[N,K]^T + bias).  mixed=True (or a bf16 `a`): bf16 MFMA inputs,
     fp32 accumulate/output; falls back to the exact-fp32 kernel for shapes the bf16 kernel refuses."""
     a_bf16 = a.dtype == torch.bfloat16
-    _chk(a, "a", a.dtype if a_bf16 else torch.float32); _chk(w, "w"); _chk(bias, "bias")
+    w_bf16 = w.dtype == torch.bfloat16
+    _chk(a, "a", a.dtype if a_bf16 else torch.float32); _chk(w, "w", w.dtype if w_bf16 else torch.float32)
+    _chk(bias, "bias")
     M, K = a.shape
     N = w.shape[0]
     assert w.shape[1] == K
@@ -57,8 +59,8 @@ def gemm_nt(a, w, bias=None, act=ACT_NONE, out=None, accumulate=False, mixed=Fal
     if accumulate:
         act = act | 0x100
     if (mixed or a_bf16) and _bf16_ok(a, K, K) and w.data_ptr() % 16 == 0:
-        rc = _lib.lib().lob_gemm_nt_bf16(_ptr(a), 1 if a_bf16 else 0, K, _ptr(w), K, _ptr(bias), _ptr(out), N,
-                                         M, N, K, act, float(drop_p), C.c_uint64(seed), _stream())
+        rc = _lib.lib().lob_gemm_nt_bf16(_ptr(a), 1 if a_bf16 else 0, K, _ptr(w), int(w_bf16), K, _ptr(bias),
+                                         _ptr(out), N, M, N, K, act, float(drop_p), C.c_uint64(seed), _stream())
         _lib.check(rc, "lob_gemm_nt_bf16")
         return out
     if drop_p > 0:
@@ -94,6 +96,14 @@ def gemm_tn(a, b, out, mixed=False):
     return out
 
 
+#: bf16 x bf16 NT GEMMs with K >= 128, K % 32 == 0 go through the LDS-DMA kernel (pass bf16 weights)
+NT_DMA = True
+
+
+def dma_ok(K):
+    return NT_DMA and K % 32 == 0 and K >= 128
+
+
 #: mixed mode, H == 128: store the fragment-order pre-activations / saved gates as bf16 (half the HBM
 #: bytes of the two largest streams of the step).  Set to False to keep them fp32.
 PG_BF16 = True
@@ -103,7 +113,9 @@ def gate_gemm_x(x, wih, bias, T, Bp, H, D, frag, mixed=False):
     """P = x[T*Bp,K] @ wih[D*4H,K]^T + bias, fragment order when frag.  In mixed mode at H == 128 P is
     bf16 when ``ops.PG_BF16`` (it is only ever read by the bf16 recurrent kernel)."""
     x16 = x.dtype == torch.bfloat16
-    _chk(x, "x", x.dtype if x16 else torch.float32); _chk(wih, "wih"); _chk(bias, "bias")
+    w16 = wih.dtype == torch.bfloat16
+    _chk(x, "x", x.dtype if x16 else torch.float32); _chk(wih, "wih", wih.dtype if w16 else torch.float32)
+    _chk(bias, "bias")
     K = x.shape[1]
     assert x.shape[0] == T * Bp and wih.shape == (D * 4 * H, K)
     if (mixed or x16) and not frag:
@@ -111,7 +123,7 @@ def gate_gemm_x(x, wih, bias, T, Bp, H, D, frag, mixed=False):
     if (mixed or x16) and _bf16_ok(x, K, K):
         p16 = PG_BF16 and H == 128
         P = torch.empty((T * Bp, D * 4 * H), device=x.device, dtype=torch.bfloat16 if p16 else torch.float32)
-        rc = _lib.lib().lob_gate_gemm_x_bf16(_ptr(x), int(x16), K, _ptr(wih), _ptr(bias), _ptr(P), int(p16),
+        rc = _lib.lib().lob_gate_gemm_x_bf16(_ptr(x), int(x16), K, _ptr(wih), int(w16), _ptr(bias), _ptr(P), int(p16),
                                              T, Bp, H, D, K, _stream())
         _lib.check(rc, "lob_gate_gemm_x_bf16")
         return P
@@ -129,7 +141,7 @@ def can_fuse_dropout(H, mixed):
     return bool(mixed) and H == 128
 
 
-def lstm_rec_fwd(P, whh, T, Bp, H, D, save, mixed=False, drop_p=0.0, seed=0):
+def lstm_rec_fwd(P, whh, T, Bp, H, D, save, mixed=False, drop_p=0.0, seed=0, want_bf16=False):
     """Runs the persistent recurrent kernel; returns (Y[T*Bp, D*H], Csave or None, Yd or None).
     mixed: h W_hh^T on bf16 MFMA (H == 128), everything else fp32.  drop_p > 0 (only with
     can_fuse_dropout): also returns Yd = bf16(dropout(Y))."""
@@ -140,7 +152,7 @@ def lstm_rec_fwd(P, whh, T, Bp, H, D, save, mixed=False, drop_p=0.0, seed=0):
     Cs = torch.empty((D * T * Bp * H,), device=P.device, dtype=torch.float32) if save else None
     Yd = None
     if mixed and H == 128:
-        if drop_p > 0:
+        if drop_p > 0 or want_bf16:
             Yd = torch.empty((T * Bp, D * H), device=P.device, dtype=torch.bfloat16)
         rc = _lib.lib().lob_lstm_rec_fwd_bf16(_ptr(P), int(p16), _ptr(whh), _ptr(Y), _ptr(Cs), _ptr(Yd),
                                               float(drop_p), C.c_uint64(seed), T, Bp, H, D, 1 if save else 0,

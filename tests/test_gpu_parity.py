@@ -585,7 +585,45 @@ def test_fused_dropout_equals_separate_kernels(dev, monkeypatch):
     lf, gf, xf = run()
     monkeypatch.setattr(ops, "can_fuse_dropout", lambda H, mixed: False)
     lu, gu, xu = run()
-    assert abs(lf - lu) < 1e-6
-    assert (xf - xu).abs().max().item() <= 1e-6 * max(1.0, xu.abs().max().item())
+    # the two pipelines run different GEMM kernels (LDS-DMA vs register-staged: other accumulation order),
+    # so equality is to fp32 rounding, not bitwise; a mask mismatch would be an O(1) difference
+    assert abs(lf - lu) < 1e-5
+    assert (xf - xu).abs().max().item() <= 2e-3 * xu.abs().max().item()
     for k in gf:
-        assert (gf[k] - gu[k]).abs().max().item() <= 2e-5 * max(1e-6, gu[k].abs().max().item()) + 1e-9, k
+        assert (gf[k] - gu[k]).abs().max().item() <= 2e-3 * max(1e-6, gu[k].abs().max().item()) + 1e-9, k
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 1024, 256), (8192, 256, 1024), (1000, 256, 128), (128, 128, 512)])
+def test_gemm_nt_lds_dma(dev, M, N, K):
+    """bf16 x bf16 NT GEMM through the LDS-DMA kernel (row-major epilogue, ragged M, fused dropout)."""
+    from lstm_ode_bci_amd import ops
+    rng = np.random.default_rng(M + N + K)
+    a = torch.from_numpy(rng.standard_normal((M, K), dtype=np.float32)).to(dev).to(torch.bfloat16)
+    w = torch.from_numpy(rng.standard_normal((N, K), dtype=np.float32)).to(dev).to(torch.bfloat16)
+    ref = a.cpu().double() @ w.cpu().double().T
+    out = ops.gemm_nt(a, w)
+    assert (out.cpu().double() - ref).abs().max().item() < 1e-5 * K ** 0.5 * 4
+    # twice in a row on the same buffers (persistent ring must start clean), and with the dropout epilogue
+    out2 = ops.gemm_nt(a, w, drop_p=0.4, seed=99)
+    mask = ops.dropout(torch.ones((M, N), device=dev), 0.4, 99)
+    assert torch.equal(out2, out * mask)
+
+
+def test_gate_gemm_lds_dma_fragment_layout(dev):
+    """bf16 x bf16 gate GEMM (fragment epilogue, fp32 and bf16 P) == the register-staged kernel."""
+    from lstm_ode_bci_amd import ops
+    rng = np.random.default_rng(5)
+    T, Bp, H, D, K = 6, 128, 128, 2, 256
+    x = torch.from_numpy(rng.standard_normal((T * Bp, K), dtype=np.float32)).to(dev).to(torch.bfloat16)
+    wih = torch.from_numpy(rng.uniform(-0.1, 0.1, (D * 4 * H, K)).astype(np.float32)).to(dev)
+    bias = torch.from_numpy(rng.standard_normal(D * 4 * H).astype(np.float32)).to(dev)
+    for pg in (False, True):
+        ops.PG_BF16 = pg
+        try:
+            p_reg = ops.gate_gemm_x(x, wih, bias, T, Bp, H, D, True, mixed=True)
+            p_dma = ops.gate_gemm_x(x, wih.to(torch.bfloat16), bias, T, Bp, H, D, True, mixed=True)
+        finally:
+            ops.PG_BF16 = True
+        assert p_reg.dtype == p_dma.dtype == (torch.bfloat16 if pg else torch.float32)
+        # the fp32 weights are rounded to bf16 inside the register-staged kernel: same products
+        assert (p_reg.float() - p_dma.float()).abs().max().item() < (2e-2 if pg else 1e-5)

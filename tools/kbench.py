@@ -81,3 +81,19 @@ for mixed in (False, True):
             report(f"dX {tag}", timeit(lambda: ops.gemm_nt(dP, wt, mixed=mixed)), 2.0 * rows * N * K,
                    eb * rows * N + 4.0 * rows * K)
         del Pk, Y, Cs, dP
+
+# ---- LDS-DMA NT GEMM (bf16 x bf16) ----------------------------------------------------------
+if on("dma"):
+    for K in (128, 256):
+        xb = torch.randn((rows, K), generator=g).to(dev).to(torch.bfloat16)
+        wb = (torch.rand((N, K), generator=g) * 0.17 - 0.085).to(dev)
+        bias = torch.zeros(N, device=dev)
+        for wdt, nm in ((torch.float32, "regstage"), (torch.bfloat16, "dma")):
+            report(f"gate_gemm K={K} bf16X {nm}", timeit(lambda: ops.gate_gemm_x(xb, wb.to(wdt), bias, T, Bp, H, D, True, mixed=True)),
+                   2.0 * rows * N * K, rows * (2.0 * K + 2.0 * N))
+    dPb = torch.randn((rows, N), generator=g).to(dev).to(torch.bfloat16)
+    for Kout in (128, 256):
+        wt = (torch.rand((Kout, N), generator=g) * 0.1).to(dev)
+        for wdt, nm in ((torch.float32, "regstage"), (torch.bfloat16, "dma")):
+            report(f"dX N={Kout} {nm}", timeit(lambda: ops.gemm_nt(dPb, wt.to(wdt), mixed=True)), 2.0 * rows * N * Kout,
+                   rows * (2.0 * N + 4.0 * Kout))
