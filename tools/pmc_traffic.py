@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (collected SEPARATELY, as
+MI355X_MICROARCH.md prescribes) into per-launch HBM traffic of the bench's hot kernels.
+
+    python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <tag> [B]
+
+gfx950 corrections (MI355X_MICROARCH.md §HBM): FETCH_SIZE counts 64 B per 128-B request, i.e. exactly
+half of the bytes of wide coalesced reads (checked here on kernels with a known byte count: the bf16
+recurrent kernels read 2.1 GB of P and report 1.05 M KB), so reads = 2 x FETCH_SIZE; WRITE_SIZE is exact.
+Both counters are in KB.  Writes profiles/<tag>_pmc_summary.csv and updates profiles/pmc_traffic.json,
+which bench.py reads to fill roofline.traffic.
+"""
+import collections
+import csv
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# bench label -> (precision, substring of the profiler's kernel name)
+KERNELS = {
+    "lstm_rec_fwd(save)": [("mixed", "lstm_rec_fwd_h128_bf16_kernelILb1ELb0"), ("fp32", "lstm_rec_fwd_h128_kernel<true")],
+    "lstm_rec_fwd": [("mixed", "lstm_rec_fwd_h128_bf16_kernelILb0ELb0"), ("fp32", "lstm_rec_fwd_h128_kernel<false")],
+    "lstm_rec_bwd": [("mixed", "lstm_rec_bwd_h128_bf16_kernel"), ("fp32", "lstm_rec_bwd_h128_kernel")],
+    "gate_gemm_x(K=256)": [("mixed", "gemm_nt_bf16_kernel<false, 1"), ("fp32", "gemm_nt_kernel<true, 1>")],
+}
+
+
+def load(path, counter):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return agg
+
+
+def main():
+    fetch, write, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+    B = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
+    f, w = load(fetch, "FETCH_SIZE"), load(write, "WRITE_SIZE")
+    rows = []
+    for k in sorted(set(f) | set(w), key=lambda k: -(sum(f.get(k, [0])) + sum(w.get(k, [0])))):
+        fv, wv = f.get(k, [0.0]), w.get(k, [0.0])
+        fa, wa = sum(fv) / len(fv), sum(wv) / len(wv)
+        rows.append({"kernel": k, "launches": max(len(fv), len(wv)), "FETCH_SIZE_KB_avg": round(fa, 1),
+                     "WRITE_SIZE_KB_avg": round(wa, 1), "hbm_bytes_per_launch_corrected": int((2 * fa + wa) * 1024)})
+    out = os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.csv")
+    with open(out, "w", newline="") as fh:
+        wr = csv.DictWriter(fh, fieldnames=list(rows[0]))
+        wr.writeheader()
+        wr.writerows(rows)
+    jpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    table = json.load(open(jpath)) if os.path.exists(jpath) else {}
+    for label, alts in KERNELS.items():
+        for prec, sub in alts:
+            for r in rows:
+                if sub in r["kernel"]:
+                    table[f"{label}|{prec}|B{B}"] = r["hbm_bytes_per_launch_corrected"]
+                    break
+    json.dump(table, open(jpath, "w"), indent=1, sort_keys=True)
+    print(out)
+    print(json.dumps(table, indent=1))
+
+
+if __name__ == "__main__":
+    main()
