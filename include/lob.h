@@ -168,11 +168,13 @@ int lob_attn_pool_bwd_f32(const float* V, const float* U, const float* attn, con
  * dropout, optional (b,t)->(t,b) row remap.  out[row'] = drop(act(LN(in[row]))).
  *   remap_T > 0: in rows are ordered (b, t) with t < remap_T; out row = t*Bp + b.
  *   remap_T = 0: out row = in row.
+ *   out_bf16 = 1 (widths 128/256/512 only): the result is stored as bf16 (mixed mode: it only feeds
+ *   bf16 MFMA GEMMs).
  * nn.LayerNorm + nn.GELU + nn.Dropout of input_proj (04_lstm_model.py:175-177) and
  * the post-LSTM nn.LayerNorm (04:192, 212).
  * ---------------------------------------------------------------------------------- */
 int lob_layernorm_act_f32(const float* in, const float* gamma, const float* beta,
-                          float* out, int rows, int width, float eps, int act,
+                          void* out, int out_bf16, int rows, int width, float eps, int act,
                           int remap_T, int remap_B, int remap_Bp,
                           float drop_p, uint64_t seed, void* stream);
 

@@ -54,8 +54,8 @@ def _forward_impl(x, ps, cfg, save):
     sv = {} if save else None
 
     pre = ops.gemm_nt(x2d, proj_w, proj_b)                                   # (B*T, H), rows (b,t)
-    a = ops.layernorm_act(pre, ln0_g, ln0_b, act=ACT_GELU, remap=(T, B, Bp),
-                          drop_p=p_in, seed=_seed(seed, 0))                  # (T*Bp, H) time-major
+    a = ops.layernorm_act(pre, ln0_g, ln0_b, act=ACT_GELU, remap=(T, B, Bp), drop_p=p_in, seed=_seed(seed, 0),
+                          out_bf16=mixed and frag)   # (T*Bp, H) time-major; bf16 when only bf16 GEMMs read it
     if save:
         sv["x2d"], sv["pre"], sv["a"] = x2d, pre, a
         sv["layers"] = []
@@ -67,7 +67,8 @@ def _forward_impl(x, ps, cfg, save):
         bias = torch.cat([d[2] + d[3] for d in dirs], 0)
         # bf16 x bf16 operands (bf16 activations from the layer below + a bf16 copy of the weights) take
         # the LDS-DMA GEMM; everything else the register-staged kernels
-        w_in = wih.to(torch.bfloat16) if (inp.dtype == torch.bfloat16 and ops.dma_ok(inp.shape[1])) else wih
+        w_in = wih.to(torch.bfloat16) if (inp.dtype == torch.bfloat16 and frag and
+                                          ops.dma_ok(inp.shape[1], wih.shape[0], inp.shape[0])) else wih
         P = ops.gate_gemm_x(inp, w_in, bias, T, Bp, H, D, frag, mixed=mixed)
         drop_here = layer + 1 < L and p_lstm > 0
         fusable = layer + 1 < L and ops.can_fuse_dropout(H, mixed)

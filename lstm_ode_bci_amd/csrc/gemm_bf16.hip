@@ -263,7 +263,7 @@ __device__ __forceinline__ void dma_rows16(const __bf16* G, int ld, int row0, in
 
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(NTArgs g) {
-    __shared__ __attribute__((aligned(1024))) __bf16 ring[DS * 2 * DSLOT + 2048];     // 64 KB ring + 4 KB bias
+    __shared__ __attribute__((aligned(1024))) __bf16 ring[DS * 2 * DSLOT + 4096];     // 64 KB ring + 8 KB bias
     float* bias_s = reinterpret_cast<float*>(ring + DS * 2 * DSLOT);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(NTArgs g) {
     const int my_tiles = (ntile - slot + nslot - 1) / nslot;
     const int total = my_tiles * nk;
     if (EPI == 1) {       // bias via LDS: an ordinary global load inside the loop would make hipcc drain the DMA queue
-        for (int i = tid; i < g.N && i < 1024; i += 256) bias_s[i] = g.bias ? g.bias[i] : 0.f;
+        for (int i = tid; i < g.N && i < 2048; i += 256) bias_s[i] = g.bias ? g.bias[i] : 0.f;
         __syncthreads();
     }
 
@@ -636,7 +636,7 @@ extern "C" int lob_gate_gemm_x_bf16(const void* X, int x_bf16, int ldx, const vo
     NTArgs g{X, reinterpret_cast<const float*>(Wih), bias, reinterpret_cast<float*>(P), ldx, K, N, M, N, K, LOB_ACT_NONE, 0,
              dbg_flags(), T, Bp, H, D, p_bf16, 0.f, 0};
     if (w_bf16) {
-        if (!x_bf16 || (K % DTK) || K / DTK < DS || N > 1024 || (N % 128) || (M % 128)) return LOB_E_SHAPE;
+        if (!x_bf16 || (K % DTK) || K / DTK < DS || N > 2048 || (N % 128) || (M % 128)) return LOB_E_SHAPE;
         hipLaunchKernelGGL((gemm_nt_dma_kernel<1>), dim3((unsigned)nt_dma_grid(M, N)), dim3(256), 0,
                            (hipStream_t)stream, g);
         LOB_CHECK_LAUNCH();

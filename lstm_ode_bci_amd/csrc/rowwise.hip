@@ -234,9 +234,18 @@ __device__ __forceinline__ void stv(float* p, const float (&v)[VPL]) {
 }
 
 template <int VPL>
+__device__ __forceinline__ void stv_bf16(__bf16* p, const float (&v)[VPL]) {
+    typedef __bf16 bvec __attribute__((ext_vector_type(VPL)));
+    bvec t;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) t[i] = (__bf16)v[i];
+    *reinterpret_cast<bvec*>(p) = t;
+}
+
+template <int VPL, bool OUT_BF16>
 __global__ __launch_bounds__(256) void layernorm_act_vec_kernel(
     const float* __restrict__ in, const float* __restrict__ gamma, const float* __restrict__ beta,
-    float* __restrict__ out, int rows, float eps, int act,
+    void* __restrict__ outv, int rows, float eps, int act,
     int remap_T, int remap_B, int remap_Bp, float drop_p, uint64_t seed) {
     constexpr int width = 64 * VPL;
     const int lane = threadIdx.x & 63;
@@ -266,7 +275,8 @@ __global__ __launch_bounds__(256) void layernorm_act_vec_kernel(
             if (drop_p > 0.f) o *= lob_dropout_scale(seed, (uint64_t)orow * width + lane * VPL + i, drop_p);
             v[i] = o;
         }
-        stv<VPL>(out + (size_t)orow * width + lane * VPL, v);
+        if (OUT_BF16) stv_bf16<VPL>(reinterpret_cast<__bf16*>(outv) + (size_t)orow * width + lane * VPL, v);
+        else          stv<VPL>(reinterpret_cast<float*>(outv) + (size_t)orow * width + lane * VPL, v);
     }
 }
 
@@ -394,7 +404,7 @@ extern "C" int lob_dropout_f32(const float* in, float* out, int64_t n, float p, 
 }
 
 extern "C" int lob_layernorm_act_f32(const float* in, const float* gamma, const float* beta,
-                                     float* out, int rows, int width, float eps, int act,
+                                     void* out, int out_bf16, int rows, int width, float eps, int act,
                                      int remap_T, int remap_B, int remap_Bp,
                                      float drop_p, uint64_t seed, void* stream) {
     if (!in || !gamma || !beta || !out || rows <= 0 || width <= 0) return LOB_E_ARG;
@@ -406,14 +416,18 @@ extern "C" int lob_layernorm_act_f32(const float* in, const float* gamma, const 
     if (blocks > 256 * 16) blocks = 256 * 16;
     const bool al = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) |
                       reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) == 0;
-#define LOB_LN_VEC(V) hipLaunchKernelGGL((layernorm_act_vec_kernel<V>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, \
-                       in, gamma, beta, out, rows, eps, act, remap_T, remap_B, remap_Bp, drop_p, seed)
+#define LOB_LN_VEC(V) do { if (out_bf16) hipLaunchKernelGGL((layernorm_act_vec_kernel<V, true>), dim3(blocks), dim3(256), 0, \
+        (hipStream_t)stream, in, gamma, beta, out, rows, eps, act, remap_T, remap_B, remap_Bp, drop_p, seed); \
+    else hipLaunchKernelGGL((layernorm_act_vec_kernel<V, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, \
+        in, gamma, beta, out, rows, eps, act, remap_T, remap_B, remap_Bp, drop_p, seed); } while (0)
     if (al && width == 128) LOB_LN_VEC(2);
     else if (al && width == 256) LOB_LN_VEC(4);
     else if (al && width == 512) LOB_LN_VEC(8);
-    else
-    hipLaunchKernelGGL(layernorm_act_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                       in, gamma, beta, out, rows, width, eps, act, remap_T, remap_B, remap_Bp, drop_p, seed);
+    else {
+        if (out_bf16) return LOB_E_SHAPE;       // bf16 output exists on the vectorised path only
+        hipLaunchKernelGGL(layernorm_act_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, gamma, beta,
+                           reinterpret_cast<float*>(out), rows, width, eps, act, remap_T, remap_B, remap_Bp, drop_p, seed);
+    }
 #undef LOB_LN_VEC
     LOB_CHECK_LAUNCH();
     return 0;

@@ -100,8 +100,9 @@ def gemm_tn(a, b, out, mixed=False):
 NT_DMA = True
 
 
-def dma_ok(K):
-    return NT_DMA and K % 32 == 0 and K >= 128
+def dma_ok(K, N=128, M=128):
+    """Shapes the LDS-DMA NT GEMM accepts (K = contraction, N = output columns, M = rows)."""
+    return NT_DMA and K % 32 == 0 and K >= 128 and N % 128 == 0 and N <= 2048 and M % 128 == 0
 
 
 #: mixed mode, H == 128: store the fragment-order pre-activations / saved gates as bf16 (half the HBM
@@ -165,22 +166,26 @@ def lstm_rec_fwd(P, whh, T, Bp, H, D, save, mixed=False, drop_p=0.0, seed=0, wan
     return Y, Cs, Yd
 
 
-def layernorm_act(x, gamma, beta, act=ACT_NONE, eps=1e-5, remap=None, drop_p=0.0, seed=0, out=None):
+def layernorm_act(x, gamma, beta, act=ACT_NONE, eps=1e-5, remap=None, drop_p=0.0, seed=0, out=None,
+                  out_bf16=False):
     """LN(+act, +dropout) over the last axis of x[rows, width]; remap=(T, B, Bp) relays rows
     (b,t) -> t*Bp + b (out must then have T*Bp rows; pad rows are left untouched)."""
     _chk(x, "x"); _chk(gamma, "gamma"); _chk(beta, "beta")
     rows, width = x.shape
+    out_bf16 = bool(out_bf16) and width in (128, 256, 512)
+    odt = torch.bfloat16 if out_bf16 else torch.float32
     if remap is None:
         rT = rB = rBp = 0
         if out is None:
-            out = torch.empty_like(x)
+            out = torch.empty((rows, width), device=x.device, dtype=odt)
     else:
         rT, rB, rBp = remap
         if out is None:
-            out = torch.zeros((rT * rBp, width), device=x.device, dtype=torch.float32) if rBp != rB else \
-                torch.empty((rT * rBp, width), device=x.device, dtype=torch.float32)
-    _chk(out, "out")
-    rc = _lib.lib().lob_layernorm_act_f32(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(out), rows, width, eps, act,
+            out = torch.zeros((rT * rBp, width), device=x.device, dtype=odt) if rBp != rB else \
+                torch.empty((rT * rBp, width), device=x.device, dtype=odt)
+    _chk(out, "out", odt)
+    rc = _lib.lib().lob_layernorm_act_f32(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(out), int(out_bf16), rows, width,
+                                          eps, act,
                                           rT, rB, rBp, float(drop_p), C.c_uint64(seed), _stream())
     _lib.check(rc, "lob_layernorm_act_f32")
     return out
