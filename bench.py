@@ -110,7 +110,7 @@ def kernel_roofline(dev, B, mode, precision):
             return ops.lstm_rec_fwd(Pk, whh, T, Bp, H, D, True, mixed=mixed)
         t_copy = timeit(lambda: Pk.copy_(P))
         sec = timeit(rec_fwd, n=3) - t_copy
-        Y, Cs, _ = rec_fwd()
+        Y, Cs, _, _ = rec_fwd()
         out["lstm_rec_fwd(save)"] = {"sec": sec, "flop": 2.0 * rows * N * H, "per_step": L,
                                      "mfma": "bf16" if bf16_rec else "f32",
                                      "bytes": rows * (2 * pe * N + 8.0 * K)}   # P in, gates out, c out, Y out

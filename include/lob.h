@@ -136,10 +136,12 @@ int lob_gemm_tn_bf16(const void* A, int a_bf16, int lda, const void* B, int b_bf
  * stored and carried through time stays fp32).  Same arguments as lob_lstm_rec_fwd_f32 /
  * lob_lstm_rec_bwd_f32; dP is always bf16 here.                                            */
 int lob_lstm_rec_fwd_bf16(void* P, int pg_bf16, const float* Whh, float* Y, float* Csave,
-                          void* Yd, float drop_p, uint64_t seed,
+                          void* Y16, void* Yd, float drop_p, uint64_t seed,
                           int T, int Bp, int H, int D, int save, void* stream);
-/*   Yd != NULL: additionally writes Yd = bf16(dropout(Y; drop_p, seed)), element index = position in
- *   Y -- nn.LSTM's inter-layer dropout fused into the producer; the next layer's bf16 GEMMs read it. */
+/*   Outputs, any non-empty subset with Y or Y16 present: Y (fp32 [T*Bp][D*H]), Y16 = bf16(Y) and
+ *   Yd = bf16(dropout(Y; drop_p, seed)) (element index = position in Y) -- nn.LSTM's inter-layer dropout
+ *   (04_lstm_model.py:186) fused into the producer.  In mixed mode the bf16 GEMMs of the next layer read
+ *   Yd (or Y16 without dropout) and dW_hh reads Y16, so layers below the last never write fp32 Y.  */
 int lob_lstm_rec_bwd_bf16(const void* G, int pg_bf16, const float* Csave, const float* Whh, const float* dY,
                           void* dP, float* dbias, int T, int Bp, int H, int D, void* stream);
 

@@ -70,19 +70,26 @@ def _forward_impl(x, ps, cfg, save):
         w_in = wih.to(torch.bfloat16) if (inp.dtype == torch.bfloat16 and frag and
                                           ops.dma_ok(inp.shape[1], wih.shape[0], inp.shape[0])) else wih
         P = ops.gate_gemm_x(inp, w_in, bias, T, Bp, H, D, frag, mixed=mixed)
-        drop_here = layer + 1 < L and p_lstm > 0
-        fusable = layer + 1 < L and ops.can_fuse_dropout(H, mixed)
-        fuse = drop_here and fusable
-        Y, Cs, Yd = ops.lstm_rec_fwd(P, whh, T, Bp, H, D, save, mixed=mixed,
-                                     drop_p=p_lstm if fuse else 0.0, seed=_seed(seed, 10 + layer),
-                                     want_bf16=fusable)
-        nxt = Y
-        if fusable:
-            nxt = Yd                  # bf16 (dropped in training): read by the next layer's bf16 GEMMs
+        last = layer + 1 == L
+        drop_here = not last and p_lstm > 0
+        bf16_out = ops.can_fuse_dropout(H, mixed)        # the bf16-MFMA recurrent kernel emits bf16 copies itself
+        fuse = drop_here and bf16_out
+        # mixed mode: layers below the last never materialise fp32 Y (only bf16 consumers remain: the next
+        # layer's GEMMs read Yd / Y16, dW_hh reads Y16); the last layer keeps fp32 Y for the LayerNorm
+        Y, Cs, Y16, Yd = ops.lstm_rec_fwd(P, whh, T, Bp, H, D, save, mixed=mixed,
+                                          drop_p=p_lstm if fuse else 0.0, seed=_seed(seed, 10 + layer),
+                                          want_f32=last or not bf16_out, want_bf16=bf16_out and (save or not last))
+        if fuse:
+            nxt = Yd
+        elif bf16_out and not last:
+            nxt = Y16
         elif drop_here:
             nxt = ops.dropout(Y, p_lstm, _seed(seed, 10 + layer))
+        else:
+            nxt = Y
         if save:
-            sv["layers"].append({"inp": inp, "G": P, "C": Cs, "Y": Y, "wih": wih, "whh": whh, "fused_drop": fuse})
+            sv["layers"].append({"inp": inp, "G": P, "C": Cs, "Y": Y16 if Y16 is not None else Y, "wih": wih,
+                                 "whh": whh, "fused_drop": fuse})
         inp = nxt
     ln_g, ln_b = next(it), next(it)
     a0w, a0b, a2w, a2b = next(it), next(it), next(it), next(it)

@@ -89,10 +89,15 @@ __device__ __forceinline__ void store_frag4(E* p, unsigned off, const f32x16 (&s
         }
 }
 
-template <bool SAVE, bool DROP, typename PE>
+// Outputs: Y (fp32, scattered 128-B segments straight from the accumulator layout) when YF32; the bf16
+// copies -- Y16 (h_t as the next GEMMs' bf16 operand) and Yd (the same with nn.LSTM's inter-layer dropout
+// applied) -- are produced from the bf16 h tile in LDS one barrier later, as whole 256-B row segments
+// (16 B per lane), instead of 2-byte stores from the accumulator layout.
+template <bool SAVE, bool YF32, bool Y16, bool DROP, typename PE>
 __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_h128_bf16_kernel(
     PE* __restrict__ P, const float* __restrict__ Whh, float* __restrict__ Y,
-    float* __restrict__ Csave, __bf16* __restrict__ Yd, float drop_p, uint64_t seed, int T, int Bp) {
+    float* __restrict__ Csave, __bf16* __restrict__ Y16p, __bf16* __restrict__ Yd, float drop_p, uint64_t seed,
+    int T, int Bp) {
     __shared__ __attribute__((aligned(16))) __bf16 hs[2 * 32 * HB_LD];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -154,12 +159,7 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_h128_bf16_kernel(
             const float h = og * fast_tanh(c[r]);
             const int row = (r & 3) + 8 * (r >> 2);
             hnext[row * HB_LD] = (__bf16)h;
-            (yrow + (size_t)row * (D * H))[y_off] = h;
-            if (DROP) {   // nn.LSTM's inter-layer dropout, fused: the next layer's GEMMs read this bf16 copy
-                const uint64_t idx = ybase + (uint64_t)row * (D * H) + y_off;
-                (Yd + ybase + (size_t)row * (D * H))[y_off] =
-                    (__bf16)(drop_p > 0.f ? h * lob_dropout_scale(seed, idx, drop_p) : h);
-            }
+            if (YF32) (yrow + (size_t)row * (D * H))[y_off] = h;
             if (SAVE) { acc[0][r] = ig; acc[1][r] = fg; acc[2][r] = gg; acc[3][r] = og; }
         }
         if (SAVE) {
@@ -172,6 +172,23 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_h128_bf16_kernel(
             }
         }
         __syncthreads();
+        if (Y16 || DROP) {       // h_t is now complete in hs[cur ^ 1]: emit the bf16 row segments
+            const __bf16* hsrc = hs + (cur ^ 1) * 32 * HB_LD;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int idx = tid + 256 * i, row = idx >> 4, c8 = (idx & 15) * 8;
+                const bf16x8 hv = *reinterpret_cast<const bf16x8*>(hsrc + row * HB_LD + c8);
+                const size_t o = ((size_t)t * Bp + bt * 32 + row) * (D * H) + d * H + c8;
+                if (Y16) *reinterpret_cast<bf16x8*>(Y16p + o) = hv;
+                if (DROP) {
+                    bf16x8 dv;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        dv[j] = (__bf16)((float)hv[j] * lob_dropout_scale(seed, (uint64_t)o + j, drop_p));
+                    *reinterpret_cast<bf16x8*>(Yd + o) = dv;
+                }
+            }
+        }
     };
 
     for (int step = 0; step < T; step += 2) {
@@ -293,26 +310,32 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_h128_bf16_kernel(
 }  // namespace
 
 extern "C" int lob_lstm_rec_fwd_bf16(void* P, int pg_bf16, const float* Whh, float* Y, float* Csave,
-                                     void* Yd, float drop_p, uint64_t seed,
+                                     void* Y16, void* Yd, float drop_p, uint64_t seed,
                                      int T, int Bp, int Hh, int D, int save, void* stream) {
-    if (!P || !Whh || !Y || T <= 0 || Bp <= 0 || (D != 1 && D != 2)) return LOB_E_ARG;
+    if (!P || !Whh || T <= 0 || Bp <= 0 || (D != 1 && D != 2)) return LOB_E_ARG;
+    if (!Y && !Y16) return LOB_E_ARG;
     if (save && !Csave) return LOB_E_ARG;
-    if (Yd && (drop_p < 0.f || drop_p >= 1.f)) return LOB_E_ARG;      // drop_p = 0: plain bf16 copy
+    if (Yd && (drop_p <= 0.f || drop_p >= 1.f)) return LOB_E_ARG;
     if (Hh != 128 || (Bp % 32)) return LOB_E_SHAPE;
-    if ((reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(Whh) |
-         reinterpret_cast<uintptr_t>(Csave)) & 15) return LOB_E_ALIGN;
+    if ((reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(Whh) | reinterpret_cast<uintptr_t>(Csave) |
+         reinterpret_cast<uintptr_t>(Y16) | reinterpret_cast<uintptr_t>(Yd)) & 15) return LOB_E_ALIGN;
     const dim3 grid(Bp / 32, D), block(256);
     hipStream_t s = (hipStream_t)stream;
+    __bf16* y16 = reinterpret_cast<__bf16*>(Y16);
     __bf16* yd = reinterpret_cast<__bf16*>(Yd);
-#define LOB_FWD(SV, DR, PE) hipLaunchKernelGGL((lstm_rec_fwd_h128_bf16_kernel<SV, DR, PE>), grid, block, 0, s, \
-        reinterpret_cast<PE*>(P), Whh, Y, Csave, yd, drop_p, seed, T, Bp)
-    if (pg_bf16) {
-        if (save && yd) LOB_FWD(true, true, __bf16); else if (save) LOB_FWD(true, false, __bf16);
-        else if (yd) LOB_FWD(false, true, __bf16); else LOB_FWD(false, false, __bf16);
-    } else {
-        if (save && yd) LOB_FWD(true, true, float); else if (save) LOB_FWD(true, false, float);
-        else if (yd) LOB_FWD(false, true, float); else LOB_FWD(false, false, float);
-    }
+#define LOB_FWD(SV, YF, Y6, DR, PE) hipLaunchKernelGGL((lstm_rec_fwd_h128_bf16_kernel<SV, YF, Y6, DR, PE>), grid, block, \
+        0, s, reinterpret_cast<PE*>(P), Whh, Y, Csave, y16, yd, drop_p, seed, T, Bp)
+#define LOB_FWD_OUT(SV, PE) do {                                                     \
+        if (Y && !y16 && !yd) LOB_FWD(SV, true, false, false, PE);                   \
+        else if (Y && y16 && !yd) LOB_FWD(SV, true, true, false, PE);                \
+        else if (Y && !y16 && yd) LOB_FWD(SV, true, false, true, PE);                \
+        else if (Y && y16 && yd) LOB_FWD(SV, true, true, true, PE);                  \
+        else if (!Y && y16 && !yd) LOB_FWD(SV, false, true, false, PE);              \
+        else LOB_FWD(SV, false, true, true, PE); } while (0)
+    if (!Y && !y16) return LOB_E_ARG;
+    if (pg_bf16) { if (save) LOB_FWD_OUT(true, __bf16); else LOB_FWD_OUT(false, __bf16); }
+    else         { if (save) LOB_FWD_OUT(true, float); else LOB_FWD_OUT(false, float); }
+#undef LOB_FWD_OUT
 #undef LOB_FWD
     LOB_CHECK_LAUNCH();
     return 0;

@@ -142,28 +142,33 @@ def can_fuse_dropout(H, mixed):
     return bool(mixed) and H == 128
 
 
-def lstm_rec_fwd(P, whh, T, Bp, H, D, save, mixed=False, drop_p=0.0, seed=0, want_bf16=False):
-    """Runs the persistent recurrent kernel; returns (Y[T*Bp, D*H], Csave or None, Yd or None).
-    mixed: h W_hh^T on bf16 MFMA (H == 128), everything else fp32.  drop_p > 0 (only with
-    can_fuse_dropout): also returns Yd = bf16(dropout(Y))."""
+def lstm_rec_fwd(P, whh, T, Bp, H, D, save, mixed=False, drop_p=0.0, seed=0, want_f32=True, want_bf16=False):
+    """Runs the persistent recurrent kernel; returns (Y fp32 or None, Csave or None, Y16 or None, Yd or None).
+    mixed: h W_hh^T on bf16 MFMA (H == 128), everything else fp32.  With can_fuse_dropout: want_bf16 adds
+    Y16 = bf16(Y); drop_p > 0 adds Yd = bf16(dropout(Y)); want_f32=False skips the fp32 Y."""
     p16 = P.dtype == torch.bfloat16
     _chk(P, "P", P.dtype if p16 else torch.float32); _chk(whh, "whh")
     assert whh.shape == (D, 4 * H, H)
-    Y = torch.empty((T * Bp, D * H), device=P.device, dtype=torch.float32)
-    Cs = torch.empty((D * T * Bp * H,), device=P.device, dtype=torch.float32) if save else None
-    Yd = None
+    dev = P.device
+    Cs = torch.empty((D * T * Bp * H,), device=dev, dtype=torch.float32) if save else None
+    Y = Y16 = Yd = None
     if mixed and H == 128:
-        if drop_p > 0 or want_bf16:
-            Yd = torch.empty((T * Bp, D * H), device=P.device, dtype=torch.bfloat16)
-        rc = _lib.lib().lob_lstm_rec_fwd_bf16(_ptr(P), int(p16), _ptr(whh), _ptr(Y), _ptr(Cs), _ptr(Yd),
+        if want_f32 or not want_bf16:
+            Y = torch.empty((T * Bp, D * H), device=dev, dtype=torch.float32)
+        if want_bf16:
+            Y16 = torch.empty((T * Bp, D * H), device=dev, dtype=torch.bfloat16)
+        if drop_p > 0:
+            Yd = torch.empty((T * Bp, D * H), device=dev, dtype=torch.bfloat16)
+        rc = _lib.lib().lob_lstm_rec_fwd_bf16(_ptr(P), int(p16), _ptr(whh), _ptr(Y), _ptr(Cs), _ptr(Y16), _ptr(Yd),
                                               float(drop_p), C.c_uint64(seed), T, Bp, H, D, 1 if save else 0,
                                               _stream())
     else:
-        assert drop_p == 0 and not p16
+        assert drop_p == 0 and not p16 and not want_bf16
+        Y = torch.empty((T * Bp, D * H), device=dev, dtype=torch.float32)
         rc = _lib.lib().lob_lstm_rec_fwd_f32(_ptr(P), _ptr(whh), _ptr(Y), _ptr(Cs), T, Bp, H, D, 1 if save else 0,
                                              _stream())
     _lib.check(rc, "lob_lstm_rec_fwd")
-    return Y, Cs, Yd
+    return Y, Cs, Y16, Yd
 
 
 def layernorm_act(x, gamma, beta, act=ACT_NONE, eps=1e-5, remap=None, drop_p=0.0, seed=0, out=None,

@@ -108,7 +108,7 @@ def test_lstm_layer_vs_oracle(dev, H, D, B):
     bias = torch.from_numpy(np.concatenate([w[2] + w[3] for w in ws], 0)).to(dev)
     for save in (False, True):
         P = ops.gate_gemm_x(torch.from_numpy(xt.reshape(T * Bp, K)).to(dev), wih, bias, T, Bp, H, D, ops.uses_frag(H))
-        Y, Cs, _ = ops.lstm_rec_fwd(P, whh, T, Bp, H, D, save)
+        Y, Cs, _, _ = ops.lstm_rec_fwd(P, whh, T, Bp, H, D, save)
         y = Y.cpu().numpy().reshape(T, Bp, D * H)[:, :B].transpose(1, 0, 2)
         ref = np.concatenate([R.lstm_direction(x.astype(np.float64), *[w.astype(np.float64) for w in ws[d]], d == 1)
                               for d in range(D)], -1)
@@ -587,10 +587,11 @@ def test_fused_dropout_equals_separate_kernels(dev, monkeypatch):
     lu, gu, xu = run()
     # the two pipelines run different GEMM kernels (LDS-DMA vs register-staged: other accumulation order),
     # so equality is to fp32 rounding, not bitwise; a mask mismatch would be an O(1) difference
-    assert abs(lf - lu) < 1e-5
-    assert (xf - xu).abs().max().item() <= 2e-3 * xu.abs().max().item()
+    # (the fused path also rounds h to bf16 BEFORE the 1/(1-p) scaling: one extra bf16 rounding)
+    assert abs(lf - lu) < 1e-4
+    assert (xf - xu).abs().max().item() <= 1e-2 * xu.abs().max().item()
     for k in gf:
-        assert (gf[k] - gu[k]).abs().max().item() <= 2e-3 * max(1e-6, gu[k].abs().max().item()) + 1e-9, k
+        assert (gf[k] - gu[k]).abs().max().item() <= 1e-2 * max(1e-6, gu[k].abs().max().item()) + 1e-9, k
 
 
 @pytest.mark.parametrize("M,N,K", [(4096, 1024, 256), (8192, 256, 1024), (1000, 256, 128), (128, 128, 512)])

@@ -56,11 +56,11 @@ for mixed in (False, True):
                2.0 * rows * N * H, 4.0 * rows * (N + D * H))
     if on(f"rec_fwd_save {tag}") or on(f"rec_bwd {tag}") or on("tn") or on("dX"):
         Pk = P.clone()
-        Y, Cs, _ = ops.lstm_rec_fwd(Pk, whh, T, Bp, H, D, True, mixed=mixed)
+        Y, Cs, _, _ = ops.lstm_rec_fwd(Pk, whh, T, Bp, H, D, True, mixed=mixed)
         if on(f"rec_fwd_save {tag}"):
             report(f"rec_fwd_save {tag} (on gates)", timeit(lambda: ops.lstm_rec_fwd(Pk, whh, T, Bp, H, D, True, mixed=mixed), 3),
                    2.0 * rows * N * H, 4.0 * rows * (2 * N + 2 * D * H))
-            Pk.copy_(P); Y, Cs, _ = ops.lstm_rec_fwd(Pk, whh, T, Bp, H, D, True, mixed=mixed)
+            Pk.copy_(P); Y, Cs, _, _ = ops.lstm_rec_fwd(Pk, whh, T, Bp, H, D, True, mixed=mixed)
         dY = (torch.randn((rows, D * H), generator=g) * 1e-3).to(dev)
         if on(f"rec_bwd {tag}"):
             report(f"rec_bwd {tag}", timeit(lambda: ops.lstm_rec_bwd(Pk, Cs, whh, dY, T, Bp, H, D, dp_bf16=mixed), 3),
