@@ -28,7 +28,7 @@ __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
 
 struct NTArgs {
     const void* A; const float* W; const float* bias; float* C;
-    int lda, ldw, ldc, M, N, K, act, accumulate, dbg;
+    int lda, ldw, ldc, M, N, K, act, accumulate;
     int T, Bp, H, D;     // fragment epilogue
     int out_bf16;                  // fragment epilogue: P stored as bf16
     float drop_p; uint64_t seed;   // row-major epilogue: C *= dropout mask of element (row*ldc + col)
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256, TKT == 32 ? 3 : 2) void gemm_nt_bf16_kernel(NT
         __syncthreads();
         int buf = 0;
         for (int kt = 0; kt < nk; ++kt) {
-            if (kt + 1 < nk && !(g.dbg & 2)) load(m0, n0, (kt + 1) * TKT);
+            if (kt + 1 < nk) load(m0, n0, (kt + 1) * TKT);
             mma_tile<TKT>(As + buf * TM * LD, Ws + buf * TM * LD, wr, wc, lane, acc);
             if (kt + 1 < nk) store(buf ^ 1);
             __syncthreads();
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256, TKT == 32 ? 3 : 2) void gemm_nt_bf16_kernel(NT
             m0 = ((nit / ntn) * 8 + xcd) * TM; n0 = (nit % ntn) * TN_;
             load(m0, n0, 0);
         }
-        if (!(g.dbg & 1)) {
+        {
             if (EPI == 0) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -222,8 +222,6 @@ __global__ __launch_bounds__(256, TKT == 32 ? 3 : 2) void gemm_nt_bf16_kernel(NT
                     }
                 }
             }
-        } else if (acc[0][0][0] + acc[1][1][5] == 12345.678f) {
-            g.C[0] = 1.f;     // timing experiments: keep the accumulators alive
         }
         if (!more) break;
         it = nit;
@@ -545,6 +543,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(TNArgs g) {
         }
 }
 
+
 __global__ __launch_bounds__(256) void colsum_bf16_kernel(const __bf16* __restrict__ A, int lda, int M, int N,
                                                           int rows_per_block, float* __restrict__ out) {
     __shared__ float red[4][64];
@@ -562,11 +561,6 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const __bf16* __restri
 }
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-
-inline int dbg_flags() {
-    static const int v = [] { const char* e = getenv("LOB_DBG"); return e ? atoi(e) : 0; }();
-    return v;
-}
 
 // persistent grid of the NT kernel: one resident wave of workgroups (multiple of 8 for the XCD map)
 inline int nt_grid(int M, int N) {
@@ -605,7 +599,7 @@ extern "C" int lob_gemm_nt_bf16(const void* A, int a_bf16, int lda, const void* 
     if ((act & 0xff) > LOB_ACT_GELU || act < 0) return LOB_E_ARG;
     if (!al16(A) || !al16(W) || (K % 8) || (lda % 8) || (ldw % 4)) return LOB_E_ALIGN;
     NTArgs g{A, reinterpret_cast<const float*>(W), bias, C, lda, ldw, ldc, M, N, K, act & 0xff, (act >> 8) & 1,
-             dbg_flags(), 0, 0, 0, 0, 0, drop_p, seed};
+             0, 0, 0, 0, 0, drop_p, seed};
     if (drop_p < 0.f || drop_p >= 1.f) return LOB_E_ARG;
     if (w_bf16) {      // both operands bf16 in HBM: LDS-DMA kernel (no bias / activation in its row-major epilogue)
         if (!a_bf16 || bias || act || (K % DTK) || K / DTK < DS || (ldw % 8)) return LOB_E_SHAPE;
@@ -634,7 +628,7 @@ extern "C" int lob_gate_gemm_x_bf16(const void* X, int x_bf16, int ldx, const vo
     if (!al16(X) || !al16(Wih) || !al16(P) || (K % 8) || (ldx % 8)) return LOB_E_ALIGN;
     const int N = D * 4 * H, M = T * Bp;
     NTArgs g{X, reinterpret_cast<const float*>(Wih), bias, reinterpret_cast<float*>(P), ldx, K, N, M, N, K, LOB_ACT_NONE, 0,
-             dbg_flags(), T, Bp, H, D, p_bf16, 0.f, 0};
+             T, Bp, H, D, p_bf16, 0.f, 0};
     if (w_bf16) {
         if (!x_bf16 || (K % DTK) || K / DTK < DS || N > 2048 || (N % 128) || (M % 128)) return LOB_E_SHAPE;
         hipLaunchKernelGGL((gemm_nt_dma_kernel<1>), dim3((unsigned)nt_dma_grid(M, N)), dim3(256), 0,
@@ -671,6 +665,8 @@ extern "C" int lob_gemm_tn_bf16(const void* A, int a_bf16, int lda, const void* 
     TNArgs g{A, B, C, lda, ldb, ldc, M, N, Kc, kchunk, tiles};
     const dim3 grid((unsigned)(tiles * nchunk8)), block(256);
     hipStream_t s = (hipStream_t)stream;
+    // (an LDS-DMA ring variant of this kernel was measured 12-20 % SLOWER: 64 KB of ring halves the
+    //  resident workgroups, and this kernel already keeps 4 workgroups x 1 k-tile in flight per CU)
     if (a_bf16 && b_bf16)       hipLaunchKernelGGL((gemm_tn_bf16_kernel<true, true>), grid, block, 0, s, g);
     else if (a_bf16)            hipLaunchKernelGGL((gemm_tn_bf16_kernel<true, false>), grid, block, 0, s, g);
     else if (b_bf16)            hipLaunchKernelGGL((gemm_tn_bf16_kernel<false, true>), grid, block, 0, s, g);

@@ -97,3 +97,12 @@ if on("dma"):
         for wdt, nm in ((torch.float32, "regstage"), (torch.bfloat16, "dma")):
             report(f"dX N={Kout} {nm}", timeit(lambda: ops.gemm_nt(dPb, wt.to(wdt), mixed=True)), 2.0 * rows * N * Kout,
                    rows * (2.0 * N + 4.0 * Kout))
+
+if on("tndma"):
+    dPb = torch.randn((rows, N), generator=g).to(dev).to(torch.bfloat16)
+    xb = torch.randn((rows, 256), generator=g).to(dev).to(torch.bfloat16)
+    dw = torch.zeros((N, 256), device=dev)
+    report("tn dWih bf16xbf16", timeit(lambda: ops.gemm_tn(dPb, xb, dw)), 2.0 * rows * N * 256, 2.0 * rows * (N + 256))
+    dwh = torch.zeros((512, 128), device=dev)
+    report("tn dWhh bf16xbf16", timeit(lambda: ops.gemm_tn(dPb[Bp:, :512], xb[:rows - Bp, :128], dwh)),
+           2.0 * rows * 512 * 128, 2.0 * rows * (512 + 128))
