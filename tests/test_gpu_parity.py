@@ -628,3 +628,61 @@ def test_gate_gemm_lds_dma_fragment_layout(dev):
         assert p_reg.dtype == p_dma.dtype == (torch.bfloat16 if pg else torch.float32)
         # the fp32 weights are rounded to bf16 inside the register-staged kernel: same products
         assert (p_reg.float() - p_dma.float()).abs().max().item() < (2e-2 if pg else 1e-5)
+
+
+# ------------------------------------------------------------------------------------------
+# BASELINE.json full sizes: size-independent properties (the oracle cannot run these in seconds)
+# ------------------------------------------------------------------------------------------
+def test_full_size_b4096_properties(dev):
+    """B = 4096 (configs[2] size), fp32 path: window independence, attention normalisation, oracle on a
+    sample, gradient additivity over the batch (sum-reduced loss), and the mixed path within tolerance."""
+    from oracle import torch_cpu_path as TP
+    B = 4096
+    sd = syn.make_state_dict(61, 128, 3, 2, True)
+    x, y = syn.make_windows(B)
+    m = _model(sd, 61, 128, 3, True, dev)
+    xt, yt = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+    with torch.no_grad():
+        logits, attn = m(xt, return_attention=True)
+        sub = torch.cat([xt[:40], xt[-24:]])
+        l_sub = m(sub)
+    assert torch.isfinite(logits).all() and logits.shape == (B, 2)
+    assert (attn.sum(1) - 1).abs().max().item() < 2e-6 and attn.min().item() >= 0
+    assert (l_sub - torch.cat([logits[:40], logits[-24:]])).abs().max().item() < 1e-6      # independence
+    idx = np.r_[0:8, 2044:2052, B - 8:B]
+    ref = TP.build(sd, 61, 128)
+    with torch.no_grad():
+        rl, ra = ref(torch.from_numpy(x[idx]), return_attention=True)
+    assert np.abs(logits.cpu().numpy()[idx] - rl.numpy()).max() < TOL
+    assert np.abs(attn.cpu().numpy()[idx] - ra.numpy()).max() < TOL
+
+    def grads(xs, ys):
+        m.zero_grad(set_to_none=True)
+        torch.nn.functional.cross_entropy(m(xs), ys, reduction="sum").backward()
+        return {k: p.grad.clone() for k, p in m.named_parameters()}
+    g_all = grads(xt, yt)
+    g_a, g_b = grads(xt[:1504], yt[:1504]), grads(xt[1504:], yt[1504:])        # ragged split
+    for k in g_all:
+        ref_ = g_a[k] + g_b[k]
+        assert (g_all[k] - ref_).abs().max().item() <= 3e-4 * ref_.abs().max().item() + 1e-7, k
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        lm = m(xt)
+    assert (lm - logits).abs().max().item() < 5e-3
+
+
+def test_full_size_coupled_b65536_properties(dev):
+    """Global batch of configs[4] through the ODE stage on one device: conservation, bounds, decision rule,
+    and agreement with the closed form on a sample."""
+    from lstm_ode_bci_amd import ops
+    from oracle import restatement as R
+    probs_np = syn.make_probs(65536)
+    probs = torch.from_numpy(probs_np).to(dev)
+    rates = [syn.FITTED_RATES[k] for k in syn.RATE_KEYS]
+    traj, final, pred = ops.ode_rk4(rates, 300, 0.0, 300.0, 16, probs=probs, alpha=1.0, want_final=True)
+    assert traj.shape == (65536, 300, 3)
+    assert (traj.sum(2) - 1).abs().max().item() < 1e-12 and traj.min().item() >= 0 and traj.max().item() <= 1
+    assert torch.equal(final, traj[:, -1]) and torch.equal(pred, (traj[:, -1, 2] > 0.5).long())
+    for i in (0, 777, 65535):
+        mp = R.modulate_rates(syn.FITTED_RATES, 1.0, probs_np[i, 1], probs_np[i, 0])
+        _, te = R.solve_expm(R.initial_state_rule(probs_np[i, 1], probs_np[i, 0]), (0, 300), 300, mp)
+        assert np.abs(traj[i].cpu().numpy() - te).max() < 1e-6
