@@ -87,7 +87,7 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad):
         # producer, its backward (the same mask) is fused into this GEMM's epilogue
         below_fused = layer > 0 and sv["layers"][layer - 1]["fused_drop"]
         wt = _t(wih)
-        if dP.dtype == torch.bfloat16 and ops.dma_ok(dP.shape[1]):
+        if dP.dtype == torch.bfloat16 and ops.dma_ok(dP.shape[1], wt.shape[0], dP.shape[0]):
             wt = wt.to(torch.bfloat16)                # bf16 x bf16 -> LDS-DMA kernel
         dY = ops.gemm_nt(dP, wt, mixed=mixed, drop_p=p_lstm if below_fused else 0.0,
                          seed=_seed(seed, 10 + layer - 1))

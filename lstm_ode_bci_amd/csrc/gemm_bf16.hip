@@ -244,7 +244,6 @@ __global__ __launch_bounds__(256, TKT == 32 ? 3 : 2) void gemm_nt_bf16_kernel(NT
 // ------------------------------------------------------------------------------------------
 constexpr int DS = 4;            // ring slots
 constexpr int DTK = 32;          // k per slot
-constexpr int DSLOT = 128 * DTK; // bf16 elements per operand per slot
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_cvoid;
@@ -259,16 +258,26 @@ __device__ __forceinline__ void dma_rows16(const __bf16* G, int ld, int row0, in
     __builtin_amdgcn_global_load_lds((gbl_cvoid*)src, (lds_void*)lds_rows, 16, 0, 0);
 }
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(NTArgs g) {
-    __shared__ __attribute__((aligned(1024))) __bf16 ring[DS * 2 * DSLOT + 4096];     // 64 KB ring + 8 KB bias
-    float* bias_s = reinterpret_cast<float*>(ring + DS * 2 * DSLOT);
+// Output tile BTM x BTN per workgroup, one wave per 64x64 block of it (4 waves at 128x128, 16 at
+// 256x256).  The bigger tile halves the bytes that cross the L2 -> LDS path per FLOP (every operand
+// tile is re-read once per tile of the OTHER dimension) -- at 128x128 that path carried 3x the
+// algorithmic bytes and, not HBM, set the rate.
+template <int EPI, int BTM, int BTN>
+__global__ __launch_bounds__((BTM / 64) * (BTN / 64) * 64, (BTM * BTN > 128 * 128) ? 4 : 2)
+void gemm_nt_dma_kernel(NTArgs g) {
+    constexpr int WR = BTM / 64, WC = BTN / 64, NWV = WR * WC, NTHR = NWV * 64;
+    constexpr int NA = BTM / 16 / NWV, NB = BTN / 16 / NWV;      // 1-KB DMA instructions per wave per k-tile
+    constexpr int ASLOT = BTM * DTK, WSLOT = BTN * DTK, SLOT = ASLOT + WSLOT;
+    constexpr int VM_STEADY = (DS - 2) * (NA + NB), VM_EPI = VM_STEADY + 16;
+    static_assert(NA >= 1 && NB >= 1 && VM_EPI < 64, "tile / wave configuration");
+    __shared__ __attribute__((aligned(1024))) __bf16 ring[DS * SLOT + 4096];     // ring + 8 KB bias
+    float* bias_s = reinterpret_cast<float*>(ring + DS * SLOT);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WC, wc = wave % WC;
     const __bf16* A = reinterpret_cast<const __bf16*>(g.A);
     const __bf16* W = reinterpret_cast<const __bf16*>(g.W);
-    const int ntn = (g.N + TN_ - 1) / TN_, ntm = (g.M + TM - 1) / TM;
+    const int ntn = (g.N + BTN - 1) / BTN, ntm = (g.M + BTM - 1) / BTM;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
     const int panels = (ntm - xcd + 7) / 8, ntile = panels * ntn;
     const int nk = g.K / DTK;
@@ -276,20 +285,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(NTArgs g) {
     const int my_tiles = (ntile - slot + nslot - 1) / nslot;
     const int total = my_tiles * nk;
     if (EPI == 1) {       // bias via LDS: an ordinary global load inside the loop would make hipcc drain the DMA queue
-        for (int i = tid; i < g.N && i < 2048; i += 256) bias_s[i] = g.bias ? g.bias[i] : 0.f;
+        for (int i = tid; i < g.N && i < 2048; i += NTHR) bias_s[i] = g.bias ? g.bias[i] : 0.f;
         __syncthreads();
     }
 
     // producer cursor (runs DS-1 k-tiles ahead of the consumer, across tile boundaries)
     int p_q = 0, p_it = slot, p_kt = 0;
     auto issue = [&]() {
-        const int m0 = ((p_it / ntn) * 8 + xcd) * TM, n0 = (p_it % ntn) * TN_;
-        __bf16* as = ring + (p_q % DS) * 2 * DSLOT;
-        __bf16* ws = as + DSLOT;
+        const int m0 = ((p_it / ntn) * 8 + xcd) * BTM, n0 = (p_it % ntn) * BTN;
+        __bf16* as = ring + (p_q % DS) * SLOT;
+        __bf16* ws = as + ASLOT;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int rb = (wave * 2 + j) * 16;
+        for (int j = 0; j < NA; ++j) {
+            const int rb = (wave * NA + j) * 16;
             dma_rows16(A, g.lda, m0 + rb, g.M, p_kt * DTK, as + rb * DTK, lane);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int rb = (wave * NB + j) * 16;
             dma_rows16(W, g.ldw, n0 + rb, g.N, p_kt * DTK, ws + rb * DTK, lane);
         }
         ++p_q;
@@ -309,22 +322,22 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(NTArgs g) {
 
     for (int q = 0; q < total; ++q) {
         // ---- wait for slot q: all but the younger operations of THIS wave may still be in flight:
-        //      (DS-2) k-tiles x 4 DMAs, plus the 16 epilogue stores if they were issued after DMA(q)
+        //      (DS-2) k-tiles x (NA+NB) DMAs, plus the 16 epilogue stores if they were issued after DMA(q)
         if (q + DS - 1 > total) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else if (EPI == 1 && since_epi < DS - 1) {
-            asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_EPI) : "memory");
         } else if (since_epi < DS - 1) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_STEADY) : "memory");
         }
         __builtin_amdgcn_s_barrier();
         if (p_q < total) issue();                       // refills the slot read in iteration q-1
         ++since_epi;
 
-        const __bf16* as = ring + (q % DS) * 2 * DSLOT;
-        const __bf16* ws = as + DSLOT;
+        const __bf16* as = ring + (q % DS) * SLOT;
+        const __bf16* ws = as + ASLOT;
         const int r31 = lane & 31, hi = lane >> 5, sw = (r31 >> 2) & 3;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -342,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(NTArgs g) {
 
         // ---- epilogue of tile `it`
         kt = 0;
-        const int cm0 = ((it / ntn) * 8 + xcd) * TM, cn0 = (it % ntn) * TN_;
+        const int cm0 = ((it / ntn) * 8 + xcd) * BTM, cn0 = (it % ntn) * BTN;
         it += nslot;
         since_epi = 0;
         if (EPI == 0) {
@@ -351,18 +364,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(NTArgs g) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int col = cn0 + 64 * wc + 32 * j + (lane & 31);
-                    if (col < g.N) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int row = cm0 + 64 * wr + 32 * i + acc_row(r, lane);
-                            if (row < g.M) {
-                                float* dst = g.C + (size_t)row * g.ldc + col;
-                                float val = acc[i][j][r];
-                                if (g.drop_p > 0.f) val *= lob_dropout_scale(g.seed, (uint64_t)row * g.ldc + col, g.drop_p);
-                                *dst = val;      // no accumulate here: a read-modify-write would drain the DMA queue
-                            }
-                            acc[i][j][r] = 0.f;
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = cm0 + 64 * wr + 32 * i + acc_row(r, lane);
+                        if (row < g.M && col < g.N) {
+                            float* dst = g.C + (size_t)row * g.ldc + col;
+                            float val = acc[i][j][r];
+                            if (g.drop_p > 0.f) val *= lob_dropout_scale(g.seed, (uint64_t)row * g.ldc + col, g.drop_p);
+                            *dst = val;      // no accumulate here: a read-modify-write would drain the DMA queue
                         }
+                        acc[i][j][r] = 0.f;
                     }
                 }
         } else {
@@ -584,11 +595,31 @@ inline bool nt_dma_enabled() {
     static const bool v = [] { const char* e = getenv("LOB_NT_DMA"); return !(e && atoi(e) == 0); }();
     return v;
 }
-inline int nt_dma_grid(int M, int N) {
-    const long tiles = (long)((M + TM - 1) / TM) * ((N + TN_ - 1) / TN_);
-    long gsz = 256L * 2;
+inline int nt_dma_tile() {      // output tile edge of the LDS-DMA kernel (tuning knob; LOB_DMA_TILE=128|256)
+    static const int v = [] { const char* e = getenv("LOB_DMA_TILE"); return (e && atoi(e) == 128) ? 128 : 256; }();
+    return v;
+}
+inline int nt_dma_grid(int M, int N, int tile) {
+    const long tiles = (long)((M + tile - 1) / tile) * ((N + tile - 1) / tile);
+    long gsz = 256L * (tile == 128 ? 2 : 1);
     if (gsz > tiles) gsz = ((tiles + 7) / 8) * 8;
     return (int)gsz;
+}
+inline int nt_dma_grid2(int M, int N) {     // 256 x 128 tiles, one workgroup per CU
+    const long tiles = (long)((M + 255) / 256) * ((N + 127) / 128);
+    long gsz = 256L;
+    if (gsz > tiles) gsz = ((tiles + 7) / 8) * 8;
+    return (int)gsz;
+}
+template <int EPI>
+inline void launch_nt_dma(const NTArgs& g, hipStream_t s) {
+    // 256x256 tiles need the whole tile inside the matrix only along N (rows are clamped/guarded)
+    if (nt_dma_tile() == 256 && g.N % 256 == 0)
+        hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI, 256, 256>), dim3((unsigned)nt_dma_grid(g.M, g.N, 256)), dim3(1024), 0, s, g);
+    else if (nt_dma_tile() == 256)     // N = 128 (dX of layer 0): 256 x 128 tiles, 8 waves
+        hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI, 256, 128>), dim3((unsigned)nt_dma_grid2(g.M, g.N)), dim3(512), 0, s, g);
+    else
+        hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI, 128, 128>), dim3((unsigned)nt_dma_grid(g.M, g.N, 128)), dim3(256), 0, s, g);
 }
 
 extern "C" int lob_gemm_nt_bf16(const void* A, int a_bf16, int lda, const void* W, int w_bf16, int ldw,
@@ -603,8 +634,7 @@ extern "C" int lob_gemm_nt_bf16(const void* A, int a_bf16, int lda, const void* 
     if (drop_p < 0.f || drop_p >= 1.f) return LOB_E_ARG;
     if (w_bf16) {      // both operands bf16 in HBM: LDS-DMA kernel (no bias / activation in its row-major epilogue)
         if (!a_bf16 || bias || act || (K % DTK) || K / DTK < DS || (ldw % 8)) return LOB_E_SHAPE;
-        hipLaunchKernelGGL((gemm_nt_dma_kernel<0>), dim3((unsigned)nt_dma_grid(M, N)), dim3(256), 0,
-                           (hipStream_t)stream, g);
+        launch_nt_dma<0>(g, (hipStream_t)stream);
         LOB_CHECK_LAUNCH();
         return 0;
     }
@@ -630,9 +660,8 @@ extern "C" int lob_gate_gemm_x_bf16(const void* X, int x_bf16, int ldx, const vo
     NTArgs g{X, reinterpret_cast<const float*>(Wih), bias, reinterpret_cast<float*>(P), ldx, K, N, M, N, K, LOB_ACT_NONE, 0,
              T, Bp, H, D, p_bf16, 0.f, 0};
     if (w_bf16) {
-        if (!x_bf16 || (K % DTK) || K / DTK < DS || N > 2048 || (N % 128) || (M % 128)) return LOB_E_SHAPE;
-        hipLaunchKernelGGL((gemm_nt_dma_kernel<1>), dim3((unsigned)nt_dma_grid(M, N)), dim3(256), 0,
-                           (hipStream_t)stream, g);
+        if (!x_bf16 || (K % DTK) || K / DTK < DS || N > 2048 || (N % 128) || (M % 256)) return LOB_E_SHAPE;
+        launch_nt_dma<1>(g, (hipStream_t)stream);
         LOB_CHECK_LAUNCH();
         return 0;
     }

@@ -100,9 +100,9 @@ def gemm_tn(a, b, out, mixed=False):
 NT_DMA = True
 
 
-def dma_ok(K, N=128, M=128):
+def dma_ok(K, N, M):
     """Shapes the LDS-DMA NT GEMM accepts (K = contraction, N = output columns, M = rows)."""
-    return NT_DMA and K % 32 == 0 and K >= 128 and N % 128 == 0 and N <= 2048 and M % 128 == 0
+    return NT_DMA and K % 32 == 0 and K >= 128 and N % 128 == 0 and N <= 2048 and M % 256 == 0
 
 
 #: mixed mode, H == 128: store the fragment-order pre-activations / saved gates as bf16 (half the HBM
