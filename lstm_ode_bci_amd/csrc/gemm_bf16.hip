@@ -555,6 +555,116 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(TNArgs g) {
 }
 
 
+
+// ------------------------------------------------------------------------------------------
+// LDS-DMA variant of the TN (weight-gradient) GEMM for bf16 sources, BTM x BTN output tiles (256 x 256
+// with 16 waves, 256 x 128 with 8).  The [k][cols] source tiles need no transformation on their way into
+// LDS (ds_read_b64_tr_b16 transposes on the read side), so they are DMA'd: 4-slot ring, three k-tiles in
+// flight, counted vmcnt, raw barrier; no stores until the final atomics.  (At 128 x 128 this variant was
+// 12-20 % slower than the register-staged kernel -- half the resident workgroups; the big tile halves the
+// operand re-reads instead.)  Rows are unpadded: the 64-B granule of k-row k is XOR-ed with (k & 3), on
+// the DMA source address and on the tr-read address, which spreads the four k-rows of a tr block over the
+// 256-B bank row exactly like the +64-B row pad of the register-staged kernel.
+// ------------------------------------------------------------------------------------------
+template <int COLS>
+__device__ __forceinline__ void dma_krows(const __bf16* G, int ld, int k0, int krow0, int c0, __bf16* lds_rows, int lane) {
+    // one wave-instruction = 1 KB = (512 / COLS) k-rows of COLS bf16
+    constexpr int CPR = COLS / 8;                       // 16-B chunks per row
+    const int kr = krow0 + lane / CPR, ch = lane % CPR;
+    const __bf16* src = G + (size_t)(k0 + kr) * ld + c0 + ((ch ^ ((kr & 3) << 2)) * 8);
+    __builtin_amdgcn_global_load_lds((gbl_cvoid*)src, (lds_void*)lds_rows, 16, 0, 0);
+}
+
+template <int COLS>
+__device__ __forceinline__ bf16x8 tr_frag_sw(const __bf16* S, int cb, int s, int lane) {
+    const int h = lane >> 5, mh = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
+    const __bf16* a = S + (16 * s + 8 * h + q) * COLS + ((cb + 16 * mh + 4 * p) ^ (q * 32));
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a + 4 * COLS));
+    bf16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return f;
+}
+
+template <int BTM, int BTN>
+__global__ __launch_bounds__((BTM / 64) * (BTN / 64) * 64, (BTM / 64) * (BTN / 64) / 4) void gemm_tn_dma_kernel(TNArgs g) {
+    constexpr int WC = BTN / 64, NWV = (BTM / 64) * WC;
+    constexpr int ASLOT = 32 * BTM, BSLOT = 32 * BTN, SLOT = ASLOT + BSLOT;
+    constexpr int RPA = 512 / BTM, RPB = 512 / BTN;                  // k-rows per DMA instruction
+    constexpr int NA = 32 / RPA / NWV, NB = 32 / RPB / NWV;          // DMA instructions per wave per k-tile
+    static_assert(NA >= 1 && NB >= 1, "tile / wave configuration");
+    constexpr int VM_STEADY = (DS - 2) * (NA + NB);
+    __shared__ __attribute__((aligned(1024))) __bf16 ring[DS * SLOT];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WC, wc = wave % WC;
+    const __bf16* A = reinterpret_cast<const __bf16*>(g.A);
+    const __bf16* B = reinterpret_cast<const __bf16*>(g.B);
+    const int ntn = g.N / BTN;
+    const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+    const int tile = rest % g.tiles, chunk = (rest / g.tiles) * 8 + xcd;
+    const int m0 = (tile / ntn) * BTM, n0 = (tile % ntn) * BTN;
+    const int kbeg = chunk * g.kchunk, kend = min(g.Kc, kbeg + g.kchunk);
+    if (kbeg >= kend) return;
+    const int total = (kend - kbeg) / 32;
+
+    int p_q = 0;
+    auto issue = [&]() {
+        __bf16* as = ring + (p_q % DS) * SLOT;
+        __bf16* bs = as + ASLOT;
+        const int k0 = kbeg + p_q * 32;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int kr0 = (wave * NA + j) * RPA;
+            dma_krows<BTM>(A, g.lda, k0, kr0, m0, as + kr0 * BTM, lane);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int kr0 = (wave * NB + j) * RPB;
+            dma_krows<BTN>(B, g.ldb, k0, kr0, n0, bs + kr0 * BTN, lane);
+        }
+        ++p_q;
+    };
+#pragma unroll 1
+    for (int i = 0; i < DS - 1 && i < total; ++i) issue();
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int q = 0; q < total; ++q) {
+        if (q + DS - 1 > total) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_STEADY) : "memory");
+        __builtin_amdgcn_s_barrier();
+        if (p_q < total) issue();
+        const __bf16* as = ring + (q % DS) * SLOT;
+        const __bf16* bs = as + ASLOT;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const bf16x8 a0 = tr_frag_sw<BTM>(as, 64 * wr, s, lane), a1 = tr_frag_sw<BTM>(as, 64 * wr + 32, s, lane);
+            const bf16x8 b0 = tr_frag_sw<BTN>(bs, 64 * wc, s, lane), b1 = tr_frag_sw<BTN>(bs, 64 * wc + 32, s, lane);
+            acc[0][0] = mfma_bf16(a0, b0, acc[0][0]);
+            acc[0][1] = mfma_bf16(a0, b1, acc[0][1]);
+            acc[1][0] = mfma_bf16(a1, b0, acc[1][0]);
+            acc[1][1] = mfma_bf16(a1, b1, acc[1][1]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + 64 * wc + 32 * j + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + 64 * wr + 32 * i + acc_row(r, lane);
+                atomicAdd(g.C + (size_t)row * g.ldc + col, acc[i][j][r]);
+            }
+        }
+}
+
 __global__ __launch_bounds__(256) void colsum_bf16_kernel(const __bf16* __restrict__ A, int lda, int M, int N,
                                                           int rows_per_block, float* __restrict__ out) {
     __shared__ float red[4][64];
@@ -684,22 +794,28 @@ extern "C" int lob_gemm_tn_bf16(const void* A, int a_bf16, int lda, const void* 
     // 16-byte vector loads along the column index of both sources
     const int am = a_bf16 ? 8 : 4, bm = b_bf16 ? 8 : 4;
     if ((M % am) || (lda % am) || (N % bm) || (ldb % bm) || !al16(A) || !al16(B)) return LOB_E_ALIGN;
-    const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
-    int nchunk = (2048 + tiles - 1) / tiles;
+    hipStream_t s = (hipStream_t)stream;
+    // big-tile LDS-DMA kernel: both sources bf16, output a multiple of 256 x 256, contraction a multiple of 32
+    // (measured: 0.93 vs 1.02 ms on dW_ih 1024 x 256; on 256 x 128 tiles it LOSES to the register-staged kernel,
+    //  0.33 vs 0.30 ms on dW_hh, so those shapes stay there)
+    const bool dma = a_bf16 && b_bf16 && nt_dma_enabled() && M % 256 == 0 && N % 256 == 0 && Kc % 32 == 0;
+    const int tm = dma ? 256 : 128, tn = dma ? 256 : 128;
+    const int tiles = ((M + tm - 1) / tm) * ((N + tn - 1) / tn);
+    const int target = dma ? 256 : 2048;                  // workgroups: one per CU for the big tiles (fewer, larger
+                                                          // partial sums = fewer atomics), 8 per CU otherwise
+    int nchunk = (target + tiles - 1) / tiles;
     int kchunk = (Kc + nchunk - 1) / nchunk;
     kchunk = ((kchunk + TK2 - 1) / TK2) * TK2;
     if (kchunk < 512) kchunk = 512;
     nchunk = (Kc + kchunk - 1) / kchunk;
     const int nchunk8 = ((nchunk + 7) / 8) * 8;
     TNArgs g{A, B, C, lda, ldb, ldc, M, N, Kc, kchunk, tiles};
-    const dim3 grid((unsigned)(tiles * nchunk8)), block(256);
-    hipStream_t s = (hipStream_t)stream;
-    // (an LDS-DMA ring variant of this kernel was measured 12-20 % SLOWER: 64 KB of ring halves the
-    //  resident workgroups, and this kernel already keeps 4 workgroups x 1 k-tile in flight per CU)
-    if (a_bf16 && b_bf16)       hipLaunchKernelGGL((gemm_tn_bf16_kernel<true, true>), grid, block, 0, s, g);
-    else if (a_bf16)            hipLaunchKernelGGL((gemm_tn_bf16_kernel<true, false>), grid, block, 0, s, g);
-    else if (b_bf16)            hipLaunchKernelGGL((gemm_tn_bf16_kernel<false, true>), grid, block, 0, s, g);
-    else                        hipLaunchKernelGGL((gemm_tn_bf16_kernel<false, false>), grid, block, 0, s, g);
+    const dim3 grid((unsigned)(tiles * nchunk8));
+    if (dma)                    hipLaunchKernelGGL((gemm_tn_dma_kernel<256, 256>), grid, dim3(1024), 0, s, g);
+    else if (a_bf16 && b_bf16)  hipLaunchKernelGGL((gemm_tn_bf16_kernel<true, true>), grid, dim3(256), 0, s, g);
+    else if (a_bf16)            hipLaunchKernelGGL((gemm_tn_bf16_kernel<true, false>), grid, dim3(256), 0, s, g);
+    else if (b_bf16)            hipLaunchKernelGGL((gemm_tn_bf16_kernel<false, true>), grid, dim3(256), 0, s, g);
+    else                        hipLaunchKernelGGL((gemm_tn_bf16_kernel<false, false>), grid, dim3(256), 0, s, g);
     LOB_CHECK_LAUNCH();
     return 0;
 }
