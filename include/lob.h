@@ -156,14 +156,20 @@ int lob_act_bwd_f32(const float* dy, const float* pre, float* dx, int64_t n, int
 int lob_layernorm_act_bwd_f32(const float* x, const float* gamma, const float* beta, const float* dy,
                               float* dx, float* dgamma, float* dbeta, int rows, int width, float eps,
                               int act, int remap_T, int remap_B, int remap_Bp, float drop_p,
-                              uint64_t seed, void* stream);
+                              uint64_t seed, const float* pool_attn, const float* pool_dctx,
+                              int pool_T, int pool_B, int pool_Bp, void* stream);
+/*   pool_attn != NULL (time-major rows, widths 128/256/512): dy[t*Bp+b][:] += pool_attn[b][t] * pool_dctx[b][:]
+ *   before the LayerNorm backward -- the context path of the attention pooling, fused here instead of
+ *   being written to HBM by lob_attn_pool_bwd_f32.                                              */
 
 /* Backward of lob_attn_pool_fwd_f32.  dV [T*Bp][W] and dPreU [T*Bp][W2] are WRITTEN for rows
  * b < B (pad rows untouched); dw2 [W2] is accumulated (atomics).  dPreU is the gradient w.r.t.
  * the pre-tanh hidden W1 v + b1; the caller adds dPreU W1 into dV with lob_gemm_nt_f32.   */
-int lob_attn_pool_bwd_f32(const float* V, const float* U, const float* attn, const float* dctx,
-                          const float* w2, float* dV, float* dPreU, float* dw2,
+int lob_attn_pool_bwd_f32(const void* V, int v_bf16, const float* U, const float* attn, const float* dctx,
+                          const float* w2, float* dV, void* dPreU, int du_bf16, float* dw2,
                           int T, int B, int Bp, int W, int W2, void* stream);
+/*   v_bf16 / du_bf16: V read / dPreU written as bf16 (mixed mode).  dV == NULL: the direct term
+ *   a[t] * dctx is not materialised; pass pool_attn / pool_dctx to lob_layernorm_act_bwd_f32 instead. */
 
 /* ------------------------------------------------------------------------------------
  * Row-wise LayerNorm (biased variance, eps) with affine, optional GELU, optional
@@ -189,7 +195,7 @@ int lob_dropout_f32(const float* in, float* out, int64_t n, float p, uint64_t se
  *   s[t,b] = U[t*Bp+b,:] . w2 + b2   (U = tanh(W1 v + b1), computed by lob_gemm_nt_f32)
  *   a[b,:] = softmax_t(s[:,b]);   ctx[b,:] = sum_t a[b,t] * V[t*Bp+b,:]
  *   V [T*Bp][W], U [T*Bp][W2], attn [B][T], ctx [B][W].                              */
-int lob_attn_pool_fwd_f32(const float* V, const float* U, const float* w2, const float* b2,
+int lob_attn_pool_fwd_f32(const void* V, int v_bf16, const float* U, const float* w2, const float* b2,
                           float* ctx, float* attn, int T, int B, int Bp, int W, int W2,
                           void* stream);
 

@@ -94,8 +94,11 @@ def _forward_impl(x, ps, cfg, save):
     ln_g, ln_b = next(it), next(it)
     a0w, a0b, a2w, a2b = next(it), next(it), next(it), next(it)
     c0w, c0b, c3w, c3b, c6w, c6b = (next(it) for _ in range(6))
-    v = ops.layernorm_act(inp, ln_g, ln_b)                                   # (T*Bp, W)
-    u = ops.gemm_nt(v, a0w, a0b, act=ACT_TANH, mixed=mixed)                  # (T*Bp, W/2)
+    # mixed mode: the normalised sequence v only feeds bf16 MFMA GEMMs and the pooling sums -> bf16
+    v = ops.layernorm_act(inp, ln_g, ln_b, out_bf16=mixed)                   # (T*Bp, W)
+    w1 = a0w.to(torch.bfloat16) if (v.dtype == torch.bfloat16 and
+                                    ops.dma_ok(v.shape[1], a0w.shape[0], v.shape[0])) else a0w
+    u = ops.gemm_nt(v, w1, a0b, act=ACT_TANH, mixed=mixed)                   # (T*Bp, W/2)
     ctx, attn = ops.attn_pool_fwd(v, u, a2w.reshape(-1), a2b, T, B, Bp)
     if save:       # keep the pre-activations of the two classifier GELUs for their backward
         z1p = ops.gemm_nt(ctx, c0w, c0b)

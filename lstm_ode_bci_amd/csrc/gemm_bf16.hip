@@ -284,7 +284,7 @@ void gemm_nt_dma_kernel(NTArgs g) {
     if (slot >= ntile) return;
     const int my_tiles = (ntile - slot + nslot - 1) / nslot;
     const int total = my_tiles * nk;
-    if (EPI == 1) {       // bias via LDS: an ordinary global load inside the loop would make hipcc drain the DMA queue
+    {       // bias via LDS: an ordinary global load inside the loop would make hipcc drain the DMA queue
         for (int i = tid; i < g.N && i < 2048; i += NTHR) bias_s[i] = g.bias ? g.bias[i] : 0.f;
         __syncthreads();
     }
@@ -364,12 +364,13 @@ void gemm_nt_dma_kernel(NTArgs g) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int col = cn0 + 64 * wc + 32 * j + (lane & 31);
+                    const float bv = bias_s[col < 2048 ? col : 0];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = cm0 + 64 * wr + 32 * i + acc_row(r, lane);
                         if (row < g.M && col < g.N) {
                             float* dst = g.C + (size_t)row * g.ldc + col;
-                            float val = acc[i][j][r];
+                            float val = apply_act(acc[i][j][r] + bv, g.act);
                             if (g.drop_p > 0.f) val *= lob_dropout_scale(g.seed, (uint64_t)row * g.ldc + col, g.drop_p);
                             *dst = val;      // no accumulate here: a read-modify-write would drain the DMA queue
                         }
@@ -743,7 +744,7 @@ extern "C" int lob_gemm_nt_bf16(const void* A, int a_bf16, int lda, const void* 
              0, 0, 0, 0, 0, drop_p, seed};
     if (drop_p < 0.f || drop_p >= 1.f) return LOB_E_ARG;
     if (w_bf16) {      // both operands bf16 in HBM: LDS-DMA kernel (no bias / activation in its row-major epilogue)
-        if (!a_bf16 || bias || act || (K % DTK) || K / DTK < DS || (ldw % 8)) return LOB_E_SHAPE;
+        if (!a_bf16 || (act >> 8) || N > 2048 || (K % DTK) || K / DTK < DS || (ldw % 8)) return LOB_E_SHAPE;
         launch_nt_dma<0>(g, (hipStream_t)stream);
         LOB_CHECK_LAUNCH();
         return 0;

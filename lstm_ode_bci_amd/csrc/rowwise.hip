@@ -51,8 +51,9 @@ __global__ __launch_bounds__(256) void layernorm_act_kernel(
 }
 
 // One workgroup per window b.
+template <typename VE>
 __global__ __launch_bounds__(256) void attn_pool_fwd_kernel(
-    const float* __restrict__ V, const float* __restrict__ U, const float* __restrict__ w2,
+    const VE* __restrict__ V, const float* __restrict__ U, const float* __restrict__ w2,
     const float* __restrict__ b2, float* __restrict__ ctx, float* __restrict__ attn,
     int T, int Bp, int W, int W2) {
     extern __shared__ __attribute__((aligned(16))) float sc[];   // [T] scores, then weights
@@ -82,9 +83,9 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_kernel(
     for (int t = tid; t < T; t += 256) { const float a = sc[t] * inv; sc[t] = a; attn[(size_t)b * T + t] = a; }
     __syncthreads();
     for (int c = tid; c < W; c += 256) {
-        const float* v = V + (size_t)b * W + c;
+        const VE* v = V + (size_t)b * W + c;
         float acc = 0.f;
-        for (int t = 0; t < T; ++t) acc = fmaf(sc[t], v[(size_t)t * Bp * W], acc);
+        for (int t = 0; t < T; ++t) acc = fmaf(sc[t], (float)v[(size_t)t * Bp * W], acc);
         ctx[(size_t)b * W + c] = acc;
     }
 }
@@ -284,7 +285,8 @@ template <int VPL>
 __global__ __launch_bounds__(256) void layernorm_act_bwd_vec_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
-    int rows, float eps, int act, int remap_T, int remap_B, int remap_Bp, float drop_p, uint64_t seed) {
+    int rows, float eps, int act, int remap_T, int remap_B, int remap_Bp, float drop_p, uint64_t seed,
+    const float* __restrict__ pool_attn, const float* __restrict__ pool_dctx, int pool_T, int pool_B, int pool_Bp) {
     constexpr int width = 64 * VPL;
     __shared__ float red[2][4][width];
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
@@ -302,6 +304,16 @@ __global__ __launch_bounds__(256) void layernorm_act_bwd_vec_kernel(
         float v[VPL], go[VPL];
         ldv<VPL>(x + (size_t)row * width + lane * VPL, v);
         ldv<VPL>(dy + (size_t)orow * width + lane * VPL, go);
+        if (pool_attn) {     // rows are (t, b) time-major: dy += attn[b][t] * dctx[b][:] (Attention's context path)
+            const int t = row / pool_Bp, b = row % pool_Bp;
+            if (b < pool_B) {
+                const float a = pool_attn[(size_t)b * pool_T + t];
+                float dcv[VPL];
+                ldv<VPL>(pool_dctx + (size_t)b * width + lane * VPL, dcv);
+#pragma unroll
+                for (int i = 0; i < VPL; ++i) go[i] = fmaf(a, dcv[i], go[i]);
+            }
+        }
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) s += v[i];
@@ -343,10 +355,11 @@ __global__ __launch_bounds__(256) void layernorm_act_bwd_vec_kernel(
 //   dV[t,b,:]    = a[t] * dctx[b,:]                      (the W1 path is added by a GEMM afterwards)
 //   ds[t]        = a[t] * (da[t] - sum_t a da),  da[t] = dctx . V[t,b,:]
 //   dPreU[t,b,j] = ds[t] * w2[j] * (1 - U^2);   dw2[j] += sum_t ds[t] U[t,b,j]
+template <typename VE, typename UE>
 __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(
-    const float* __restrict__ V, const float* __restrict__ U, const float* __restrict__ attn,
+    const VE* __restrict__ V, const float* __restrict__ U, const float* __restrict__ attn,
     const float* __restrict__ dctx, const float* __restrict__ w2, float* __restrict__ dV,
-    float* __restrict__ dPreU, float* __restrict__ dw2, int T, int Bp, int W, int W2) {
+    UE* __restrict__ dPreU, float* __restrict__ dw2, int T, int Bp, int W, int W2) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* a = sm;            // [T]
     float* ds = sm + T;       // [T]  (da, then ds)
@@ -357,9 +370,9 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(
     for (int c = tid; c < W; c += 256) dc[c] = dctx[(size_t)b * W + c];
     __syncthreads();
     for (int t = wave; t < T; t += 4) {
-        const float* v = V + ((size_t)t * Bp + b) * W;
+        const VE* v = V + ((size_t)t * Bp + b) * W;
         float s = 0.f;
-        for (int c = lane; c < W; c += 64) s = fmaf(dc[c], v[c], s);
+        for (int c = lane; c < W; c += 64) s = fmaf(dc[c], (float)v[c], s);
         s = wave_sum(s);
         if (lane == 0) ds[t] = s;
     }
@@ -373,20 +386,22 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(
     __syncthreads();
     for (int t = tid; t < T; t += 256) ds[t] = a[t] * (ds[t] - dot);
     __syncthreads();
-    for (int c = tid; c < W; c += 256) {
-        const float g = dc[c];
-        float* o = dV + (size_t)b * W + c;
-        for (int t = 0; t < T; ++t) o[(size_t)t * Bp * W] = a[t] * g;
+    if (dV) {      // (NULL: the caller adds a[t] * dctx inside the LayerNorm backward instead)
+        for (int c = tid; c < W; c += 256) {
+            const float g = dc[c];
+            float* o = dV + (size_t)b * W + c;
+            for (int t = 0; t < T; ++t) o[(size_t)t * Bp * W] = a[t] * g;
+        }
     }
     for (int j = tid; j < W2; j += 256) {
         const float wj = w2[j];
         const float* u = U + (size_t)b * W2 + j;
-        float* o = dPreU + (size_t)b * W2 + j;
+        UE* o = dPreU + (size_t)b * W2 + j;
         float acc = 0.f;
         for (int t = 0; t < T; ++t) {
             const float uv = u[(size_t)t * Bp * W2];
             acc = fmaf(ds[t], uv, acc);
-            o[(size_t)t * Bp * W2] = ds[t] * wj * (1.f - uv * uv);
+            o[(size_t)t * Bp * W2] = (UE)(ds[t] * wj * (1.f - uv * uv));
         }
         atomicAdd(dw2 + j, acc);
     }
@@ -433,13 +448,17 @@ extern "C" int lob_layernorm_act_f32(const float* in, const float* gamma, const 
     return 0;
 }
 
-extern "C" int lob_attn_pool_fwd_f32(const float* V, const float* U, const float* w2, const float* b2,
+extern "C" int lob_attn_pool_fwd_f32(const void* V, int v_bf16, const float* U, const float* w2, const float* b2,
                                      float* ctx, float* attn, int T, int B, int Bp, int W, int W2,
                                      void* stream) {
     if (!V || !U || !w2 || !ctx || !attn || T <= 0 || B <= 0 || Bp < B || W <= 0 || W2 <= 0) return LOB_E_ARG;
     if ((size_t)T * sizeof(float) > 60 * 1024) return LOB_E_SHAPE;
-    hipLaunchKernelGGL(attn_pool_fwd_kernel, dim3(B), dim3(256), (size_t)T * sizeof(float), (hipStream_t)stream,
-                       V, U, w2, b2, ctx, attn, T, Bp, W, W2);
+    if (v_bf16)
+        hipLaunchKernelGGL((attn_pool_fwd_kernel<__bf16>), dim3(B), dim3(256), (size_t)T * sizeof(float), (hipStream_t)stream,
+                           reinterpret_cast<const __bf16*>(V), U, w2, b2, ctx, attn, T, Bp, W, W2);
+    else
+        hipLaunchKernelGGL((attn_pool_fwd_kernel<float>), dim3(B), dim3(256), (size_t)T * sizeof(float), (hipStream_t)stream,
+                           reinterpret_cast<const float*>(V), U, w2, b2, ctx, attn, T, Bp, W, W2);
     LOB_CHECK_LAUNCH();
     return 0;
 }
@@ -473,7 +492,8 @@ extern "C" int lob_act_bwd_f32(const float* dy, const float* pre, float* dx, int
 extern "C" int lob_layernorm_act_bwd_f32(const float* x, const float* gamma, const float* beta, const float* dy,
                                          float* dx, float* dgamma, float* dbeta, int rows, int width, float eps,
                                          int act, int remap_T, int remap_B, int remap_Bp, float drop_p,
-                                         uint64_t seed, void* stream) {
+                                         uint64_t seed, const float* pool_attn, const float* pool_dctx,
+                                         int pool_T, int pool_B, int pool_Bp, void* stream) {
     if (!x || !gamma || !beta || !dy || !dx || !dgamma || !dbeta || rows <= 0 || width <= 0) return LOB_E_ARG;
     if (width > 64 * LN_MAX_PER_LANE) return LOB_E_SHAPE;
     if (drop_p < 0.f || drop_p >= 1.f) return LOB_E_ARG;
@@ -484,12 +504,15 @@ extern "C" int lob_layernorm_act_bwd_f32(const float* x, const float* gamma, con
     if (al && (width == 128 || width == 256 || width == 512)) {
         if (blocks > 256 * 8) blocks = 256 * 8;
 #define LOB_LNB_VEC(V) hipLaunchKernelGGL((layernorm_act_bwd_vec_kernel<V>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, \
-                       x, gamma, beta, dy, dx, dgamma, dbeta, rows, eps, act, remap_T, remap_B, remap_Bp, drop_p, seed)
+                       x, gamma, beta, dy, dx, dgamma, dbeta, rows, eps, act, remap_T, remap_B, remap_Bp, drop_p, seed, \
+                       pool_attn, pool_dctx, pool_T, pool_B, pool_Bp)
+        if (pool_attn && (!pool_dctx || pool_T <= 0 || pool_Bp <= 0 || rows != pool_T * pool_Bp || remap_T)) return LOB_E_SHAPE;
         if (width == 128) LOB_LNB_VEC(2); else if (width == 256) LOB_LNB_VEC(4); else LOB_LNB_VEC(8);
 #undef LOB_LNB_VEC
         LOB_CHECK_LAUNCH();
         return 0;
     }
+    if (pool_attn) return LOB_E_SHAPE;        // the fused pooling term exists on the vectorised path only
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(layernorm_act_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, dy,
                        dx, dgamma, dbeta, rows, width, eps, act, remap_T, remap_B, remap_Bp, drop_p, seed);
@@ -497,15 +520,20 @@ extern "C" int lob_layernorm_act_bwd_f32(const float* x, const float* gamma, con
     return 0;
 }
 
-extern "C" int lob_attn_pool_bwd_f32(const float* V, const float* U, const float* attn, const float* dctx,
-                                     const float* w2, float* dV, float* dPreU, float* dw2,
+extern "C" int lob_attn_pool_bwd_f32(const void* V, int v_bf16, const float* U, const float* attn, const float* dctx,
+                                     const float* w2, float* dV, void* dPreU, int du_bf16, float* dw2,
                                      int T, int B, int Bp, int W, int W2, void* stream) {
-    if (!V || !U || !attn || !dctx || !w2 || !dV || !dPreU || !dw2) return LOB_E_ARG;
+    if (!V || !U || !attn || !dctx || !w2 || !dPreU || !dw2) return LOB_E_ARG;
     if (T <= 0 || B <= 0 || Bp < B || W <= 0 || W2 <= 0) return LOB_E_ARG;
     const size_t smem = ((size_t)2 * T + W) * sizeof(float);
     if (smem > 60 * 1024) return LOB_E_SHAPE;
-    hipLaunchKernelGGL(attn_pool_bwd_kernel, dim3(B), dim3(256), smem, (hipStream_t)stream,
-                       V, U, attn, dctx, w2, dV, dPreU, dw2, T, Bp, W, W2);
+#define LOB_APB(VE, UE) hipLaunchKernelGGL((attn_pool_bwd_kernel<VE, UE>), dim3(B), dim3(256), smem, (hipStream_t)stream, \
+        reinterpret_cast<const VE*>(V), U, attn, dctx, w2, dV, reinterpret_cast<UE*>(dPreU), dw2, T, Bp, W, W2)
+    if (v_bf16 && du_bf16) LOB_APB(__bf16, __bf16);
+    else if (v_bf16) LOB_APB(__bf16, float);
+    else if (du_bf16) LOB_APB(float, __bf16);
+    else LOB_APB(float, float);
+#undef LOB_APB
     LOB_CHECK_LAUNCH();
     return 0;
 }

@@ -206,11 +206,12 @@ def dropout(x, p, seed, out=None):
 
 
 def attn_pool_fwd(v, u, w2, b2, T, B, Bp):
-    _chk(v, "v"); _chk(u, "u"); _chk(w2, "w2"); _chk(b2, "b2")
+    v16 = v.dtype == torch.bfloat16
+    _chk(v, "v", v.dtype if v16 else torch.float32); _chk(u, "u"); _chk(w2, "w2"); _chk(b2, "b2")
     W, W2 = v.shape[1], u.shape[1]
     ctx = torch.empty((B, W), device=v.device, dtype=torch.float32)
     attn = torch.empty((B, T), device=v.device, dtype=torch.float32)
-    rc = _lib.lib().lob_attn_pool_fwd_f32(_ptr(v), _ptr(u), _ptr(w2), _ptr(b2), _ptr(ctx), _ptr(attn),
+    rc = _lib.lib().lob_attn_pool_fwd_f32(_ptr(v), int(v16), _ptr(u), _ptr(w2), _ptr(b2), _ptr(ctx), _ptr(attn),
                                           T, B, Bp, W, W2, _stream())
     _lib.check(rc, "lob_attn_pool_fwd_f32")
     return ctx, attn
@@ -305,30 +306,34 @@ def act_bwd(dy, pre, kind):
     return dx
 
 
-def layernorm_act_bwd(x, gamma, beta, dy, act=ACT_NONE, eps=1e-5, remap=None, drop_p=0.0, seed=0):
-    """Returns (dx [rows,width] in INPUT row order, dgamma, dbeta)."""
+def layernorm_act_bwd(x, gamma, beta, dy, act=ACT_NONE, eps=1e-5, remap=None, drop_p=0.0, seed=0, pool=None):
+    """Returns (dx [rows,width] in INPUT row order, dgamma, dbeta).  pool=(attn [B,T], dctx [B,width], T, B, Bp)
+    adds attn[b][t] * dctx[b] to dy on the fly (context path of the attention pooling)."""
     _chk(x, "x"); _chk(gamma, "gamma"); _chk(beta, "beta"); _chk(dy, "dy")
     rows, width = x.shape
     rT, rB, rBp = (0, 0, 0) if remap is None else remap
     dx = torch.empty_like(x)
     dg = torch.zeros_like(gamma)
     db = torch.zeros_like(beta)
+    pa, pd, pT, pB, pBp = (None, None, 0, 0, 0) if pool is None else pool
     rc = _lib.lib().lob_layernorm_act_bwd_f32(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(dy), _ptr(dx), _ptr(dg), _ptr(db),
                                               rows, width, eps, act, rT, rB, rBp, float(drop_p), C.c_uint64(seed),
-                                              _stream())
+                                              _ptr(pa), _ptr(pd), pT, pB, pBp, _stream())
     _lib.check(rc, "lob_layernorm_act_bwd_f32")
     return dx, dg, db
 
 
-def attn_pool_bwd(v, u, attn, dctx, w2, T, B, Bp):
-    """Returns (dV [T*Bp,W], dPreU [T*Bp,W2], dw2 [W2]); pad rows are zero."""
-    _chk(v, "v"); _chk(u, "u"); _chk(attn, "attn"); _chk(dctx, "dctx"); _chk(w2, "w2")
+def attn_pool_bwd(v, u, attn, dctx, w2, T, B, Bp, want_dv=True, du_bf16=False):
+    """Returns (dV [T*Bp,W] fp32 or None, dPreU [T*Bp,W2] fp32|bf16, dw2 [W2]); pad rows are zero.
+    want_dv=False: the direct term a[t]*dctx is left to layernorm_act_bwd(pool=...)."""
+    v16 = v.dtype == torch.bfloat16
+    _chk(v, "v", v.dtype if v16 else torch.float32); _chk(u, "u"); _chk(attn, "attn"); _chk(dctx, "dctx"); _chk(w2, "w2")
     W, W2 = v.shape[1], u.shape[1]
     alloc = torch.zeros if Bp != B else torch.empty
-    dV = alloc((T * Bp, W), device=v.device, dtype=torch.float32)
-    dU = alloc((T * Bp, W2), device=v.device, dtype=torch.float32)
+    dV = alloc((T * Bp, W), device=v.device, dtype=torch.float32) if want_dv else None
+    dU = alloc((T * Bp, W2), device=v.device, dtype=torch.bfloat16 if du_bf16 else torch.float32)
     dw2 = torch.zeros((W2,), device=v.device, dtype=torch.float32)
-    rc = _lib.lib().lob_attn_pool_bwd_f32(_ptr(v), _ptr(u), _ptr(attn), _ptr(dctx), _ptr(w2), _ptr(dV), _ptr(dU),
-                                          _ptr(dw2), T, B, Bp, W, W2, _stream())
+    rc = _lib.lib().lob_attn_pool_bwd_f32(_ptr(v), int(v16), _ptr(u), _ptr(attn), _ptr(dctx), _ptr(w2), _ptr(dV),
+                                          _ptr(dU), int(du_bf16), _ptr(dw2), T, B, Bp, W, W2, _stream())
     _lib.check(rc, "lob_attn_pool_bwd_f32")
     return dV, dU, dw2
