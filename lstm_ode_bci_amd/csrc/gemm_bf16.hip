@@ -364,7 +364,7 @@ void gemm_nt_dma_kernel(NTArgs g) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int col = cn0 + 64 * wc + 32 * j + (lane & 31);
-                    const float bv = bias_s[col < 2048 ? col : 0];
+                    const float bv = lds_read_f32_opaque(bias_s + (col < 2048 ? col : 0));
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = cm0 + 64 * wr + 32 * i + acc_row(r, lane);
@@ -387,7 +387,7 @@ void gemm_nt_dma_kernel(NTArgs g) {
                 for (int j = 0; j < 2; ++j) {
                     const int ncol = cn0 + 64 * wc + 32 * j;
                     const int d = ncol / H4, gg = (ncol % H4) / g.H, w = (ncol % g.H) >> 5;
-                    const float bv = bias_s[ncol + (lane & 31)];
+                    const float bv = lds_read_f32_opaque(bias_s + ncol + (lane & 31));
                     const size_t fo = ((((size_t)(d * g.T + t) * NBT + bt) * NW + w) * 4 + gg) * 1024 + lane * 4;
                     if (g.out_bf16) {
                         __bf16* dst = reinterpret_cast<__bf16*>(g.C) + fo;

@@ -11,6 +11,7 @@
 // its terms, and with this order every lane reads 16 CONTIGUOUS floats of its row from
 // LDS (4 x ds_read_b128) instead of 16 scalar reads.  LDS rows are padded to 36 floats
 // (144 B): for ds_read_b128 the 16-lane groups then hit 16 distinct 16-B slots.
+#include <stdlib.h>
 #include "lob_common.h"
 
 namespace {
@@ -165,6 +166,156 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT g) {
 }
 
 
+// ------------------------------------------------------------------------------------------
+// LDS-DMA variant of the exact-fp32 NT GEMM (K % 32 == 0, K >= 128).  Same 128x128 tile and MFMA
+// schedule as gemm_nt_kernel, but the fp32 operand tiles go HBM -> LDS by global_load_lds_dwordx4:
+// no staging VGPRs, no ds_write pass, and a 4-slot ring keeps THREE 32-deep k-tiles (5 us of MFMA
+// work) in flight across output-tile boundaries, so a persistent workgroup never waits on memory at a
+// tile seam.  Counted s_waitcnt vmcnt + raw s_barrier, as in gemm_bf16.hip.
+//
+// LDS image of a slot: [128 rows][32 floats] = 128-B rows, lane-linear (8 rows per DMA instruction).
+// A lane's 16 contiguous k (4 x ds_read_b128) would be 8-way conflicted on unpadded rows, so 16-B
+// chunk c of row r is stored at chunk slot c ^ ((r >> 1) & 7) -- on the DMA's per-lane source address
+// and again on the fragment read; the 16 lanes of a b128 group then hit 16 distinct slots.
+// ------------------------------------------------------------------------------------------
+constexpr int FDS = 2, FTK = 32, FSLOT = 128 * FTK;     // floats per operand per slot (16 KB); 2 slots = 64 KB
+// (2 slots -> 2 workgroups per CU: with the 64-cycle fp32 MFMA one k-tile is 1.7 us of work, enough to cover the
+//  DMA of the next one, and the second resident workgroup covers the ds_read -> MFMA latency at each k-tile
+//  start; 4 slots / 1 workgroup per CU measured 13 % slower than the register-staged kernel)
+
+typedef __attribute__((address_space(3))) void lds_void_f;
+typedef __attribute__((address_space(1))) const void gbl_cvoid_f;
+
+__device__ __forceinline__ void dma_rows8_f32(const float* G, int ld, int row0, int nrows, int k0, float* lds_rows,
+                                              int lane) {
+    const int r = row0 + (lane >> 3), p = lane & 7;
+    const int c = p ^ ((r >> 1) & 7);
+    const int rr = r < nrows ? r : nrows - 1;                    // clamp: padded rows are never stored
+    __builtin_amdgcn_global_load_lds((gbl_cvoid_f*)(G + (size_t)rr * ld + k0 + c * 4), (lds_void_f*)lds_rows, 16, 0, 0);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_dma_f32_kernel(GemmNT g) {
+    __shared__ __attribute__((aligned(1024))) float ring[FDS * 2 * FSLOT + 2048];     // 128 KB ring + 8 KB bias
+    float* bias_s = ring + FDS * 2 * FSLOT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+    const int panels = (ntm - xcd + 7) / 8, ntile = panels * ntn;
+    const int nk = g.K / FTK;
+    if (slot >= ntile) return;
+    const int total = ((ntile - slot + nslot - 1) / nslot) * nk;
+    for (int i = tid; i < g.N && i < 2048; i += 256) bias_s[i] = g.bias ? g.bias[i] : 0.f;
+    __syncthreads();
+
+    int p_q = 0, p_it = slot, p_kt = 0;
+    auto issue = [&]() {
+        const int m0 = ((p_it / ntn) * 8 + xcd) * BM, n0 = (p_it % ntn) * BN;
+        float* as = ring + (p_q % FDS) * 2 * FSLOT;
+        float* ws = as + FSLOT;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int rb = (wave * 4 + j) * 8;
+            dma_rows8_f32(g.A, g.lda, m0 + rb, g.M, p_kt * FTK, as + rb * FTK, lane);
+            dma_rows8_f32(g.W, g.ldw, n0 + rb, g.N, p_kt * FTK, ws + rb * FTK, lane);
+        }
+        ++p_q;
+        if (++p_kt == nk) { p_kt = 0; p_it += nslot; }
+    };
+#pragma unroll 1
+    for (int i = 0; i < FDS - 1 && i < total; ++i) issue();
+
+    int it = slot, kt = 0, since_epi = 99;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int q = 0; q < total; ++q) {
+        // younger operations of this wave that may stay in flight: (FDS-2) k-tiles x 8 DMAs, plus the 16
+        // fragment-epilogue stores if they were issued after DMA(q)
+        constexpr int VM_STEADY = (FDS - 2) * 8, VM_EPI = VM_STEADY + 16;
+        if (q + FDS - 1 > total)                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (EPI == 1 && since_epi < FDS - 1)   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_EPI) : "memory");
+        else if (since_epi < FDS - 1)               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else                                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_STEADY) : "memory");
+        __builtin_amdgcn_s_barrier();
+        if (p_q < total) issue();
+        ++since_epi;
+
+        const float* as = ring + (q % FDS) * 2 * FSLOT;
+        const float* ws = as + FSLOT;
+        const int r31 = lane & 31, hi = lane >> 5, sw = (r31 >> 1) & 7;      // (64wr + 32i) >> 1 is a multiple of 8
+        f32x4 af[2][4], bf[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int pc = ((4 * hi + qq) ^ sw) * 4;
+                af[i][qq] = *reinterpret_cast<const f32x4*>(as + (64 * wr + 32 * i + r31) * FTK + pc);
+                bf[i][qq] = *reinterpret_cast<const f32x4*>(ws + (64 * wc + 32 * i + r31) * FTK + pc);
+            }
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = mfma32(af[i][qq][e], bf[j][qq][e], acc[i][j]);
+        if (++kt < nk) continue;
+
+        kt = 0;
+        const int cm0 = ((it / ntn) * 8 + xcd) * BM, cn0 = (it % ntn) * BN;
+        it += nslot;
+        since_epi = 0;
+        if (EPI == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = cn0 + 64 * wc + 32 * j + (lane & 31);
+                    const float bv = lds_read_f32_opaque(bias_s + (col < 2048 ? col : 0));
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = cm0 + 64 * wr + 32 * i + acc_row(r, lane);
+                        if (row < g.M && col < g.N) g.C[(size_t)row * g.ldc + col] = apply_act(acc[i][j][r] + bv, g.act);
+                        acc[i][j][r] = 0.f;
+                    }
+                }
+        } else {
+            const int NBT = g.Bp >> 5, NW = g.H >> 5, H4 = 4 * g.H;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int mrow = cm0 + 64 * wr + 32 * i;
+                const int t = mrow / g.Bp, bt = (mrow % g.Bp) >> 5;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int ncol = cn0 + 64 * wc + 32 * j;
+                    const int d = ncol / H4, gg = (ncol % H4) / g.H, w = (ncol % g.H) >> 5;
+                    const float bv = lds_read_f32_opaque(bias_s + ncol + (lane & 31));
+                    float* dst = g.C + ((((size_t)(d * g.T + t) * NBT + bt) * NW + w) * 4 + gg) * 1024 + lane * 4;
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        f32x4 v = {acc[i][j][4 * qq + 0] + bv, acc[i][j][4 * qq + 1] + bv,
+                                   acc[i][j][4 * qq + 2] + bv, acc[i][j][4 * qq + 3] + bv};
+                        *reinterpret_cast<f32x4*>(dst + qq * 256) = v;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                }
+            }
+        }
+    }
+}
+
+
 // ------------------------------------------------------------------------------------
 // C[M,N] += A[Kc,M]^T * B[Kc,N]  -- weight gradients.  The contraction index is the ROW index
 // of both operands (time x batch, ~1M), the output is small, so the grid splits Kc and every
@@ -292,8 +443,25 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+inline bool f32_dma_enabled() {
+    static const bool v = [] { const char* e = getenv("LOB_F32_DMA"); return !(e && atoi(e) == 0); }();
+    return v;
+}
+
 int launch_nt(const GemmNT& g, int epi, hipStream_t s) {
     const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
+    // LDS-DMA kernel: 16-B aligned K-contiguous fp32 operands, K a multiple of 32 and >= 4 k-tiles, no accumulate;
+    // fragment epilogue needs whole tiles
+    if (f32_dma_enabled() && aligned16(g.A) && aligned16(g.W) && g.lda % 4 == 0 && g.ldw % 4 == 0 && g.K % FTK == 0 &&
+        g.K / FTK >= 4 && !g.accumulate && g.N <= 2048 && (epi == 0 || (g.M % BM == 0 && g.N % BN == 0))) {
+        long gsz = 512;
+        const long tiles = (long)ntm * ntn;
+        if (gsz > tiles) gsz = ((tiles + 7) / 8) * 8;
+        if (epi == 0) hipLaunchKernelGGL((gemm_nt_dma_f32_kernel<0>), dim3((unsigned)gsz), dim3(256), 0, s, g);
+        else          hipLaunchKernelGGL((gemm_nt_dma_f32_kernel<1>), dim3((unsigned)gsz), dim3(256), 0, s, g);
+        LOB_CHECK_LAUNCH();
+        return 0;
+    }
     const dim3 grid((unsigned)(((ntm + 7) / 8) * 8 * ntn)), block(256);
     const bool vec = aligned16(g.A) && aligned16(g.W) && (g.lda % 4 == 0) && (g.ldw % 4 == 0) && (g.K % 4 == 0);
     if (epi == 0) {

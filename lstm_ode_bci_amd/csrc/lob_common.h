@@ -68,3 +68,13 @@ __device__ __forceinline__ float lob_dropout_scale(uint64_t seed, uint64_t idx, 
     const uint32_t thr = (uint32_t)(p * 4294967296.0);
     return lob_hash32(seed, idx) >= thr ? 1.0f / (1.0f - p) : 0.0f;
 }
+
+// LDS read that the compiler cannot see (inline asm): used next to in-flight LDS-DMA (global_load_lds),
+// where an ordinary LDS read of ANOTHER region makes hipcc drain the whole DMA queue (s_waitcnt vmcnt(0))
+// because it cannot prove the regions disjoint.  The caller guarantees the word is not a DMA target.
+__device__ __forceinline__ float lds_read_f32_opaque(const float* p) {
+    const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float*)p;
+    float v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}

@@ -106,3 +106,14 @@ if on("tndma"):
     dwh = torch.zeros((512, 128), device=dev)
     report("tn dWhh bf16xbf16", timeit(lambda: ops.gemm_tn(dPb[Bp:, :512], xb[:rows - Bp, :128], dwh)),
            2.0 * rows * 512 * 128, 2.0 * rows * (512 + 128))
+
+if on("f32dma"):
+    for K in (128, 256):
+        x = torch.randn((rows, K), generator=g).to(dev)
+        wih = (torch.rand((N, K), generator=g) * 0.17 - 0.085).to(dev)
+        bias = torch.zeros(N, device=dev)
+        report(f"gate_gemm K={K} f32", timeit(lambda: ops.gate_gemm_x(x, wih, bias, T, Bp, H, D, True)),
+               2.0 * rows * N * K, 4.0 * rows * (K + N))
+    dPf = torch.randn((rows, N), generator=g).to(dev)
+    wt = (torch.rand((256, N), generator=g) * 0.1).to(dev)
+    report("dX f32 N=256", timeit(lambda: ops.gemm_nt(dPf, wt)), 2.0 * rows * N * 256, 4.0 * rows * (N + 256))
