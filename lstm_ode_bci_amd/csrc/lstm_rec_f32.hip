@@ -15,8 +15,11 @@
 //
 // Generic path (any H): VALU dot products, W_hh streamed from L2.  Correct, not fast;
 // it exists so that every (H, num_layers, bidirectional) the reference accepts runs.
+#include <stdlib.h>
 #include "lob_common.h"
 
+// H = 128 on 16-row sub-tiles / v_mfma_f32_16x16x4_f32 (lstm_rec_f32_s16.hip)
+int lob_rec_fwd_s16(float* P, const float* Whh, float* Y, float* Csave, int T, int Bp, int D, int save, hipStream_t s);
 // H = 32 / 64 / 256: W_hh streamed from L2 (lstm_rec_stream.hip)
 int lob_stream_supports(int H);
 int lob_stream_fwd(float* P, const float* Whh, float* Y, float* Csave, int T, int Bp, int H, int D, int save, hipStream_t s);
@@ -457,6 +460,10 @@ extern "C" int lob_lstm_rec_fwd_f32(float* P, const float* Whh, float* Y, float*
         if (Bp % 32) return LOB_E_SHAPE;
         if ((reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(Whh) |
              reinterpret_cast<uintptr_t>(Csave)) & 15) return LOB_E_ALIGN;
+        // 16-row tiles (v_mfma_f32_16x16x4_f32) by default: twice the workgroups for small batches and 2-8 % faster at
+        // B = 4096; LOB_REC_FWD=32 selects the 32-row kernel below (kept for A/B measurements)
+        static const bool rows32 = [] { const char* e = getenv("LOB_REC_FWD"); return e && atoi(e) == 32; }();
+        if (!rows32) return lob_rec_fwd_s16(P, Whh, Y, Csave, T, Bp, D, save, s);
         const dim3 grid(Bp / 32, D), block(256);
         if (save) hipLaunchKernelGGL((lstm_rec_fwd_h128_kernel<true, SAVE_WLDS>), grid, block, 0, s, P, Whh, Y, Csave, T, Bp);
         else      hipLaunchKernelGGL((lstm_rec_fwd_h128_kernel<false, false>), grid, block, 0, s, P, Whh, Y, Csave, T, Bp);
