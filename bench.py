@@ -195,13 +195,21 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with python -m torch.distributed.run --nproc-per-node N")
+    # LOB_DIST_BACKEND=gloo + LOB_SHARE_GPU=1: rehearsal of the N > 1 code path on a one-GPU box (all ranks on
+    # cuda:0, collectives through host memory); the real multi-GPU run uses nccl (= RCCL over xGMI), one GPU each
+    backend = os.environ.get("LOB_DIST_BACKEND", "nccl")
+    if os.environ.get("LOB_SHARE_GPU") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from lstm_ode_bci_amd import CognitiveStateODE, LSTMODEIntegration
     from lstm_ode_bci_amd import synthetic as syn
