@@ -94,14 +94,22 @@ def kernel_roofline(dev, B, mode, precision):
     bf16_rec = mixed and H == 128                       # bf16-MFMA recurrent kernels exist at H = 128
     pe = 2.0 if (bf16_rec and ops.PG_BF16) else 4.0     # bytes per stored pre-activation / saved gate
     de = 2.0 if mixed else 4.0                          # bytes per dP element
+    # operand storage types as the step itself uses them: in mixed mode at H = 128 the layer below hands
+    # over bf16 activations and the weights are cast once per step -> the LDS-DMA GEMM kernels
+    act16 = bf16_rec and ops.dma_ok(K, N, rows)
+    xe = 2.0 if act16 else 4.0                          # bytes per inter-layer activation element
     x = torch.randn((rows, K), generator=g).to(dev)
     wih = (torch.rand((N, K), generator=g) * 0.17 - 0.085).to(dev)
+    if act16:
+        x, w_in = x.to(torch.bfloat16), wih.to(torch.bfloat16)
+    else:
+        w_in = wih
     bias = torch.zeros(N, device=dev)
     whh = (torch.rand((D, 4 * H, H), generator=g) * 0.17 - 0.085).to(dev)
-    sec = timeit(lambda: ops.gate_gemm_x(x, wih, bias, T, Bp, H, D, True, mixed=mixed))
-    out["gate_gemm_x(K=256)"] = {"sec": sec, "flop": 2.0 * rows * N * K, "bytes": rows * (4.0 * K + pe * N) + 4.0 * N * K,
+    sec = timeit(lambda: ops.gate_gemm_x(x, w_in, bias, T, Bp, H, D, True, mixed=mixed))
+    out["gate_gemm_x(K=256)"] = {"sec": sec, "flop": 2.0 * rows * N * K, "bytes": rows * (xe * K + pe * N) + xe * N * K,
                                  "per_step": L - 1, "mfma": "bf16" if mixed else "f32"}
-    P = ops.gate_gemm_x(x, wih, bias, T, Bp, H, D, True, mixed=mixed)
+    P = ops.gate_gemm_x(x, w_in, bias, T, Bp, H, D, True, mixed=mixed)
     if train:
         Pk = P.clone()
 
@@ -124,8 +132,10 @@ def kernel_roofline(dev, B, mode, precision):
         sec = timeit(lambda: ops.gemm_tn(dP, x, dw, mixed=mixed))
         out["gemm_tn(dW_ih)"] = {"sec": sec, "flop": 2.0 * rows * N * K, "per_step": L - 1,
                                  "mfma": "bf16" if mixed else "f32",
-                                 "bytes": de * rows * N + 4.0 * rows * K}
+                                 "bytes": de * rows * N + xe * rows * K}
         wt = wih.t().contiguous()
+        if dP.dtype == torch.bfloat16 and ops.dma_ok(N, K, rows):
+            wt = wt.to(torch.bfloat16)
         sec = timeit(lambda: ops.gemm_nt(dP, wt, mixed=mixed))
         out["gemm_nt(dX)"] = {"sec": sec, "flop": 2.0 * rows * N * K, "per_step": L - 1,
                               "mfma": "bf16" if mixed else "f32",
