@@ -36,6 +36,9 @@ extern "C" {
 #define LOB_ACT_TANH 1     /* nn.Tanh  (04_lstm_model.py:119)                        */
 #define LOB_ACT_GELU 2     /* nn.GELU, exact erf form (04_lstm_model.py:176,198,201) */
 #define LOB_ACCUMULATE 0x100  /* OR into `act` of lob_gemm_nt_f32: C += result instead of C = */
+#define LOB_LN_IDENTITY 0x200 /* OR into `act` of lob_layernorm_act(_bwd)_f32: skip the normalisation and the
+                               * affine (nn.Identity in place of nn.LayerNorm: the no-LayerNorm ablation,
+                               * 09_sensitivity_analysis.py:190,209); gamma/beta/dgamma/dbeta may be NULL */
 
 int lob_version(void);
 
@@ -169,7 +172,8 @@ int lob_attn_pool_bwd_f32(const void* V, int v_bf16, const float* U, const float
                           const float* w2, float* dV, void* dPreU, int du_bf16, float* dw2,
                           int T, int B, int Bp, int W, int W2, void* stream);
 /*   v_bf16 / du_bf16: V read / dPreU written as bf16 (mixed mode).  dV == NULL: the direct term
- *   a[t] * dctx is not materialised; pass pool_attn / pool_dctx to lob_layernorm_act_bwd_f32 instead. */
+ *   a[t] * dctx is not materialised; pass pool_attn / pool_dctx to lob_layernorm_act_bwd_f32 instead.
+ *   U == NULL (mean pooling): only dV = a[t] * dctx is written; w2, dPreU, dw2 are ignored.          */
 
 /* ------------------------------------------------------------------------------------
  * Row-wise LayerNorm (biased variance, eps) with affine, optional GELU, optional
@@ -194,7 +198,9 @@ int lob_dropout_f32(const float* in, float* out, int64_t n, float p, uint64_t se
 /* Additive attention pooling over time (Attention.forward, 04_lstm_model.py:123-128):
  *   s[t,b] = U[t*Bp+b,:] . w2 + b2   (U = tanh(W1 v + b1), computed by lob_gemm_nt_f32)
  *   a[b,:] = softmax_t(s[:,b]);   ctx[b,:] = sum_t a[b,t] * V[t*Bp+b,:]
- *   V [T*Bp][W], U [T*Bp][W2], attn [B][T], ctx [B][W].                              */
+ *   V [T*Bp][W], U [T*Bp][W2], attn [B][T], ctx [B][W].
+ *   U == NULL: all scores equal, a = 1/T -- mean pooling over time, the no-attention ablation
+ *   (torch.mean(lstm_out, dim=1), 09_sensitivity_analysis.py:236); w2, b2, W2 are then ignored.   */
 int lob_attn_pool_fwd_f32(const void* V, int v_bf16, const float* U, const float* w2, const float* b2,
                           float* ctx, float* attn, int T, int B, int Bp, int W, int W2,
                           void* stream);
@@ -231,6 +237,40 @@ int lob_ode_rk4_f64(const float* probs, const double* y0_in, const double* base_
 /* y0[b] = prob_to_ode_state(P(closed)) (08_forecasting.py:215-234): A = 1-p; (F,P) = (.6p,.4p) if
  * p > .5 else (.3p,.3p); normalised.  probs [B][2] f32 -> y0 [B][3] f64.                   */
 int lob_prob_to_state_f64(const float* probs, double* y0, int B, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * The steps either side of fwd+bwd in the reference's training loop (04_lstm_model.py:482-512),
+ * over FLAT fp32 parameter / gradient / moment buffers (all tensors of the model back to back).
+ * ---------------------------------------------------------------------------------- */
+
+/* nn.CrossEntropyLoss(weight=class_weight) (04:430-435), reduction 'mean':
+ *   loss[0]  = sum_i w[y_i] * nll_i / sum_i w[y_i]
+ *   dlogits  = scale * d loss / d logits        (may be NULL; scale = 1/gradient_accumulation_steps, 04:489)
+ *   correct[0] = #{i : argmax_c logits[i][c] == y_i}   (04:508-509; may be NULL)
+ * logits [B][C] f32, target [B] int64, class_weight [C] f32 or NULL (all ones).  One workgroup.      */
+int lob_weighted_ce_f32(const float* logits, const int64_t* target, const float* class_weight,
+                        float* loss, float* dlogits, int* correct, int B, int C, float scale,
+                        void* stream);
+
+/* out[0] += sum x[i]^2 (the squared global gradient norm of clip_grad_norm_, 04:501).  x 16-B aligned;
+ * the caller zeroes out[0].                                                                         */
+int lob_sumsq_f32(const float* x, int64_t n, float* out, void* stream);
+
+/* g *= min(1, max_norm / (sqrt(normsq[0]) + 1e-6)): torch.nn.utils.clip_grad_norm_ in place (04:501),
+ * normsq read on the device (no host round trip).                                                   */
+int lob_clip_scale_f32(float* g, int64_t n, const float* normsq, float max_norm, void* stream);
+
+/* One torch.optim.AdamW step (04:438, 502) on flat buffers, with the clip folded in:
+ *   g' = grad_scale * g * min(1, max_norm / (grad_scale * sqrt(normsq[0]) + 1e-6))   (normsq NULL: no clip)
+ *   p *= 1 - lr * weight_decay;  m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2
+ *   p -= lr / (1 - b1^step) * m / (sqrt(v) / sqrt(1 - b2^step) + eps)                                */
+int lob_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int64_t step, const float* normsq,
+                  float max_norm, float grad_scale, void* stream);
+
+/* out[c] += scale * sum_{rows} |gx[row][c]|: the |input gradient| reduction of the gradient attribution
+ * (07_explainability.py:257-258: X.grad[i].abs().mean(dim=0), summed over windows), gx [rows][C].    */
+int lob_abs_colsum_f32(const float* gx, int64_t rows, int C, float scale, float* out, void* stream);
 
 #ifdef __cplusplus
 }

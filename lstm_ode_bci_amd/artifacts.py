@@ -58,3 +58,21 @@ def load_models(models_path, device="cuda"):
     """Mirror of 06_lstm_ode_integration.py:409-440: (lstm_model, ode_model) from a models directory."""
     lstm, _, _ = load_lstm_checkpoint(os.path.join(models_path, LSTM_FILE), device)
     return lstm, load_ode_model(os.path.join(models_path, ODE_FILE))
+
+
+def load_processed_sequences(path):
+    """``load_data`` of 04_lstm_model.py:250-287 / 09:246-262: the arrays of ``processed_sequences.npz``
+    (02_preprocessing.py:400-408) as ``(X_train, y_train, X_val, y_val, X_test, y_test)``; when the archive
+    has no validation split, 15 % of the training windows are split off (04:266-276, numpy global RNG)."""
+    import numpy as np
+    data = np.load(path)
+    X_train, y_train = data["X_train"], data["y_train"]
+    X_test, y_test = data["X_test"], data["y_test"]
+    if "X_val" in data.files and len(data["X_val"]) > 0:
+        X_val, y_val = data["X_val"], data["y_val"]
+    else:
+        n_val = int(len(X_train) * 0.15)
+        indices = np.random.permutation(len(X_train))
+        X_val, y_val = X_train[indices[:n_val]], y_train[indices[:n_val]]
+        X_train, y_train = X_train[indices[n_val:]], y_train[indices[n_val:]]
+    return X_train, y_train, X_val, y_val, X_test, y_test

@@ -16,21 +16,26 @@ from .ops import ACT_GELU, ACT_NONE, ACT_TANH, ceil32
 
 
 def _collect(model):
-    ps = [model.input_proj[0].weight, model.input_proj[0].bias,
-          model.input_proj[1].weight, model.input_proj[1].bias]
+    """Parameters in pipeline order.  The ablation variants (09_sensitivity_analysis.py:176-242) keep the
+    positions and put None where a sub-module is nn.Identity / absent."""
+    def wb(mod):
+        return [getattr(mod, "weight", None), getattr(mod, "bias", None)]
+    ps = [model.input_proj[0].weight, model.input_proj[0].bias] + wb(model.input_proj[1])
     for layer in range(model.num_layers):
         for tup in model.lstm.layer_params(layer):
             ps.extend(tup)
-    ps += [model.layer_norm.weight, model.layer_norm.bias,
-           model.attention.attention[0].weight, model.attention.attention[0].bias,
-           model.attention.attention[2].weight, model.attention.attention[2].bias,
-           model.classifier[0].weight, model.classifier[0].bias,
+    att = model.attention.attention if model.attention is not None else None
+    ps += wb(model.layer_norm)
+    ps += [att[0].weight, att[0].bias, att[2].weight, att[2].bias] if att is not None else [None] * 4
+    ps += [model.classifier[0].weight, model.classifier[0].bias,
            model.classifier[3].weight, model.classifier[3].bias,
            model.classifier[6].weight, model.classifier[6].bias]
     return ps
 
 
 def _f32c(t):
+    if t is None:
+        return None
     t = t.detach()
     if t.dtype != torch.float32:
         t = t.float()
@@ -96,10 +101,14 @@ def _forward_impl(x, ps, cfg, save):
     c0w, c0b, c3w, c3b, c6w, c6b = (next(it) for _ in range(6))
     # mixed mode: the normalised sequence v only feeds bf16 MFMA GEMMs and the pooling sums -> bf16
     v = ops.layernorm_act(inp, ln_g, ln_b, out_bf16=mixed)                   # (T*Bp, W)
-    w1 = a0w.to(torch.bfloat16) if (v.dtype == torch.bfloat16 and
-                                    ops.dma_ok(v.shape[1], a0w.shape[0], v.shape[0])) else a0w
-    u = ops.gemm_nt(v, w1, a0b, act=ACT_TANH, mixed=mixed)                   # (T*Bp, W/2)
-    ctx, attn = ops.attn_pool_fwd(v, u, a2w.reshape(-1), a2b, T, B, Bp)
+    if a0w is None:            # no-attention ablation: mean pooling over time (09:236)
+        u = None
+        ctx, attn = ops.attn_pool_fwd(v, None, None, None, T, B, Bp)
+    else:
+        w1 = a0w.to(torch.bfloat16) if (v.dtype == torch.bfloat16 and
+                                        ops.dma_ok(v.shape[1], a0w.shape[0], v.shape[0])) else a0w
+        u = ops.gemm_nt(v, w1, a0b, act=ACT_TANH, mixed=mixed)               # (T*Bp, W/2)
+        ctx, attn = ops.attn_pool_fwd(v, u, a2w.reshape(-1), a2b, T, B, Bp)
     if save:       # keep the pre-activations of the two classifier GELUs for their backward
         z1p = ops.gemm_nt(ctx, c0w, c0b)
         z1 = ops.act(z1p, ACT_GELU)

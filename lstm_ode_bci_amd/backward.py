@@ -50,23 +50,27 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad):
     # ---- attention pooling (04:123-128)
     v, u = sv["v"], sv["u"]
     a0w = ps[i_a0w]
-    fused = v.dtype == torch.bfloat16            # mixed mode: bf16 v / dU, context path folded into the LN backward
-    dV, dU, dw2 = ops.attn_pool_bwd(v, u, sv["attn"], dctx, ps[i_a2w].reshape(-1), T, B, Bp,
-                                    want_dv=not fused, du_bf16=fused)
-    g[i_a2w] = dw2.reshape(1, -1)
-    g[i_a2b] = torch.zeros_like(ps[i_a2b])            # b2 cancels in the softmax: exactly 0
-    g[i_a0w] = torch.zeros_like(a0w)
-    ops.gemm_tn(dU, v, g[i_a0w], mixed=mixed)
-    g[i_a0b] = ops.colsum(dU)
-    if fused:
-        w1t = _t(a0w)
-        if ops.dma_ok(dU.shape[1], w1t.shape[0], dU.shape[0]):
-            w1t = w1t.to(torch.bfloat16)
-        dV = ops.gemm_nt(dU, w1t, mixed=mixed)                       # dU W1; + a[t] dctx is added below
-        pool = (sv["attn"], dctx, T, B, Bp)
-    else:
-        ops.gemm_nt(dU, _t(a0w), out=dV, accumulate=True, mixed=mixed)
+    if a0w is None:          # mean pooling (09:236): dV = dctx / T, no parameters
+        dV, _, _ = ops.attn_pool_bwd(v, None, sv["attn"], dctx, None, T, B, Bp)
         pool = None
+    else:
+        fused = v.dtype == torch.bfloat16        # mixed mode: bf16 v / dU, context path folded into the LN backward
+        dV, dU, dw2 = ops.attn_pool_bwd(v, u, sv["attn"], dctx, ps[i_a2w].reshape(-1), T, B, Bp,
+                                        want_dv=not fused, du_bf16=fused)
+        g[i_a2w] = dw2.reshape(1, -1)
+        g[i_a2b] = torch.zeros_like(ps[i_a2b])            # b2 cancels in the softmax: exactly 0
+        g[i_a0w] = torch.zeros_like(a0w)
+        ops.gemm_tn(dU, v, g[i_a0w], mixed=mixed)
+        g[i_a0b] = ops.colsum(dU)
+        if fused:
+            w1t = _t(a0w)
+            if ops.dma_ok(dU.shape[1], w1t.shape[0], dU.shape[0]):
+                w1t = w1t.to(torch.bfloat16)
+            dV = ops.gemm_nt(dU, w1t, mixed=mixed)                       # dU W1; + a[t] dctx is added below
+            pool = (sv["attn"], dctx, T, B, Bp)
+        else:
+            ops.gemm_nt(dU, _t(a0w), out=dV, accumulate=True, mixed=mixed)
+            pool = None
 
     # ---- post-LSTM LayerNorm (04:212)
     dY, g[i_ln], g[i_ln + 1] = ops.layernorm_act_bwd(sv["ylast"], ps[i_ln], ps[i_ln + 1], dV, pool=pool)

@@ -15,6 +15,8 @@ __global__ __launch_bounds__(256) void layernorm_act_kernel(
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     const int per = (width + 63) >> 6;
+    const bool norm = !(act & LOB_LN_IDENTITY);      // identity: y = act(x) (the no-LayerNorm ablation, 09:190)
+    act &= 0xff;
     for (int row = wave; row < rows; row += nwaves) {
         const float* x = in + (size_t)row * width;
         float v[LN_MAX_PER_LANE];
@@ -25,7 +27,7 @@ __global__ __launch_bounds__(256) void layernorm_act_kernel(
             v[i] = (i < per && c < width) ? x[c] : 0.f;
             s += v[i];
         }
-        const float mean = wave_sum(s) / (float)width;
+        const float mean = norm ? wave_sum(s) / (float)width : 0.f;
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
@@ -33,7 +35,7 @@ __global__ __launch_bounds__(256) void layernorm_act_kernel(
             const float dlt = (i < per && c < width) ? v[i] - mean : 0.f;
             q += dlt * dlt;
         }
-        const float rstd = rsqrtf(wave_sum(q) / (float)width + eps);
+        const float rstd = norm ? rsqrtf(wave_sum(q) / (float)width + eps) : 1.f;
         int orow = row;
         if (remap_T > 0) { const int b = row / remap_T, t = row % remap_T; orow = t * remap_Bp + b; }
         float* y = out + (size_t)orow * width;
@@ -41,7 +43,7 @@ __global__ __launch_bounds__(256) void layernorm_act_kernel(
         for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
             const int c = lane + 64 * i;
             if (i < per && c < width) {
-                float o = (v[i] - mean) * rstd * gamma[c] + beta[c];
+                float o = norm ? (v[i] - mean) * rstd * gamma[c] + beta[c] : v[i];
                 o = apply_act(o, act);
                 if (drop_p > 0.f) o *= lob_dropout_scale(seed, (uint64_t)orow * width + c, drop_p);
                 y[c] = o;
@@ -61,10 +63,12 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_kernel(
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float bias2 = b2 ? b2[0] : 0.f;
     for (int t = wave; t < T; t += 4) {
-        const float* u = U + ((size_t)t * Bp + b) * W2;
         float s = 0.f;
-        for (int j = lane; j < W2; j += 64) s = fmaf(u[j], w2[j], s);
-        s = wave_sum(s);
+        if (U) {         // U == NULL: all scores equal -> weights 1/T (mean pooling over time, 09:236)
+            const float* u = U + ((size_t)t * Bp + b) * W2;
+            for (int j = lane; j < W2; j += 64) s = fmaf(u[j], w2[j], s);
+            s = wave_sum(s);
+        }
         if (lane == 0) sc[t] = s + bias2;
     }
     __syncthreads();
@@ -143,12 +147,14 @@ __global__ __launch_bounds__(256) void layernorm_act_bwd_kernel(
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     const int per = (width + 63) >> 6;
     float dga[LN_MAX_PER_LANE], dba[LN_MAX_PER_LANE], gm[LN_MAX_PER_LANE], bt[LN_MAX_PER_LANE];
+    const bool norm = !(act & LOB_LN_IDENTITY);
+    act &= 0xff;
 #pragma unroll
     for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
         const int c = lane + 64 * i;
         dga[i] = 0.f; dba[i] = 0.f;
-        gm[i] = (i < per && c < width) ? gamma[c] : 0.f;
-        bt[i] = (i < per && c < width) ? beta[c] : 0.f;
+        gm[i] = (i < per && c < width) ? (norm ? gamma[c] : 1.f) : 0.f;
+        bt[i] = (i < per && c < width && norm) ? beta[c] : 0.f;
     }
     const float invw = 1.0f / (float)width;
     for (int row = wave; row < rows; row += nwaves) {
@@ -166,7 +172,7 @@ __global__ __launch_bounds__(256) void layernorm_act_bwd_kernel(
             go[i] = ok ? dyr[c] : 0.f;
             s += v[i];
         }
-        const float mean = wave_sum(s) * invw;
+        const float mean = norm ? wave_sum(s) * invw : 0.f;
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
@@ -174,7 +180,7 @@ __global__ __launch_bounds__(256) void layernorm_act_bwd_kernel(
             const float dl = (i < per && c < width) ? v[i] - mean : 0.f;
             q += dl * dl;
         }
-        const float rstd = rsqrtf(wave_sum(q) * invw + eps);
+        const float rstd = norm ? rsqrtf(wave_sum(q) * invw + eps) : 1.f;
         float m1 = 0.f, m2 = 0.f;
 #pragma unroll
         for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
@@ -191,8 +197,8 @@ __global__ __launch_bounds__(256) void layernorm_act_bwd_kernel(
                 m1 += dxh; m2 += dxh * xh;
             } else { v[i] = 0.f; go[i] = 0.f; }
         }
-        m1 = wave_sum(m1) * invw;
-        m2 = wave_sum(m2) * invw;
+        m1 = norm ? wave_sum(m1) * invw : 0.f;
+        m2 = norm ? wave_sum(m2) * invw : 0.f;
         float* dxr = dx + (size_t)row * width;
 #pragma unroll
         for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
@@ -203,7 +209,7 @@ __global__ __launch_bounds__(256) void layernorm_act_bwd_kernel(
 #pragma unroll
     for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
         const int c = lane + 64 * i;
-        if (i < per && c < width) { atomicAdd(dgamma + c, dga[i]); atomicAdd(dbeta + c, dba[i]); }
+        if (norm && i < per && c < width) { atomicAdd(dgamma + c, dga[i]); atomicAdd(dbeta + c, dba[i]); }
     }
 }
 
@@ -253,8 +259,13 @@ __global__ __launch_bounds__(256) void layernorm_act_vec_kernel(
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     float gm[VPL], bt[VPL];
-    ldv<VPL>(gamma + lane * VPL, gm);
-    ldv<VPL>(beta + lane * VPL, bt);
+    const bool norm = !(act & LOB_LN_IDENTITY);
+    act &= 0xff;
+    if (norm) { ldv<VPL>(gamma + lane * VPL, gm); ldv<VPL>(beta + lane * VPL, bt); }
+    else {
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) { gm[i] = 1.f; bt[i] = 0.f; }
+    }
     const float invw = 1.0f / (float)width;
     for (int row = wave; row < rows; row += nwaves) {
         float v[VPL];
@@ -262,11 +273,11 @@ __global__ __launch_bounds__(256) void layernorm_act_vec_kernel(
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) s += v[i];
-        const float mean = wave_sum(s) * invw;
+        const float mean = norm ? wave_sum(s) * invw : 0.f;
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) { const float dl = v[i] - mean; q += dl * dl; }
-        const float rstd = rsqrtf(wave_sum(q) * invw + eps);
+        const float rstd = norm ? rsqrtf(wave_sum(q) * invw + eps) : 1.f;
         int orow = row;
         if (remap_T > 0) { const int b = row / remap_T, t = row % remap_T; orow = t * remap_Bp + b; }
 #pragma unroll
@@ -293,10 +304,11 @@ __global__ __launch_bounds__(256) void layernorm_act_bwd_vec_kernel(
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     float gm[VPL], bt[VPL], dga[VPL], dba[VPL];
-    ldv<VPL>(gamma + lane * VPL, gm);
-    ldv<VPL>(beta + lane * VPL, bt);
+    const bool norm = !(act & LOB_LN_IDENTITY);
+    act &= 0xff;
+    if (norm) { ldv<VPL>(gamma + lane * VPL, gm); ldv<VPL>(beta + lane * VPL, bt); }
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) { dga[i] = 0.f; dba[i] = 0.f; }
+    for (int i = 0; i < VPL; ++i) { dga[i] = 0.f; dba[i] = 0.f; if (!norm) { gm[i] = 1.f; bt[i] = 0.f; } }
     const float invw = 1.0f / (float)width;
     for (int row = wave; row < rows; row += nwaves) {
         int orow = row;
@@ -317,11 +329,11 @@ __global__ __launch_bounds__(256) void layernorm_act_bwd_vec_kernel(
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) s += v[i];
-        const float mean = wave_sum(s) * invw;
+        const float mean = norm ? wave_sum(s) * invw : 0.f;
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) { const float dl = v[i] - mean; q += dl * dl; }
-        const float rstd = rsqrtf(wave_sum(q) * invw + eps);
+        const float rstd = norm ? rsqrtf(wave_sum(q) * invw + eps) : 1.f;
         float m1 = 0.f, m2 = 0.f;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
@@ -335,8 +347,8 @@ __global__ __launch_bounds__(256) void layernorm_act_bwd_vec_kernel(
             v[i] = xh; go[i] = dxh;
             m1 += dxh; m2 += dxh * xh;
         }
-        m1 = wave_sum(m1) * invw;
-        m2 = wave_sum(m2) * invw;
+        m1 = norm ? wave_sum(m1) * invw : 0.f;
+        m2 = norm ? wave_sum(m2) * invw : 0.f;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) v[i] = rstd * (go[i] - m1 - v[i] * m2);
         stv<VPL>(dx + (size_t)row * width + lane * VPL, v);
@@ -345,6 +357,7 @@ __global__ __launch_bounds__(256) void layernorm_act_bwd_vec_kernel(
 #pragma unroll
     for (int i = 0; i < VPL; ++i) { red[0][wib][lane * VPL + i] = dga[i]; red[1][wib][lane * VPL + i] = dba[i]; }
     __syncthreads();
+    if (!norm) return;
     for (int c = threadIdx.x; c < width; c += 256) {
         atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
         atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
@@ -369,6 +382,14 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(
     for (int t = tid; t < T; t += 256) a[t] = attn[(size_t)b * T + t];
     for (int c = tid; c < W; c += 256) dc[c] = dctx[(size_t)b * W + c];
     __syncthreads();
+    if (!U) {            // mean pooling: the weights do not depend on anything -> dV = a[t] * dctx only
+        for (int c = tid; c < W; c += 256) {
+            const float g = dc[c];
+            float* o = dV + (size_t)b * W + c;
+            for (int t = 0; t < T; ++t) o[(size_t)t * Bp * W] = a[t] * g;
+        }
+        return;
+    }
     for (int t = wave; t < T; t += 4) {
         const VE* v = V + ((size_t)t * Bp + b) * W;
         float s = 0.f;
@@ -422,7 +443,8 @@ extern "C" int lob_layernorm_act_f32(const float* in, const float* gamma, const 
                                      void* out, int out_bf16, int rows, int width, float eps, int act,
                                      int remap_T, int remap_B, int remap_Bp,
                                      float drop_p, uint64_t seed, void* stream) {
-    if (!in || !gamma || !beta || !out || rows <= 0 || width <= 0) return LOB_E_ARG;
+    const bool ident = (act & LOB_LN_IDENTITY) != 0;
+    if (!in || !out || rows <= 0 || width <= 0 || (!ident && (!gamma || !beta))) return LOB_E_ARG;
     if (width > 64 * LN_MAX_PER_LANE) return LOB_E_SHAPE;
     if (drop_p < 0.f || drop_p >= 1.f) return LOB_E_ARG;
     if (remap_T > 0 && (remap_B <= 0 || remap_Bp < remap_B || rows != remap_T * remap_B)) return LOB_E_SHAPE;
@@ -451,7 +473,8 @@ extern "C" int lob_layernorm_act_f32(const float* in, const float* gamma, const 
 extern "C" int lob_attn_pool_fwd_f32(const void* V, int v_bf16, const float* U, const float* w2, const float* b2,
                                      float* ctx, float* attn, int T, int B, int Bp, int W, int W2,
                                      void* stream) {
-    if (!V || !U || !w2 || !ctx || !attn || T <= 0 || B <= 0 || Bp < B || W <= 0 || W2 <= 0) return LOB_E_ARG;
+    if (!V || !ctx || !attn || T <= 0 || B <= 0 || Bp < B || W <= 0) return LOB_E_ARG;
+    if (U && (!w2 || W2 <= 0)) return LOB_E_ARG;
     if ((size_t)T * sizeof(float) > 60 * 1024) return LOB_E_SHAPE;
     if (v_bf16)
         hipLaunchKernelGGL((attn_pool_fwd_kernel<__bf16>), dim3(B), dim3(256), (size_t)T * sizeof(float), (hipStream_t)stream,
@@ -494,7 +517,9 @@ extern "C" int lob_layernorm_act_bwd_f32(const float* x, const float* gamma, con
                                          int act, int remap_T, int remap_B, int remap_Bp, float drop_p,
                                          uint64_t seed, const float* pool_attn, const float* pool_dctx,
                                          int pool_T, int pool_B, int pool_Bp, void* stream) {
-    if (!x || !gamma || !beta || !dy || !dx || !dgamma || !dbeta || rows <= 0 || width <= 0) return LOB_E_ARG;
+    const bool ident = (act & LOB_LN_IDENTITY) != 0;
+    if (!x || !dy || !dx || rows <= 0 || width <= 0) return LOB_E_ARG;
+    if (!ident && (!gamma || !beta || !dgamma || !dbeta)) return LOB_E_ARG;
     if (width > 64 * LN_MAX_PER_LANE) return LOB_E_SHAPE;
     if (drop_p < 0.f || drop_p >= 1.f) return LOB_E_ARG;
     if (remap_T > 0 && (remap_B <= 0 || remap_Bp < remap_B || rows != remap_T * remap_B)) return LOB_E_SHAPE;
@@ -523,8 +548,9 @@ extern "C" int lob_layernorm_act_bwd_f32(const float* x, const float* gamma, con
 extern "C" int lob_attn_pool_bwd_f32(const void* V, int v_bf16, const float* U, const float* attn, const float* dctx,
                                      const float* w2, float* dV, void* dPreU, int du_bf16, float* dw2,
                                      int T, int B, int Bp, int W, int W2, void* stream) {
-    if (!V || !U || !attn || !dctx || !w2 || !dPreU || !dw2) return LOB_E_ARG;
-    if (T <= 0 || B <= 0 || Bp < B || W <= 0 || W2 <= 0) return LOB_E_ARG;
+    if (!V || !attn || !dctx) return LOB_E_ARG;
+    if (U ? (!w2 || !dPreU || !dw2 || W2 <= 0) : !dV) return LOB_E_ARG;
+    if (T <= 0 || B <= 0 || Bp < B || W <= 0) return LOB_E_ARG;
     const size_t smem = ((size_t)2 * T + W) * sizeof(float);
     if (smem > 60 * 1024) return LOB_E_SHAPE;
 #define LOB_APB(VE, UE) hipLaunchKernelGGL((attn_pool_bwd_kernel<VE, UE>), dim3(B), dim3(256), smem, (hipStream_t)stream, \

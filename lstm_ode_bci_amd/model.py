@@ -111,3 +111,23 @@ class EnhancedLSTMModel(nn.Module):
         if return_attention:
             return logits, attn
         return logits
+
+
+class AblationLSTMModel(EnhancedLSTMModel):
+    """The configurable variant used by the ablation study (09_sensitivity_analysis.py:176-242): same pipeline,
+    ``use_attention=False`` pools by the mean over time, ``use_layer_norm=False`` replaces both LayerNorms by
+    nn.Identity.  ``forward(x)`` returns the logits only (09:226-242); state_dict keys match the reference's."""
+
+    def __init__(self, input_size=61, hidden_size=256, num_layers=3, num_classes=2, dropout=0.4,
+                 bidirectional=True, use_attention=True, use_layer_norm=True):
+        super().__init__(input_size=input_size, hidden_size=hidden_size, num_layers=num_layers,
+                         num_classes=num_classes, dropout=dropout, bidirectional=bidirectional)
+        self.use_attention = use_attention
+        if not use_layer_norm:
+            self.input_proj[1] = nn.Identity()
+            self.layer_norm = nn.Identity()
+        if not use_attention:
+            self.attention = None
+
+    def forward(self, x):
+        return super().forward(x, return_attention=False)

@@ -10,6 +10,7 @@ import torch
 from . import _lib
 
 ACT_NONE, ACT_TANH, ACT_GELU = 0, 1, 2
+LN_IDENTITY = 0x200          # LOB_LN_IDENTITY: OR into `act` of the LayerNorm entry points
 
 
 def _stream():
@@ -176,6 +177,8 @@ def layernorm_act(x, gamma, beta, act=ACT_NONE, eps=1e-5, remap=None, drop_p=0.0
     """LN(+act, +dropout) over the last axis of x[rows, width]; remap=(T, B, Bp) relays rows
     (b,t) -> t*Bp + b (out must then have T*Bp rows; pad rows are left untouched)."""
     _chk(x, "x"); _chk(gamma, "gamma"); _chk(beta, "beta")
+    if gamma is None:            # nn.Identity in place of the LayerNorm (09_sensitivity_analysis.py:190, 209)
+        act = act | LN_IDENTITY
     rows, width = x.shape
     out_bf16 = bool(out_bf16) and width in (128, 256, 512)
     odt = torch.bfloat16 if out_bf16 else torch.float32
@@ -206,9 +209,10 @@ def dropout(x, p, seed, out=None):
 
 
 def attn_pool_fwd(v, u, w2, b2, T, B, Bp):
+    """u=None: uniform weights 1/T (mean pooling over time, 09_sensitivity_analysis.py:236)."""
     v16 = v.dtype == torch.bfloat16
     _chk(v, "v", v.dtype if v16 else torch.float32); _chk(u, "u"); _chk(w2, "w2"); _chk(b2, "b2")
-    W, W2 = v.shape[1], u.shape[1]
+    W, W2 = v.shape[1], (u.shape[1] if u is not None else 0)
     ctx = torch.empty((B, W), device=v.device, dtype=torch.float32)
     attn = torch.empty((B, T), device=v.device, dtype=torch.float32)
     rc = _lib.lib().lob_attn_pool_fwd_f32(_ptr(v), int(v16), _ptr(u), _ptr(w2), _ptr(b2), _ptr(ctx), _ptr(attn),
@@ -313,8 +317,12 @@ def layernorm_act_bwd(x, gamma, beta, dy, act=ACT_NONE, eps=1e-5, remap=None, dr
     rows, width = x.shape
     rT, rB, rBp = (0, 0, 0) if remap is None else remap
     dx = torch.empty_like(x)
-    dg = torch.zeros_like(gamma)
-    db = torch.zeros_like(beta)
+    if gamma is None:            # identity "LayerNorm": dx = dy * act' * mask, no affine gradients
+        act = act | LN_IDENTITY
+        dg = db = None
+    else:
+        dg = torch.zeros_like(gamma)
+        db = torch.zeros_like(beta)
     pa, pd, pT, pB, pBp = (None, None, 0, 0, 0) if pool is None else pool
     rc = _lib.lib().lob_layernorm_act_bwd_f32(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(dy), _ptr(dx), _ptr(dg), _ptr(db),
                                               rows, width, eps, act, rT, rB, rBp, float(drop_p), C.c_uint64(seed),
@@ -328,8 +336,15 @@ def attn_pool_bwd(v, u, attn, dctx, w2, T, B, Bp, want_dv=True, du_bf16=False):
     want_dv=False: the direct term a[t]*dctx is left to layernorm_act_bwd(pool=...)."""
     v16 = v.dtype == torch.bfloat16
     _chk(v, "v", v.dtype if v16 else torch.float32); _chk(u, "u"); _chk(attn, "attn"); _chk(dctx, "dctx"); _chk(w2, "w2")
-    W, W2 = v.shape[1], u.shape[1]
+    W = v.shape[1]
     alloc = torch.zeros if Bp != B else torch.empty
+    if u is None:                # mean pooling: dV = dctx / T only
+        dV = alloc((T * Bp, W), device=v.device, dtype=torch.float32)
+        rc = _lib.lib().lob_attn_pool_bwd_f32(_ptr(v), int(v16), None, _ptr(attn), _ptr(dctx), None, _ptr(dV), None, 0,
+                                              None, T, B, Bp, W, 0, _stream())
+        _lib.check(rc, "lob_attn_pool_bwd_f32")
+        return dV, None, None
+    W2 = u.shape[1]
     dV = alloc((T * Bp, W), device=v.device, dtype=torch.float32) if want_dv else None
     dU = alloc((T * Bp, W2), device=v.device, dtype=torch.bfloat16 if du_bf16 else torch.float32)
     dw2 = torch.zeros((W2,), device=v.device, dtype=torch.float32)
@@ -337,3 +352,60 @@ def attn_pool_bwd(v, u, attn, dctx, w2, T, B, Bp, want_dv=True, du_bf16=False):
                                           _ptr(dU), int(du_bf16), _ptr(dw2), T, B, Bp, W, W2, _stream())
     _lib.check(rc, "lob_attn_pool_bwd_f32")
     return dV, dU, dw2
+
+
+# ---------------------------------------------------------------------------------------------
+# training-step and attribution wrappers (csrc/train_step.hip)
+# ---------------------------------------------------------------------------------------------
+def weighted_ce(logits, target, class_weight=None, scale=1.0, want_grad=True):
+    """nn.CrossEntropyLoss(weight) 'mean' (04_lstm_model.py:435): returns (loss[1], dlogits*scale or None,
+    correct[1] int32), all on the device (no sync)."""
+    _chk(logits, "logits"); _chk(target, "target", torch.int64); _chk(class_weight, "class_weight")
+    B, Cn = logits.shape
+    assert target.shape == (B,) and (class_weight is None or class_weight.shape == (Cn,))
+    loss = torch.empty((1,), device=logits.device, dtype=torch.float32)
+    dl = torch.empty_like(logits) if want_grad else None
+    correct = torch.empty((1,), device=logits.device, dtype=torch.int32)
+    rc = _lib.lib().lob_weighted_ce_f32(_ptr(logits), _ptr(target), _ptr(class_weight), _ptr(loss), _ptr(dl),
+                                        _ptr(correct), B, Cn, float(scale), _stream())
+    _lib.check(rc, "lob_weighted_ce_f32")
+    return loss, dl, correct
+
+
+def sumsq(x, out=None):
+    """out[0] += sum x^2 over a flat fp32 buffer."""
+    _chk(x, "x")
+    if out is None:
+        out = torch.zeros((1,), device=x.device, dtype=torch.float32)
+    rc = _lib.lib().lob_sumsq_f32(_ptr(x), x.numel(), _ptr(out), _stream())
+    _lib.check(rc, "lob_sumsq_f32")
+    return out
+
+
+def clip_scale_(g, normsq, max_norm):
+    _chk(g, "g"); _chk(normsq, "normsq")
+    rc = _lib.lib().lob_clip_scale_f32(_ptr(g), g.numel(), _ptr(normsq), float(max_norm), _stream())
+    _lib.check(rc, "lob_clip_scale_f32")
+    return g
+
+
+def adamw_(p, g, m, v, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, normsq=None, max_norm=1.0,
+           grad_scale=1.0):
+    for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _chk(t, n)
+    _chk(normsq, "normsq")
+    assert p.numel() == g.numel() == m.numel() == v.numel()
+    rc = _lib.lib().lob_adamw_f32(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), float(betas[0]),
+                                  float(betas[1]), float(eps), float(weight_decay), int(step), _ptr(normsq),
+                                  float(max_norm), float(grad_scale), _stream())
+    _lib.check(rc, "lob_adamw_f32")
+
+
+def abs_colsum(gx2d, out, scale=1.0):
+    """out[C] += scale * sum_rows |gx2d[row, :]|."""
+    _chk(gx2d, "gx"); _chk(out, "out")
+    rows, Cn = gx2d.shape
+    assert out.shape == (Cn,)
+    rc = _lib.lib().lob_abs_colsum_f32(_ptr(gx2d), rows, Cn, float(scale), _ptr(out), _stream())
+    _lib.check(rc, "lob_abs_colsum_f32")
+    return out

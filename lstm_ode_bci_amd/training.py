@@ -1,0 +1,378 @@
+"""The steps either side of fwd+bwd in the reference's training loops, on the device.
+
+* :class:`WeightedCrossEntropy` -- ``nn.CrossEntropyLoss(weight=class_weights)`` (04_lstm_model.py:430-435):
+  one launch gives the loss, its gradient and the correct-prediction count.
+* :class:`FusedAdamW` -- ``optim.AdamW`` (04:438) over ONE flat parameter / gradient / moment buffer: the
+  parameters and their ``.grad`` are re-pointed to views of the flat buffers, so ``clip_grad_norm_`` + ``step`` of
+  the reference (04:501-502) are two launches (sum of squares, fused clip + AdamW) with no host round trip, and a
+  data-parallel run all-reduces ``flat_grad`` as one 4.5 MB message.
+* :func:`warmup_cosine` (04:441-448), :class:`DeviceWindowLoader` (04:336-402 with the windows resident in HBM),
+  :func:`train_model` (04:406-596), :func:`quick_train_evaluate` / :func:`run_architecture_ablation`
+  (09_sensitivity_analysis.py:265-378).
+
+Mixed precision: the reference trains under ``autocast()`` + ``GradScaler`` (fp16, 04:487-503).  Here the policy is
+bf16 MFMA inputs with fp32 accumulation and state: bf16 has the fp32 exponent range, so there is
+no loss scaling and no skipped steps.
+"""
+from __future__ import annotations
+
+import math
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .model import AblationLSTMModel
+
+
+# ---------------------------------------------------------------------------------------------
+# loss
+# ---------------------------------------------------------------------------------------------
+class _WeightedCEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, weight):
+        loss, dl, correct = ops.weighted_ce(logits.detach().float().contiguous(), target.contiguous(), weight,
+                                            want_grad=ctx.needs_input_grad[0])
+        ctx.dl = dl
+        ctx.mark_non_differentiable(correct)
+        return loss.reshape(()), correct
+
+    @staticmethod
+    def backward(ctx, gloss, _gc):
+        return ctx.dl * gloss, None, None
+
+
+class WeightedCrossEntropy(nn.Module):
+    """``criterion(outputs, y)`` of 04_lstm_model.py:435/489 (reduction 'mean' with class weights).  The count of
+    correct predictions of the last call (04:508-509) is left on the device in ``last_correct``."""
+
+    def __init__(self, weight=None):
+        super().__init__()
+        self.register_buffer("weight", None if weight is None else torch.as_tensor(weight, dtype=torch.float32))
+        self.last_correct = None
+
+    def forward(self, logits, target):
+        if not logits.is_cuda:
+            raise ops._lib.LobError("WeightedCrossEntropy: logits must be on the GPU (no CPU fallback)")
+        with torch.autocast(device_type="cuda", enabled=False):
+            loss, self.last_correct = _WeightedCEFn.apply(logits, target, self.weight)
+        return loss
+
+
+def class_weights_from_labels(y_train):
+    """04:430-432: inverse class frequency, normalised to sum 2."""
+    counts = np.bincount(np.asarray(y_train))
+    w = np.array([1.0 / c for c in counts], dtype=np.float32)
+    return w / w.sum() * np.float32(2.0)
+
+
+def warmup_cosine(current_epoch, warmup_epochs, epochs):
+    """``lr_lambda`` of 04:441-448."""
+    if current_epoch < warmup_epochs:
+        return (current_epoch + 1) / warmup_epochs
+    progress = (current_epoch - warmup_epochs) / (epochs - warmup_epochs)
+    return 0.5 * (1 + np.cos(np.pi * progress))
+
+
+# ---------------------------------------------------------------------------------------------
+# optimizer
+# ---------------------------------------------------------------------------------------------
+class FusedAdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW semantics (04:438) on flat buffers; a torch Optimizer, so LambdaLR (04:450) drives its
+    ``param_groups[0]['lr']``.  Construct it AFTER ``model.to(device)``: it re-points ``p.data`` / ``p.grad``."""
+
+    _ALIGN = 64        # floats: every tensor starts on a 256-B boundary of the flat buffers
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        if len(self.param_groups) != 1:
+            raise ValueError("FusedAdamW: one parameter group (the reference uses model.parameters())")
+        ps = self.param_groups[0]["params"]
+        if not ps or not all(p.is_cuda and p.dtype == torch.float32 for p in ps):
+            raise ops._lib.LobError("FusedAdamW: fp32 parameters on the GPU (no CPU fallback)")
+        dev = ps[0].device
+        self._offsets, total = [], 0
+        for p in ps:
+            self._offsets.append(total)
+            total += (p.numel() + self._ALIGN - 1) // self._ALIGN * self._ALIGN
+        self.flat_param = torch.zeros(total, device=dev)
+        self.flat_grad = torch.zeros(total, device=dev)
+        self.exp_avg = torch.zeros(total, device=dev)
+        self.exp_avg_sq = torch.zeros(total, device=dev)
+        self._normsq = torch.zeros(1, device=dev)
+        self.step_count = 0
+        with torch.no_grad():
+            for p, off in zip(ps, self._offsets):
+                view = self.flat_param[off:off + p.numel()].view_as(p)
+                view.copy_(p.data)
+                p.data = view
+        self._attach_grads()
+
+    def _grad_view(self, p, off):
+        return self.flat_grad[off:off + p.numel()].view_as(p)
+
+    def _attach_grads(self):
+        """Make every p.grad the view of flat_grad.  A foreign gradient tensor (autograd assigns one when p.grad
+        was None, e.g. after model.zero_grad()) is copied in; a missing gradient counts as zero."""
+        for p, off in zip(self.param_groups[0]["params"], self._offsets):
+            view = self._grad_view(p, off)
+            if p.grad is None:
+                view.zero_()
+            elif p.grad.data_ptr() != view.data_ptr():
+                view.copy_(p.grad)
+            else:
+                continue
+            p.grad = view
+
+    def zero_grad(self, set_to_none=False):
+        """One memset; the gradients stay views of ``flat_grad`` (set_to_none is accepted and ignored)."""
+        self.flat_grad.zero_()
+        for p, off in zip(self.param_groups[0]["params"], self._offsets):
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * off:
+                p.grad = self._grad_view(p, off)
+
+    def grad_norm_sq(self):
+        self._attach_grads()
+        self._normsq.zero_()
+        return ops.sumsq(self.flat_grad, self._normsq)
+
+    def clip_grad_norm_(self, max_norm=1.0):
+        """torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm) in place (04:501); returns the total norm
+        as a device tensor."""
+        nsq = self.grad_norm_sq()
+        total = nsq.sqrt()
+        ops.clip_scale_(self.flat_grad, nsq, max_norm)
+        return total.reshape(())
+
+    @torch.no_grad()
+    def step(self, closure=None, clip_grad_norm=None, grad_scale=1.0):
+        """One AdamW step.  ``clip_grad_norm=m`` folds ``clip_grad_norm_(params, m)`` into the same launch (the
+        gradients themselves are left unclipped); ``grad_scale`` multiplies the gradient first (e.g. 1/world)."""
+        if closure is not None:
+            raise ValueError("FusedAdamW.step: closures are not supported")
+        g = self.param_groups[0]
+        nsq = self.grad_norm_sq() if clip_grad_norm is not None else None
+        if nsq is None:
+            self._attach_grads()
+        self.step_count += 1
+        ops.adamw_(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.step_count, g["lr"],
+                   g["betas"], g["eps"], g["weight_decay"], normsq=nsq,
+                   max_norm=clip_grad_norm if clip_grad_norm is not None else 1.0, grad_scale=grad_scale)
+
+
+# ---------------------------------------------------------------------------------------------
+# data: windows resident in HBM
+# ---------------------------------------------------------------------------------------------
+class DeviceWindowLoader:
+    """Batches of ``(X (b,T,C) f32, y (b,) int64)`` gathered on the device from tensors resident in HBM.
+
+    ``sampling='weighted'``: class-balanced sampling with replacement, ``len(y)`` draws per epoch
+    (WeightedRandomSampler, 04:358-367); ``'shuffle'``: a fresh permutation per epoch (09:287);
+    ``'sequential'``: in order (validation / test loaders, 04:383-396)."""
+
+    def __init__(self, X, y, batch_size, sampling="sequential", device="cuda"):
+        # torch.FloatTensor(X) / torch.LongTensor(y) of 04:346-351: the cast happens on the host, so half the bytes
+        # of a float64 .npz cross PCIe
+        self.X = torch.as_tensor(np.asarray(X, dtype=np.float32)).to(device) if not torch.is_tensor(X) else X.to(device).float()
+        self.y = torch.as_tensor(np.asarray(y, dtype=np.int64)).to(device) if not torch.is_tensor(y) else y.to(device).long()
+        self.batch_size, self.sampling = int(batch_size), sampling
+        if sampling == "weighted":
+            counts = torch.bincount(self.y).float()
+            self._w = (1.0 / counts)[self.y]
+        elif sampling not in ("shuffle", "sequential"):
+            raise ValueError(sampling)
+
+    def __len__(self):
+        return (len(self.y) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        n = len(self.y)
+        if self.sampling == "weighted":
+            order = torch.multinomial(self._w, n, replacement=True)
+        elif self.sampling == "shuffle":
+            order = torch.randperm(n, device=self.y.device)
+        else:
+            order = None
+        for s in range(0, n, self.batch_size):
+            if order is None:
+                yield self.X[s:s + self.batch_size], self.y[s:s + self.batch_size]
+            else:
+                idx = order[s:s + self.batch_size]
+                yield self.X.index_select(0, idx), self.y.index_select(0, idx)
+
+
+def create_dataloaders(X_train, y_train, X_val, y_val, X_test, y_test, batch_size=512, val_batch_size=1024,
+                       device="cuda"):
+    """04:336-402 with device-resident data: (train_loader, val_loader, test_loader)."""
+    return (DeviceWindowLoader(X_train, y_train, batch_size, "weighted", device),
+            DeviceWindowLoader(X_val, y_val, val_batch_size, "sequential", device),
+            DeviceWindowLoader(X_test, y_test, val_batch_size, "sequential", device))
+
+
+# ---------------------------------------------------------------------------------------------
+# harness
+# ---------------------------------------------------------------------------------------------
+def binary_f1(true, pred):
+    """sklearn.metrics.f1_score(true, pred, zero_division=0) for labels {0, 1} (04:547)."""
+    true, pred = np.asarray(true), np.asarray(pred)
+    tp = int(((pred == 1) & (true == 1)).sum())
+    fp = int(((pred == 1) & (true == 0)).sum())
+    fn = int(((pred == 0) & (true == 1)).sum())
+    return 0.0 if 2 * tp + fp + fn == 0 else 2 * tp / (2 * tp + fp + fn)
+
+
+def _to_dev(t, dev):
+    return t.to(dev, non_blocking=True) if t.device != dev else t
+
+
+def train_model(model, train_loader, val_loader, y_train, epochs=100, learning_rate=3e-4, patience=15,
+                weight_decay=1e-4, warmup_epochs=5, gradient_accumulation_steps=4, use_amp=True, verbose=True):
+    """``train_model`` of 04_lstm_model.py:406-596: same arguments, same ``(model, history)`` result, same
+    arithmetic -- weighted CE / accumulation steps, clip at 1.0, AdamW, warm-up + cosine stepped per epoch,
+    early stopping on validation F1.  ``use_amp`` selects the mixed path (bf16 autocast, no GradScaler).
+
+    As in the reference the "best model" snapshot is a shallow ``state_dict().copy()`` (04:576), i.e. the model
+    that is returned carries the weights of the last epoch that ran."""
+    dev = next(model.parameters()).device
+    start_time = time.time()
+    criterion = WeightedCrossEntropy(class_weights_from_labels(y_train)).to(dev)
+    optimizer = FusedAdamW(model.parameters(), lr=learning_rate, weight_decay=weight_decay)
+    scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lambda e: warmup_cosine(e, warmup_epochs, epochs))
+    acc_steps = gradient_accumulation_steps
+    best_val_f1, best_state, stale = 0, None, 0
+    history = {k: [] for k in ("train_loss", "val_loss", "train_acc", "val_acc", "val_f1", "learning_rates")}
+
+    def amp():
+        return torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=bool(use_amp))
+
+    for epoch in range(epochs):
+        epoch_start = time.time()
+        model.train()
+        loss_sum = torch.zeros((), device=dev)
+        correct = torch.zeros((), device=dev, dtype=torch.int64)
+        total = 0
+        optimizer.zero_grad()
+        for batch_idx, (xb, yb) in enumerate(train_loader):
+            xb, yb = _to_dev(xb, dev), _to_dev(yb, dev)
+            with amp():
+                outputs = model(xb)
+                loss = criterion(outputs, yb) / acc_steps
+            loss.backward()
+            if (batch_idx + 1) % acc_steps == 0:
+                optimizer.step(clip_grad_norm=1.0)            # clip_grad_norm_(…, 1.0) + optimizer.step(), 04:501-502
+                optimizer.zero_grad()
+            loss_sum += loss.detach() * (acc_steps * xb.size(0))
+            correct += criterion.last_correct[0]
+            total += yb.size(0)
+        train_loss = float(loss_sum) / total
+        train_acc = int(correct) / total
+
+        model.eval()
+        vloss = torch.zeros((), device=dev)
+        vcorrect = torch.zeros((), device=dev, dtype=torch.int64)
+        vtotal, vpreds, vtrue = 0, [], []
+        with torch.no_grad():
+            for xb, yb in val_loader:
+                xb, yb = _to_dev(xb, dev), _to_dev(yb, dev)
+                with amp():
+                    outputs = model(xb)
+                    loss = criterion(outputs, yb)
+                vloss += loss * xb.size(0)
+                vcorrect += criterion.last_correct[0]
+                vtotal += yb.size(0)
+                vpreds.append(outputs.argmax(1))
+                vtrue.append(yb)
+        val_loss = float(vloss) / vtotal
+        val_acc = int(vcorrect) / vtotal
+        val_f1 = binary_f1(torch.cat(vtrue).cpu().numpy(), torch.cat(vpreds).cpu().numpy())
+
+        scheduler.step()
+        current_lr = optimizer.param_groups[0]["lr"]
+        for k, v in (("train_loss", train_loss), ("val_loss", val_loss), ("train_acc", train_acc),
+                     ("val_acc", val_acc), ("val_f1", val_f1), ("learning_rates", current_lr)):
+            history[k].append(v)
+        if verbose and ((epoch + 1) % 5 == 0 or epoch == 0 or epoch == warmup_epochs - 1):
+            print(f"Epoch [{epoch + 1:3d}/{epochs}] | Loss: {train_loss:.4f}/{val_loss:.4f} | "
+                  f"Acc: {train_acc:.4f}/{val_acc:.4f} | F1: {val_f1:.4f} | LR: {current_lr:.2e} | "
+                  f"Time: {time.time() - epoch_start:.1f}s", flush=True)
+        if val_f1 > best_val_f1:
+            best_val_f1, stale = val_f1, 0
+            best_state = model.state_dict().copy()
+        else:
+            stale += 1
+        if stale >= patience:
+            if verbose:
+                print(f"\nEarly stopping at epoch {epoch + 1} (no improvement for {patience} epochs)", flush=True)
+            break
+    if best_state is not None:
+        model.load_state_dict(best_state)
+    if verbose:
+        print(f"\nTraining completed in {(time.time() - start_time) / 60:.1f} minutes")
+        print(f"Best validation F1: {best_val_f1:.4f}", flush=True)
+    return model, history
+
+
+def _mcc(true, pred):
+    true, pred = np.asarray(true), np.asarray(pred)
+    tp = float(((pred == 1) & (true == 1)).sum()); tn = float(((pred == 0) & (true == 0)).sum())
+    fp = float(((pred == 1) & (true == 0)).sum()); fn = float(((pred == 0) & (true == 1)).sum())
+    den = math.sqrt((tp + fp) * (tp + fn) * (tn + fp) * (tn + fn))
+    return 0.0 if den == 0 else (tp * tn - fp * fn) / den
+
+
+def quick_train_evaluate(model, X_train, y_train, X_val, y_val, X_test, y_test, epochs=10, batch_size=512,
+                         lr=0.001, device="cuda"):
+    """09_sensitivity_analysis.py:265-327: a short un-weighted-CE / AdamW(lr) run on (at most) 20,000 random
+    training windows, then test metrics ``({'accuracy','f1','mcc'}, predictions)``."""
+    model = model.to(device)
+    n_train = min(len(X_train), 20000)
+    indices = np.random.choice(len(X_train), n_train, replace=False)
+    train_loader = DeviceWindowLoader(np.asarray(X_train)[indices], np.asarray(y_train)[indices], batch_size,
+                                      "shuffle", device)
+    test_loader = DeviceWindowLoader(X_test, y_test, batch_size * 2, "sequential", device)
+    criterion = WeightedCrossEntropy().to(device)
+    optimizer = FusedAdamW(model.parameters(), lr=lr)
+    model.train()
+    for _ in range(epochs):
+        for xb, yb in train_loader:
+            optimizer.zero_grad()
+            loss = criterion(model(xb), yb)
+            loss.backward()
+            optimizer.step()
+    model.eval()
+    preds = []
+    with torch.no_grad():
+        for xb, _ in test_loader:
+            preds.append(model(xb).argmax(dim=1))
+    preds = torch.cat(preds).cpu().numpy()
+    labels = np.asarray(y_test)
+    metrics = {"accuracy": float((preds == labels).mean()), "f1": binary_f1(labels, preds), "mcc": _mcc(labels, preds)}
+    return metrics, preds
+
+
+ABLATION_CONFIGS = [        # 09:340-347
+    {"name": "Full Model", "bidirectional": True, "use_attention": True, "num_layers": 3},
+    {"name": "No Attention", "bidirectional": True, "use_attention": False, "num_layers": 3},
+    {"name": "Unidirectional", "bidirectional": False, "use_attention": True, "num_layers": 3},
+    {"name": "1 Layer", "bidirectional": True, "use_attention": True, "num_layers": 1},
+    {"name": "2 Layers", "bidirectional": True, "use_attention": True, "num_layers": 2},
+    {"name": "Minimal", "bidirectional": False, "use_attention": False, "num_layers": 1},
+]
+
+
+def run_architecture_ablation(X_train, y_train, X_val, y_val, X_test, y_test, hidden_size=256, epochs=10,
+                              batch_size=512, device="cuda"):
+    """09:330-378: ``(results, predictions)`` keyed by configuration name."""
+    input_size = np.asarray(X_train).shape[2]
+    results, predictions = {}, {}
+    for config in ABLATION_CONFIGS:
+        model = AblationLSTMModel(input_size=input_size, hidden_size=hidden_size, num_layers=config["num_layers"],
+                                  num_classes=2, dropout=0.4, bidirectional=config["bidirectional"],
+                                  use_attention=config["use_attention"])
+        metrics, preds = quick_train_evaluate(model, X_train, y_train, X_val, y_val, X_test, y_test, epochs=epochs,
+                                              batch_size=batch_size, device=device)
+        results[config["name"]] = {"config": {k: v for k, v in config.items() if k != "name"}, "metrics": metrics}
+        predictions[config["name"]] = preds
+    return results, predictions

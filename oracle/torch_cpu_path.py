@@ -40,17 +40,19 @@ class TorchCpuModel(nn.Module):
     """Layer stack with the reference's state_dict keys (04_lstm_model.py:163-222)."""
 
     def __init__(self, input_size, hidden_size=128, num_layers=3, num_classes=2,
-                 dropout=0.4, bidirectional=True):
+                 dropout=0.4, bidirectional=True, use_attention=True, use_layer_norm=True):
         super().__init__()
         D = 2 if bidirectional else 1
+        # use_attention / use_layer_norm: the ablation variants of 09_sensitivity_analysis.py:176-242
+        # (mean pooling over time instead of attention; nn.Identity instead of both LayerNorms)
         self.input_proj = nn.Sequential(nn.Linear(input_size, hidden_size),
-                                        nn.LayerNorm(hidden_size), nn.GELU(),
-                                        nn.Dropout(dropout / 2))
+                                        nn.LayerNorm(hidden_size) if use_layer_norm else nn.Identity(),
+                                        nn.GELU(), nn.Dropout(dropout / 2))
         self.lstm = nn.LSTM(hidden_size, hidden_size, num_layers, batch_first=True,
                             dropout=dropout if num_layers > 1 else 0,
                             bidirectional=bidirectional)
-        self.layer_norm = nn.LayerNorm(hidden_size * D)
-        self.attention = _AdditiveAttention(hidden_size * D)
+        self.layer_norm = nn.LayerNorm(hidden_size * D) if use_layer_norm else nn.Identity()
+        self.attention = _AdditiveAttention(hidden_size * D) if use_attention else None
         self.classifier = nn.Sequential(
             nn.Linear(hidden_size * D, hidden_size), nn.GELU(), nn.Dropout(dropout),
             nn.Linear(hidden_size, hidden_size // 2), nn.GELU(), nn.Dropout(dropout),
@@ -60,7 +62,10 @@ class TorchCpuModel(nn.Module):
         a = self.input_proj(x)
         y, _ = self.lstm(a)
         v = self.layer_norm(y)
-        ctx, w = self.attention(v)
+        if self.attention is not None:
+            ctx, w = self.attention(v)
+        else:
+            ctx, w = v.mean(dim=1), torch.full(v.shape[:2], 1.0 / v.shape[1], dtype=v.dtype)
         logits = self.classifier(ctx)
         if return_all:
             return {"input_proj": a, "lstm": y, "layer_norm": v, "context": ctx,
@@ -69,8 +74,9 @@ class TorchCpuModel(nn.Module):
 
 
 def build(sd_numpy, input_size, hidden_size, num_layers=3, num_classes=2,
-          bidirectional=True, dropout=0.4, dtype=torch.float32):
-    m = TorchCpuModel(input_size, hidden_size, num_layers, num_classes, dropout, bidirectional)
+          bidirectional=True, dropout=0.4, dtype=torch.float32, use_attention=True, use_layer_norm=True):
+    m = TorchCpuModel(input_size, hidden_size, num_layers, num_classes, dropout, bidirectional,
+                      use_attention, use_layer_norm)
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd_numpy.items()},
                       strict=True)
     return m.to(dtype).eval()

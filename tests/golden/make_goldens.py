@@ -239,9 +239,105 @@ def g5_consumers(g6, g8, g10):
     print("g5 three_pred", out["three_pred_fitted"][:12], "fc", out["fc_pred_fitted_h20"][:3])
 
 
+def _silence():
+    import contextlib, io
+    return contextlib.redirect_stdout(io.StringIO())
+
+
+def g6_training(g4):
+    """04_lstm_model.py:406-596 train_model on a tiny model (dropout 0 -> deterministic): weighted CE, gradient
+    accumulation, clip 1.0, AdamW, warm-up + cosine.  Pins the harness arithmetic, incl. the last-epoch weights."""
+    from torch.utils.data import DataLoader, TensorDataset
+    C, H, T, L = 5, 8, 12, 3
+    sd = syn.make_state_dict(C, H, L, 2, True, seed=321, affine_jitter=0.1)
+    xtr, ytr = syn.make_windows(24, T, C, seed=61)
+    ytr[:5] = 1; ytr[5:9] = 0                      # both classes present, unbalanced
+    xva, yva = syn.make_windows(10, T, C, seed=62)
+    yva[:3] = 1; yva[3:6] = 0
+    m = g4["EnhancedLSTMModel"](input_size=C, hidden_size=H, num_layers=L, num_classes=2, dropout=0.0,
+                                bidirectional=True)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    tl = DataLoader(TensorDataset(torch.from_numpy(xtr), torch.from_numpy(ytr)), batch_size=4, shuffle=False)
+    vl = DataLoader(TensorDataset(torch.from_numpy(xva), torch.from_numpy(yva)), batch_size=5, shuffle=False)
+    kw = dict(epochs=4, learning_rate=5e-3, patience=50, weight_decay=1e-2, warmup_epochs=2,
+              gradient_accumulation_steps=2)
+    with _silence():
+        m, hist = g4["train_model"](m, tl, vl, ytr, **kw)
+    out = {"x_train": xtr, "y_train": ytr, "x_val": xva, "y_val": yva,
+           "kw_names": np.array(list(kw)), "kw_vals": np.array([float(v) for v in kw.values()])}
+    out.update({"w0:" + k: v for k, v in sd.items()})
+    out.update({"w1:" + k: v.detach().numpy().copy() for k, v in m.state_dict().items()})
+    out.update({"hist:" + k: np.array(v, dtype=np.float64) for k, v in hist.items()})
+    np.savez_compressed(os.path.join(HERE, "g6_training.npz"), **out)
+    print("g6 train_loss", hist["train_loss"], "lr", hist["learning_rates"])
+
+
+def g7_channel_importance(g7):
+    """07_explainability.py:203-285 compute_channel_importance (per-sample input gradients of the predicted
+    logit, |.| averaged over time, summed over samples, normalised)."""
+    C, H, T, L, N = 5, 8, 12, 3, 7
+    sd = syn.make_state_dict(C, H, L, 2, True, seed=77, affine_jitter=0.1)
+    x, _ = syn.make_windows(N, T, C, seed=71)
+    m = g7["EnhancedLSTMModel"](input_size=C, hidden_size=H, num_layers=L, num_classes=2, dropout=0.0,
+                                bidirectional=True)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    m.eval()
+    np.random.seed(0)
+    with _silence():
+        df = g7["compute_channel_importance"](m, x, n_samples=N, batch_size=3)
+    df = df.sort_index()                     # back to channel order
+    out = {"x": x, "importance": df["Importance"].to_numpy(np.float64), "channels": np.array(list(df["Channel"]))}
+    out.update({"w:" + k: v for k, v in sd.items()})
+    np.savez_compressed(os.path.join(HERE, "g7_channel_importance.npz"), **out)
+    print("g7", out["importance"])
+
+
+def g8_ablation(g9):
+    """09_sensitivity_analysis.py:176-242 AblationLSTMModel variants (mean pooling, no LayerNorm, uni-directional,
+    fewer layers): logits and gradients in eval mode."""
+    C, H, T, B = 5, 8, 12, 4
+    x, y = syn.make_windows(B, T, C, seed=81)
+    xt, yt = torch.from_numpy(x), torch.from_numpy(y)
+    out = {"x": x, "y": y}
+    variants = [("full", 3, True, True, True), ("noattn", 3, True, False, True), ("noln", 2, True, True, False),
+                ("minimal", 1, False, False, True), ("bare", 1, False, False, False)]
+    for name, L, bi, att, ln in variants:
+        sd = syn.make_state_dict(C, H, L, 2, bi, seed=800 + len(name), affine_jitter=0.1)
+        m = g9["AblationLSTMModel"](input_size=C, hidden_size=H, num_layers=L, num_classes=2, dropout=0.4,
+                                    bidirectional=bi, use_attention=att, use_layer_norm=ln)
+        keys = set(m.state_dict().keys())
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items() if k in keys}, strict=True)
+        m.eval()
+        m.zero_grad(set_to_none=True)
+        xg = xt.clone().requires_grad_(True)
+        logits = m(xg)
+        loss = torch.nn.functional.cross_entropy(logits, yt)
+        loss.backward()
+        out[f"{name}:cfg"] = np.array([L, int(bi), int(att), int(ln)])
+        out[f"{name}:logits"] = logits.detach().numpy()
+        out[f"{name}:loss"] = np.float64(loss.item())
+        out[f"{name}:grad_x"] = xg.grad.numpy().copy()
+        for k, v in sd.items():
+            if k in keys:
+                out[f"{name}:w:{k}"] = v
+        for k, p_ in m.named_parameters():
+            out[f"{name}:g:{k}"] = p_.grad.numpy().copy()
+        print("g8", name, logits.detach().numpy()[0])
+    np.savez_compressed(os.path.join(HERE, "g8_ablation.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
+    only = set(sys.argv[1:])
     g4 = load_ref("04_lstm_model.py")
+    if only:          # e.g. `make_goldens.py g6 g7 g8`: regenerate just those fixtures
+        if "g6" in only:
+            g6_training(g4)
+        if "g7" in only:
+            g7_channel_importance(load_ref("07_explainability.py"))
+        if "g8" in only:
+            g8_ablation(load_ref("09_sensitivity_analysis.py"))
+        sys.exit(0)
     g5 = load_ref("05_ode_model.py")
     g6 = load_ref("06_lstm_ode_integration.py")
     g1_tiny(g4)
@@ -249,3 +345,6 @@ if __name__ == "__main__":
     g3_ode(g5, g6)
     g4_coupled(g6)
     g5_consumers(g6, load_ref("08_forecasting.py"), load_ref("10_three_state_probabilities.py"))
+    g6_training(g4)
+    g7_channel_importance(load_ref("07_explainability.py"))
+    g8_ablation(load_ref("09_sensitivity_analysis.py"))

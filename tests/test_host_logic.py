@@ -139,3 +139,73 @@ def test_consumer_signatures():
     grid = np.load(os.path.join(GOLDEN, "g5_consumers.npz"))["fc_state_grid"]
     got = np.array([consumers.prob_to_ode_state(np.float32(p)) for p in np.linspace(0, 1, 21)])
     assert np.array_equal(got, grid)
+
+
+# ---- training / attribution host logic -----------------------------------
+def test_training_host_pieces_match_oracle_restatement():
+    from lstm_ode_bci_amd import training as TR
+    from oracle import train_harness as TH
+    y = np.array([0] * 13 + [1] * 5)
+    assert np.array_equal(TR.class_weights_from_labels(y), TH.class_weights(y))
+    assert abs(float(TR.class_weights_from_labels(y).sum()) - 2.0) < 1e-6
+    for epochs, warm in ((100, 5), (4, 2), (10, 1)):
+        for e in range(epochs + 1):
+            assert TR.warmup_cosine(e, warm, epochs) == TH.lr_factor(e, warm, epochs)
+    assert TR.warmup_cosine(0, 5, 100) == 0.2 and TR.warmup_cosine(4, 5, 100) == 1.0
+    assert abs(TR.warmup_cosine(100, 5, 100)) < 1e-12
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        t, p = rng.integers(0, 2, 17), rng.integers(0, 2, 17)
+        assert TR.binary_f1(t, p) == TH.binary_f1(t, p)
+    assert TR.binary_f1([0, 0], [0, 0]) == 0.0
+    assert [c["name"] for c in TR.ABLATION_CONFIGS] == ["Full Model", "No Attention", "Unidirectional", "1 Layer",
+                                                         "2 Layers", "Minimal"]
+    assert list(inspect.signature(TR.train_model).parameters)[:10] == [
+        "model", "train_loader", "val_loader", "y_train", "epochs", "learning_rate", "patience", "weight_decay",
+        "warmup_epochs", "gradient_accumulation_steps"]
+
+
+def test_device_window_loader_semantics_on_cpu_tensors():
+    from lstm_ode_bci_amd.training import DeviceWindowLoader
+    X = np.arange(10 * 2 * 3, dtype=np.float64).reshape(10, 2, 3)       # float64 as in processed_sequences.npz
+    y = np.array([0, 0, 0, 0, 0, 0, 0, 0, 1, 1])
+    seq = DeviceWindowLoader(X, y, 4, "sequential", "cpu")
+    bs = list(seq)
+    assert len(seq) == 3 and [len(b[1]) for b in bs] == [4, 4, 2] and bs[0][0].dtype == torch.float32
+    assert torch.equal(torch.cat([b[0] for b in bs]), torch.from_numpy(X).float())
+    torch.manual_seed(0)
+    sh = DeviceWindowLoader(X, y, 4, "shuffle", "cpu")
+    ys = torch.cat([b[0][:, 0, 0] for b in sh])
+    assert sorted(ys.tolist()) == sorted(X[:, 0, 0].tolist())           # a permutation
+    wl = DeviceWindowLoader(np.repeat(X, 100, 0), np.repeat(y, 100), 250, "weighted", "cpu")
+    frac = torch.cat([b[1] for b in wl]).float().mean().item()
+    assert 0.4 < frac < 0.6                                              # class-balanced draws (04:358-367)
+
+
+def test_training_and_attribution_refuse_cpu():
+    from lstm_ode_bci_amd import AblationLSTMModel, _lib
+    from lstm_ode_bci_amd.attribution import input_gradients
+    from lstm_ode_bci_amd.training import FusedAdamW, WeightedCrossEntropy
+    m = AblationLSTMModel(5, 8, 1, 2, 0.4, False, use_attention=False, use_layer_norm=False)
+    assert "attention.attention.0.weight" not in m.state_dict() and "layer_norm.weight" not in m.state_dict()
+    with pytest.raises(_lib.LobError):
+        FusedAdamW(m.parameters())
+    with pytest.raises(_lib.LobError):
+        WeightedCrossEntropy()(torch.zeros(2, 2), torch.zeros(2, dtype=torch.long))
+    with pytest.raises(_lib.LobError):
+        input_gradients(m, torch.zeros(2, 12, 5))
+
+
+def test_load_processed_sequences_formats(tmp_path):
+    from lstm_ode_bci_amd.artifacts import load_processed_sequences
+    rng = np.random.default_rng(1)
+    X, y = rng.standard_normal((40, 4, 3)), rng.integers(0, 2, 40)
+    np.savez_compressed(tmp_path / "a.npz", X_train=X, y_train=y, X_val=X[:5], y_val=y[:5], X_test=X[:7], y_test=y[:7])
+    out = load_processed_sequences(tmp_path / "a.npz")
+    assert [len(a) for a in out] == [40, 40, 5, 5, 7, 7]
+    np.savez_compressed(tmp_path / "b.npz", X_train=X, y_train=y, X_val=np.array([]), y_val=np.array([]),
+                        X_test=X[:7], y_test=y[:7])                     # 02_preprocessing.py:403-404
+    np.random.seed(0)
+    Xt, yt, Xv, yv, _, _ = load_processed_sequences(tmp_path / "b.npz")
+    assert len(Xv) == 6 and len(Xt) == 34 and len(yv) == 6
+    assert sorted(np.concatenate([Xt, Xv])[:, 0, 0].tolist()) == sorted(X[:, 0, 0].tolist())
