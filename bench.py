@@ -235,7 +235,13 @@ def main():
     class_w = torch.tensor([1.0, 1.0], device=dev)
     integ = LSTMODEIntegration(model, CognitiveStateODE(), 0.5)
     gather_buf = torch.empty((world * B, 2), device=dev) if world > 1 else None
-    params = [p for p in model.parameters()]
+    criterion = opt = None
+    if mode == "train":
+        # the reference's training-step body (04_lstm_model.py:482-512): fwd -> weighted CE -> bwd ->
+        # [data-parallel: all-reduce of the flat gradient] -> clip 1.0 + AdamW, all inside the timed step
+        from lstm_ode_bci_amd.training import FusedAdamW, WeightedCrossEntropy
+        criterion = WeightedCrossEntropy(class_w).to(dev)
+        opt = FusedAdamW(model.parameters(), lr=3e-4, weight_decay=1e-4)
 
     def step():
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(precision == "mixed")):
@@ -244,14 +250,12 @@ def main():
     def _step():
         if mode == "train":
             model.train()
-            for p in params:
-                p.grad = None
-            logits = model(x)
-            loss = torch.nn.functional.cross_entropy(logits.float(), y, weight=class_w)
+            opt.zero_grad()
+            loss = criterion(model(x), y)
             loss.backward()
             if world > 1:
-                flat = torch.cat([p.grad.reshape(-1) for p in params])
-                dist.all_reduce(flat)
+                dist.all_reduce(opt.flat_grad)
+            opt.step(clip_grad_norm=1.0, grad_scale=1.0 / world)
         elif mode == "fwd":
             model.eval()
             with torch.no_grad():
@@ -302,6 +306,8 @@ def main():
                                    + (f", RK4 ODE {a.forecast_steps} points" if mode == "coupled" else ""),
                        "batch_per_gpu": B, "global_batch": world * B, "seq_len": T, "channels": C,
                        "hidden": H, "layers": L, "mode": mode, "precision": precision,
+                       **({"step": "fwd + weighted CE + bwd + clip 1.0 + AdamW (04_lstm_model.py:482-512)"}
+                          if mode == "train" else {}),
                        "collective": ("none" if world == 1 else
                                       ("all_reduce(grads 4.55MB)" if mode == "train" else "all_gather(logits)"))},
             "gate_gemm_tflops_effective": value * flop_per_window / 1e12,

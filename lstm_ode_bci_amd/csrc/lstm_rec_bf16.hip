@@ -7,6 +7,7 @@
 // per-step matrix work drops from 16,384 to 1,024 MFMA cycles, which leaves the kernels bound by
 // the HBM streams (P in, gates/c/Y out; gates/c/dY in, dP out): P is prefetched TWO steps ahead.
 #include "lob_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -309,6 +310,17 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_h128_bf16_kernel(
 
 }  // namespace
 
+// 16-row tiles, two workgroups per CU (lstm_rec_bf16_s16.hip): the default.  LOB_REC_BF16=32 selects the 32-row
+// kernels of this file.
+int lob_rec_fwd_bf16_s16(void* P, int pg_bf16, const float* Whh, float* Y, float* Csave, void* Y16, void* Yd,
+                         float drop_p, uint64_t seed, int T, int Bp, int D, int save, hipStream_t s);
+int lob_rec_bwd_bf16_s16(const void* G, int pg_bf16, const float* Csave, const float* Whh, const float* dY, void* dP,
+                         float* dbias, int T, int Bp, int D, hipStream_t s);
+static bool use_s16() {
+    static const bool v = [] { const char* e = getenv("LOB_REC_BF16"); return !(e && atoi(e) == 32); }();
+    return v;
+}
+
 extern "C" int lob_lstm_rec_fwd_bf16(void* P, int pg_bf16, const float* Whh, float* Y, float* Csave,
                                      void* Y16, void* Yd, float drop_p, uint64_t seed,
                                      int T, int Bp, int Hh, int D, int save, void* stream) {
@@ -319,8 +331,9 @@ extern "C" int lob_lstm_rec_fwd_bf16(void* P, int pg_bf16, const float* Whh, flo
     if (Hh != 128 || (Bp % 32)) return LOB_E_SHAPE;
     if ((reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(Whh) | reinterpret_cast<uintptr_t>(Csave) |
          reinterpret_cast<uintptr_t>(Y16) | reinterpret_cast<uintptr_t>(Yd)) & 15) return LOB_E_ALIGN;
-    const dim3 grid(Bp / 32, D), block(256);
     hipStream_t s = (hipStream_t)stream;
+    if (use_s16()) return lob_rec_fwd_bf16_s16(P, pg_bf16, Whh, Y, Csave, Y16, Yd, drop_p, seed, T, Bp, D, save, s);
+    const dim3 grid(Bp / 32, D), block(256);
     __bf16* y16 = reinterpret_cast<__bf16*>(Y16);
     __bf16* yd = reinterpret_cast<__bf16*>(Yd);
 #define LOB_FWD(SV, YF, Y6, DR, PE) hipLaunchKernelGGL((lstm_rec_fwd_h128_bf16_kernel<SV, YF, Y6, DR, PE>), grid, block, \
@@ -347,6 +360,7 @@ extern "C" int lob_lstm_rec_bwd_bf16(const void* G, int pg_bf16, const float* Cs
     if (Hh != 128 || (Bp % 32)) return LOB_E_SHAPE;
     if ((reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(Csave) |
          reinterpret_cast<uintptr_t>(dP)) & 15) return LOB_E_ALIGN;
+    if (use_s16()) return lob_rec_bwd_bf16_s16(G, pg_bf16, Csave, Whh, dY, dP, dbias, T, Bp, D, (hipStream_t)stream);
     if (pg_bf16)
         hipLaunchKernelGGL((lstm_rec_bwd_h128_bf16_kernel<__bf16>), dim3(Bp / 32, D), dim3(256), 0, (hipStream_t)stream,
                            reinterpret_cast<const __bf16*>(G), Csave, Whh, dY, reinterpret_cast<__bf16*>(dP), dbias, T, Bp);
