@@ -262,16 +262,18 @@ __device__ __forceinline__ void dma_rows16(const __bf16* G, int ld, int row0, in
 // 256x256).  The bigger tile halves the bytes that cross the L2 -> LDS path per FLOP (every operand
 // tile is re-read once per tile of the OTHER dimension) -- at 128x128 that path carried 3x the
 // algorithmic bytes and, not HBM, set the rate.
-template <int EPI, int BTM, int BTN>
+// NDS = ring depth, BIASF = floats of the bias image.  <256,128,3,1024>: 76 KB of LDS -> TWO workgroups per CU, so
+// one workgroup's epilogue (stores at HBM rate) overlaps the other's main loop.
+template <int EPI, int BTM, int BTN, int NDS = DS, int BIASF = 2048>
 __global__ __launch_bounds__((BTM / 64) * (BTN / 64) * 64, (BTM * BTN > 128 * 128) ? 4 : 2)
 void gemm_nt_dma_kernel(NTArgs g) {
     constexpr int WR = BTM / 64, WC = BTN / 64, NWV = WR * WC, NTHR = NWV * 64;
     constexpr int NA = BTM / 16 / NWV, NB = BTN / 16 / NWV;      // 1-KB DMA instructions per wave per k-tile
     constexpr int ASLOT = BTM * DTK, WSLOT = BTN * DTK, SLOT = ASLOT + WSLOT;
-    constexpr int VM_STEADY = (DS - 2) * (NA + NB), VM_EPI = VM_STEADY + 16;
+    constexpr int VM_STEADY = (NDS - 2) * (NA + NB), VM_EPI = VM_STEADY + 16;
     static_assert(NA >= 1 && NB >= 1 && VM_EPI < 64, "tile / wave configuration");
-    __shared__ __attribute__((aligned(1024))) __bf16 ring[DS * SLOT + 4096];     // ring + 8 KB bias
-    float* bias_s = reinterpret_cast<float*>(ring + DS * SLOT);
+    __shared__ __attribute__((aligned(1024))) __bf16 ring[NDS * SLOT + 2 * BIASF];     // ring + bias image
+    float* bias_s = reinterpret_cast<float*>(ring + NDS * SLOT);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WC, wc = wave % WC;
@@ -285,7 +287,7 @@ void gemm_nt_dma_kernel(NTArgs g) {
     const int my_tiles = (ntile - slot + nslot - 1) / nslot;
     const int total = my_tiles * nk;
     {       // bias via LDS: an ordinary global load inside the loop would make hipcc drain the DMA queue
-        for (int i = tid; i < g.N && i < 2048; i += NTHR) bias_s[i] = g.bias ? g.bias[i] : 0.f;
+        for (int i = tid; i < g.N && i < BIASF; i += NTHR) bias_s[i] = g.bias ? g.bias[i] : 0.f;
         __syncthreads();
     }
 
@@ -293,7 +295,7 @@ void gemm_nt_dma_kernel(NTArgs g) {
     int p_q = 0, p_it = slot, p_kt = 0;
     auto issue = [&]() {
         const int m0 = ((p_it / ntn) * 8 + xcd) * BTM, n0 = (p_it % ntn) * BTN;
-        __bf16* as = ring + (p_q % DS) * SLOT;
+        __bf16* as = ring + (p_q % NDS) * SLOT;
         __bf16* ws = as + ASLOT;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
@@ -309,7 +311,7 @@ void gemm_nt_dma_kernel(NTArgs g) {
         if (++p_kt == nk) { p_kt = 0; p_it += nslot; }
     };
 #pragma unroll 1
-    for (int i = 0; i < DS - 1 && i < total; ++i) issue();
+    for (int i = 0; i < NDS - 1 && i < total; ++i) issue();
 
     int it = slot, kt = 0, since_epi = 99;
     f32x16 acc[2][2];
@@ -323,11 +325,11 @@ void gemm_nt_dma_kernel(NTArgs g) {
     for (int q = 0; q < total; ++q) {
         // ---- wait for slot q: all but the younger operations of THIS wave may still be in flight:
         //      (DS-2) k-tiles x (NA+NB) DMAs, plus the 16 epilogue stores if they were issued after DMA(q)
-        if (q + DS - 1 > total) {
+        if (q + NDS - 1 > total) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else if (EPI == 1 && since_epi < DS - 1) {
+        } else if (EPI == 1 && since_epi < NDS - 1) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_EPI) : "memory");
-        } else if (since_epi < DS - 1) {
+        } else if (since_epi < NDS - 1) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_STEADY) : "memory");
@@ -336,7 +338,7 @@ void gemm_nt_dma_kernel(NTArgs g) {
         if (p_q < total) issue();                       // refills the slot read in iteration q-1
         ++since_epi;
 
-        const __bf16* as = ring + (q % DS) * SLOT;
+        const __bf16* as = ring + (q % NDS) * SLOT;
         const __bf16* ws = as + ASLOT;
         const int r31 = lane & 31, hi = lane >> 5, sw = (r31 >> 2) & 3;
 #pragma unroll
@@ -364,7 +366,7 @@ void gemm_nt_dma_kernel(NTArgs g) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int col = cn0 + 64 * wc + 32 * j + (lane & 31);
-                    const float bv = lds_read_f32_opaque(bias_s + (col < 2048 ? col : 0));
+                    const float bv = lds_read_f32_opaque(bias_s + (col < BIASF ? col : 0));
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = cm0 + 64 * wr + 32 * i + acc_row(r, lane);
@@ -706,8 +708,9 @@ inline bool nt_dma_enabled() {
     static const bool v = [] { const char* e = getenv("LOB_NT_DMA"); return !(e && atoi(e) == 0); }();
     return v;
 }
-inline int nt_dma_tile() {      // output tile edge of the LDS-DMA kernel (tuning knob; LOB_DMA_TILE=128|256)
-    static const int v = [] { const char* e = getenv("LOB_DMA_TILE"); return (e && atoi(e) == 128) ? 128 : 256; }();
+inline int nt_dma_tile() {      // output tile of the LDS-DMA kernel (tuning knob; LOB_DMA_TILE=128|256|2 (= 256x128, 2 WGs/CU))
+    static const int v = [] { const char* e = getenv("LOB_DMA_TILE"); const int x = e ? atoi(e) : 256;
+                              return (x == 128 || x == 2) ? x : 256; }();
     return v;
 }
 inline int nt_dma_grid(int M, int N, int tile) {
@@ -724,10 +727,23 @@ inline int nt_dma_grid2(int M, int N) {     // 256 x 128 tiles, one workgroup pe
 }
 template <int EPI>
 inline void launch_nt_dma(const NTArgs& g, hipStream_t s) {
-    // 256x256 tiles need the whole tile inside the matrix only along N (rows are clamped/guarded)
-    if (nt_dma_tile() == 256 && g.N % 256 == 0)
+    // 256x256 tiles (16 waves, one workgroup per CU) wherever N is a multiple of 256: fewest operand bytes through
+    // LDS per FLOP.  Measured at M = 1M: gate GEMM K=256 0.955 ms vs 1.053 with 256x128 tiles on two workgroups per
+    // CU, dX N=256 0.835 vs 0.946; dX N=128 (layer 0) 0.648 (256x128, one workgroup) vs 0.591 (two workgroups).
+    const bool two_wg = g.N <= 1024 && g.K / DTK >= 3;
+    auto launch_2wg = [&] {
+        const long tiles = (long)((g.M + 255) / 256) * ((g.N + 127) / 128);
+        long gsz = 512;
+        if (gsz > tiles) gsz = ((tiles + 7) / 8) * 8;
+        hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI, 256, 128, 3, 1024>), dim3((unsigned)gsz), dim3(512), 0, s, g);
+    };
+    if (nt_dma_tile() == 2 && two_wg)
+        launch_2wg();
+    else if (nt_dma_tile() != 128 && g.N % 256 == 0)
         hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI, 256, 256>), dim3((unsigned)nt_dma_grid(g.M, g.N, 256)), dim3(1024), 0, s, g);
-    else if (nt_dma_tile() == 256)     // N = 128 (dX of layer 0): 256 x 128 tiles, 8 waves
+    else if (nt_dma_tile() != 128 && two_wg)      // N = 128 (dX of layer 0)
+        launch_2wg();
+    else if (nt_dma_tile() != 128)
         hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI, 256, 128>), dim3((unsigned)nt_dma_grid2(g.M, g.N)), dim3(512), 0, s, g);
     else
         hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI, 128, 128>), dim3((unsigned)nt_dma_grid(g.M, g.N, 128)), dim3(256), 0, s, g);

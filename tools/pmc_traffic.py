@@ -20,10 +20,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # bench label -> (precision, substring of the profiler's kernel name)
 KERNELS = {
-    "lstm_rec_fwd(save)": [("mixed", "lstm_rec_fwd_h128_bf16_kernelILb1ELb1ELb0ELb0"), ("fp32", "lstm_rec_fwd_h128_kernel<true")],
-    "lstm_rec_fwd": [("mixed", "lstm_rec_fwd_h128_bf16_kernelILb0ELb0"), ("fp32", "lstm_rec_fwd_h128_kernel<false")],
-    "lstm_rec_bwd": [("mixed", "lstm_rec_bwd_h128_bf16_kernel"), ("fp32", "lstm_rec_bwd_h128_kernel")],
-    "gate_gemm_x(K=256)": [("mixed", "gemm_nt_dma_kernel<1, 256, 256>"), ("fp32", "gemm_nt_kernel<true, 1>")],
+    "lstm_rec_fwd(save)": [("mixed", "lstm_rec_fwd_h128_bf16_s16_kernelILb1ELb1ELb0ELb0"), ("fp32", "lstm_rec_fwd_h128_s16_kernel<true")],
+    "lstm_rec_fwd": [("mixed", "lstm_rec_fwd_h128_bf16_s16_kernelILb0ELb0"), ("fp32", "lstm_rec_fwd_h128_s16_kernel<false")],
+    "lstm_rec_bwd": [("mixed", "lstm_rec_bwd_h128_bf16_s16_dma_kernel"), ("fp32", "lstm_rec_bwd_h128_kernel")],
+    "gate_gemm_x(K=256)": [("mixed", "gemm_nt_dma_kernel<1, 256, 256"), ("fp32", "gemm_nt_kernel<true, 1>")],
 }
 
 
