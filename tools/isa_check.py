@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""Static checks on the compiled ISA of the hand-synchronised BPTT kernel (lstm_rec_bwd_h128_bf16_s16_dma_kernel).
+
+That kernel issues its dY loads and reads its LDS-DMA ring through inline asm and counts `s_waitcnt vmcnt(N)` by hand,
+so two compiler behaviours would break it silently or slow it down:
+
+1. the registers written by the hand-issued `global_load_dword`s must not be touched (copied, spilled, read) by any
+   compiler-generated instruction before the `s_waitcnt vmcnt(18)` that retires them, two half-iterations later;
+2. the steady-state loop must contain no `s_waitcnt vmcnt(0)`, no scratch (spill) traffic and no other VMEM wait than
+   the hand-written one -- any of these drains the DMA queue every step.
+
+    python tools/isa_check.py            # compiles csrc/lstm_rec_bf16_s16.hip to ISA (hipcc, ~15 s) and checks it
+"""
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "lstm_ode_bci_amd", "csrc", "lstm_rec_bf16_s16.hip")
+KERNEL = r"lstm_rec_bwd_h128_bf16_s16_dma_kernelILi%dE"
+
+
+def compile_to_isa(path=None):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    out = path or os.path.join(tempfile.mkdtemp(prefix="lob_isa_"), "s16.s")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"),
+           "-I", os.path.dirname(SRC), "-S", "--cuda-device-only", SRC, "-o", out]
+    subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    return out
+
+
+def _function(lines, pat):
+    st = next(i for i, l in enumerate(lines) if re.match(r"^_ZN.*" + pat + r".*:", l))
+    end = next(i for i in range(st + 1, len(lines)) if lines[i].startswith(".Lfunc_end"))
+    return lines[st:end]
+
+
+def _instrs(body):
+    """[(index, text, in_asm)] of real instructions."""
+    out, in_asm = [], False
+    for i, l in enumerate(body):
+        t = l.strip()
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if t.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        t = t.split(";")[0].strip()
+        if not t or t.endswith(":") or t.startswith("."):
+            continue
+        out.append((i, t, in_asm))
+    return out
+
+
+def _regs(text):
+    """VGPR numbers named by an instruction's operands."""
+    regs = set()
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]", text):
+        regs.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    for m in re.finditer(r"\bv(\d+)\b", text):
+        regs.add(int(m.group(1)))
+    return regs
+
+
+def check_kernel(body):
+    ins = _instrs(body)
+    # the steady-state loop: from the first hand-written vmcnt(18) to the last backward branch after it
+    labels = {m.group(1): i for i, l in enumerate(body) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+    waits = [k for k, (_, t, a) in enumerate(ins) if a and t.startswith("s_waitcnt vmcnt(18)")]
+    assert len(waits) == 2, f"expected the two unrolled half-iterations, found {len(waits)} hand-written waits"
+    back = [k for k, (i, t, _) in enumerate(ins)
+            for m in [re.search(r"s_c?branch\S*\s+(\.LBB\d+_\d+)", t)] if m and labels.get(m.group(1), 1 << 30) < i]
+    loop_end = max(k for k in back if k > waits[1])
+    loop_start = min(k for k, (i, _, _) in enumerate(ins)
+                     if any(labels[m.group(1)] <= i for kk in back if kk >= waits[1]
+                            for m in [re.search(r"(\.LBB\d+_\d+)", ins[kk][1])] if m))
+    loop = ins[loop_start:loop_end + 1]
+    problems = []
+    for _, t, a in loop:
+        if not a and re.search(r"s_waitcnt.*vmcnt\(", t):
+            problems.append(f"compiler-generated VMEM wait in the loop: {t}")
+        if t.startswith("scratch_"):
+            problems.append(f"spill traffic in the loop: {t}")
+    # hazard 1: walk the loop cyclically from each group of hand-issued loads to the SECOND following hand wait
+    n = len(loop)
+    starts = [k for k, (_, t, a) in enumerate(loop) if a and t.startswith("global_load_dword ")
+              and not (k and loop[k - 1][2] and loop[k - 1][1].startswith("global_load_dword "))]
+    assert len(starts) == 2, f"expected two groups of hand-issued dY loads, found {len(starts)}"
+    for s in starts:
+        dst, k = set(), s
+        while loop[k][2] and loop[k][1].startswith("global_load_dword "):
+            dst |= _regs(loop[k][1].split(",")[0])
+            k += 1
+        seen_waits = 0
+        for step in range(n):
+            _, t, a = loop[(k + step) % n]
+            if a and t.startswith("s_waitcnt vmcnt(18)"):
+                seen_waits += 1
+                if seen_waits == 2:
+                    break
+                continue
+            if not a and (_regs(t) & dst):
+                problems.append(f"register of an in-flight hand-issued load touched before its wait: {t}")
+    return problems
+
+
+def main(path=None):
+    lines = open(path or compile_to_isa()).read().split("\n")
+    problems = []
+    for D in (1, 2):
+        problems += [f"D={D}: {p}" for p in check_kernel(_function(lines, KERNEL % D))]
+    return problems
+
+
+if __name__ == "__main__":
+    probs = main(sys.argv[1] if len(sys.argv) > 1 else None)
+    print("\n".join(probs) if probs else "isa_check: ok")
+    sys.exit(1 if probs else 0)
