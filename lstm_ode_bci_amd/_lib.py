@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "liblob.so")
+LIB_PATH = os.environ.get("LOB_LIB_PATH") or os.path.join(_PKG, "liblob.so")     # override: A/B of two builds
 
 _lib = None
 

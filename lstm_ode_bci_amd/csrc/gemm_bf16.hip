@@ -32,6 +32,7 @@ struct NTArgs {
     int T, Bp, H, D;     // fragment epilogue
     int out_bf16;                  // fragment epilogue: P stored as bf16
     float drop_p; uint64_t seed;   // row-major epilogue: C *= dropout mask of element (row*ldc + col)
+    int stagger;                   // LDS-DMA kernel: start delay unit (see the kernel), 0 = none
 };
 
 // ---- staging: [128 rows][TKT k] tile, source rows are K-contiguous -------------------------
@@ -201,14 +202,15 @@ __global__ __launch_bounds__(256, TKT == 32 ? 3 : 2) void gemm_nt_bf16_kernel(NT
                         if (ncol >= g.N) continue;
                         const int d = ncol / H4, gg = (ncol % H4) / g.H, w = (ncol % g.H) >> 5;
                         const float bv = g.bias ? g.bias[ncol + (lane & 31)] : 0.f;
-                        const size_t fo = ((((size_t)(d * g.T + t) * NBT + bt) * NW + w) * 4 + gg) * 1024 + lane * 4;
-                        if (g.out_bf16) {
-                            __bf16* dst = reinterpret_cast<__bf16*>(g.C) + fo;
+                        size_t fo = ((((size_t)(d * g.T + t) * NBT + bt) * NW + w) * 4 + gg) * 1024 + lane * 4;
+                        if (g.out_bf16) {        // bf16 fragment storage: [gate][q pair][lane][8] -> 16-B stores
+                            __bf16* dst = reinterpret_cast<__bf16*>(g.C) + (fo - lane * 4) + lane * 8;
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                bf16x4 v = {(__bf16)(acc[i][j][4 * q + 0] + bv), (__bf16)(acc[i][j][4 * q + 1] + bv),
-                                            (__bf16)(acc[i][j][4 * q + 2] + bv), (__bf16)(acc[i][j][4 * q + 3] + bv)};
-                                *reinterpret_cast<bf16x4*>(dst + q * 256) = v;
+                            for (int pq = 0; pq < 2; ++pq) {
+                                bf16x8 v;
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) v[e] = (__bf16)(acc[i][j][8 * pq + e] + bv);
+                                *reinterpret_cast<bf16x8*>(dst + pq * 512) = v;
                             }
                         } else {
                             float* dst = g.C + fo;
@@ -270,7 +272,7 @@ void gemm_nt_dma_kernel(NTArgs g) {
     constexpr int WR = BTM / 64, WC = BTN / 64, NWV = WR * WC, NTHR = NWV * 64;
     constexpr int NA = BTM / 16 / NWV, NB = BTN / 16 / NWV;      // 1-KB DMA instructions per wave per k-tile
     constexpr int ASLOT = BTM * DTK, WSLOT = BTN * DTK, SLOT = ASLOT + WSLOT;
-    constexpr int VM_STEADY = (NDS - 2) * (NA + NB), VM_EPI = VM_STEADY + 16;
+    constexpr int VM_STEADY = (NDS - 2) * (NA + NB), VM_EPI = VM_STEADY + 16;   // (bf16 P: 8 stores; 16 covers fp32 P)
     static_assert(NA >= 1 && NB >= 1 && VM_EPI < 64, "tile / wave configuration");
     __shared__ __attribute__((aligned(1024))) __bf16 ring[NDS * SLOT + 2 * BIASF];     // ring + bias image
     float* bias_s = reinterpret_cast<float*>(ring + NDS * SLOT);
@@ -290,6 +292,9 @@ void gemm_nt_dma_kernel(NTArgs g) {
         for (int i = tid; i < g.N && i < BIASF; i += NTHR) bias_s[i] = g.bias ? g.bias[i] : 0.f;
         __syncthreads();
     }
+    // Optional start stagger (LOB_NT_STAGGER, default 0 = off; measured: no effect at 1/2/4/8 units, so the
+    // workgroups' epilogues are not what synchronises them -- the epilogue cost is store issue, see there).
+    for (int i = ((blockIdx.x >> 3) & 7) * g.stagger; i > 0; --i) __builtin_amdgcn_s_sleep(32);
 
     // producer cursor (runs DS-1 k-tiles ahead of the consumer, across tile boundaries)
     int p_q = 0, p_it = slot, p_kt = 0;
@@ -390,14 +395,20 @@ void gemm_nt_dma_kernel(NTArgs g) {
                     const int ncol = cn0 + 64 * wc + 32 * j;
                     const int d = ncol / H4, gg = (ncol % H4) / g.H, w = (ncol % g.H) >> 5;
                     const float bv = lds_read_f32_opaque(bias_s + ncol + (lane & 31));
-                    const size_t fo = ((((size_t)(d * g.T + t) * NBT + bt) * NW + w) * 4 + gg) * 1024 + lane * 4;
+                    size_t fo = ((((size_t)(d * g.T + t) * NBT + bt) * NW + w) * 4 + gg) * 1024 + lane * 4;
                     if (g.out_bf16) {
-                        __bf16* dst = reinterpret_cast<__bf16*>(g.C) + fo;
+                        // bf16 fragment storage: [gate][q pair][lane][8]: two 16-B stores per 32x32 block.
+                        // Measured on this epilogue (gate GEMM, K = 256, 0.96 ms): without the stores 0.66 ms, with the
+                        // stores kept in L2 0.77 ms, non-temporal stores 0.96 ms -- 0.2 ms is HBM write-back that the
+                        // main loop does not hide: VMEM operations of a wave retire in order, so the DMA issued after the
+                        // epilogue cannot be counted complete before the stores are acknowledged
+                        __bf16* dst = reinterpret_cast<__bf16*>(g.C) + (fo - lane * 4) + lane * 8;
 #pragma unroll
-                        for (int qq = 0; qq < 4; ++qq) {
-                            bf16x4 v = {(__bf16)(acc[i][j][4 * qq + 0] + bv), (__bf16)(acc[i][j][4 * qq + 1] + bv),
-                                        (__bf16)(acc[i][j][4 * qq + 2] + bv), (__bf16)(acc[i][j][4 * qq + 3] + bv)};
-                            *reinterpret_cast<bf16x4*>(dst + qq * 256) = v;
+                        for (int pq = 0; pq < 2; ++pq) {
+                            bf16x8 v;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = (__bf16)(acc[i][j][8 * pq + e] + bv);
+                            *reinterpret_cast<bf16x8*>(dst + pq * 512) = v;
                         }
                     } else {
                         float* dst = g.C + fo;
@@ -704,6 +715,10 @@ inline int nt_tk() {
 }  // namespace
 
 // A: fp32 (a_bf16 = 0) or bf16 (a_bf16 = 1) row-major [M][lda]; W fp32 [N][ldw]; C fp32.
+inline int nt_stagger() {       // tuning knob LOB_NT_STAGGER (units of s_sleep(32) = 2048 clocks per group step)
+    static const int v = [] { const char* e = getenv("LOB_NT_STAGGER"); return e ? atoi(e) : 0; }();
+    return v;
+}
 inline bool nt_dma_enabled() {
     static const bool v = [] { const char* e = getenv("LOB_NT_DMA"); return !(e && atoi(e) == 0); }();
     return v;
@@ -726,7 +741,9 @@ inline int nt_dma_grid2(int M, int N) {     // 256 x 128 tiles, one workgroup pe
     return (int)gsz;
 }
 template <int EPI>
-inline void launch_nt_dma(const NTArgs& g, hipStream_t s) {
+inline void launch_nt_dma(const NTArgs& g_, hipStream_t s) {
+    NTArgs g = g_;
+    g.stagger = nt_stagger();
     // 256x256 tiles (16 waves, one workgroup per CU) wherever N is a multiple of 256: fewest operand bytes through
     // LDS per FLOP.  Measured at M = 1M: gate GEMM K=256 0.955 ms vs 1.053 with 256x128 tiles on two workgroups per
     // CU, dX N=256 0.835 vs 0.946; dX N=128 (layer 0) 0.648 (256x128, one workgroup) vs 0.591 (two workgroups).
@@ -757,7 +774,7 @@ extern "C" int lob_gemm_nt_bf16(const void* A, int a_bf16, int lda, const void* 
     if ((act & 0xff) > LOB_ACT_GELU || act < 0) return LOB_E_ARG;
     if (!al16(A) || !al16(W) || (K % 8) || (lda % 8) || (ldw % 4)) return LOB_E_ALIGN;
     NTArgs g{A, reinterpret_cast<const float*>(W), bias, C, lda, ldw, ldc, M, N, K, act & 0xff, (act >> 8) & 1,
-             0, 0, 0, 0, 0, drop_p, seed};
+             0, 0, 0, 0, 0, drop_p, seed, 0};
     if (drop_p < 0.f || drop_p >= 1.f) return LOB_E_ARG;
     if (w_bf16) {      // both operands bf16 in HBM: LDS-DMA kernel (no bias / activation in its row-major epilogue)
         if (!a_bf16 || (act >> 8) || N > 2048 || (K % DTK) || K / DTK < DS || (ldw % 8)) return LOB_E_SHAPE;
@@ -785,7 +802,7 @@ extern "C" int lob_gate_gemm_x_bf16(const void* X, int x_bf16, int ldx, const vo
     if (!al16(X) || !al16(Wih) || !al16(P) || (K % 8) || (ldx % 8)) return LOB_E_ALIGN;
     const int N = D * 4 * H, M = T * Bp;
     NTArgs g{X, reinterpret_cast<const float*>(Wih), bias, reinterpret_cast<float*>(P), ldx, K, N, M, N, K, LOB_ACT_NONE, 0,
-             T, Bp, H, D, p_bf16, 0.f, 0};
+             T, Bp, H, D, p_bf16, 0.f, 0, 0};
     if (w_bf16) {
         if (!x_bf16 || (K % DTK) || K / DTK < DS || N > 2048 || (N % 128) || (M % 256)) return LOB_E_SHAPE;
         launch_nt_dma<1>(g, (hipStream_t)stream);

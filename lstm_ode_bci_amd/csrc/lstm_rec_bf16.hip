@@ -29,65 +29,87 @@ __device__ __forceinline__ bf16x8 cvt8(const float* p) {
     return r;
 }
 
-// Fragment blocks ([gate][q][lane][4] elements) hold fp32 or -- with bf16 P/G storage -- bf16: the same
-// element order, half the bytes (8-B accesses per lane, 512 B contiguous per wave-instruction).
+// Fragment blocks: fp32 as [gate][q][lane][4]; bf16 as [gate][q pair][lane][8] (the same elements, the two q of a pair
+// side by side), so that a lane moves 16 B per access either way (the gate GEMM's epilogue is store-issue bound: half
+// the store instructions for the bf16 image).  `off` is lane * 4.
 template <typename E>
 __device__ __forceinline__ void load_frag4(const E* p, unsigned off, f32x16 (&dst)[4]) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+    for (int g = 0; g < 4; ++g) {
+        if constexpr (sizeof(E) == 4) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if constexpr (sizeof(E) == 4) {
+            for (int q = 0; q < 4; ++q) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>((p + g * 1024 + q * 256) + off);
                 dst[g][4 * q] = v[0]; dst[g][4 * q + 1] = v[1]; dst[g][4 * q + 2] = v[2]; dst[g][4 * q + 3] = v[3];
-            } else {
-                const bf16x4 v = *reinterpret_cast<const bf16x4*>((p + g * 1024 + q * 256) + off);
-                dst[g][4 * q] = (float)v[0]; dst[g][4 * q + 1] = (float)v[1];
-                dst[g][4 * q + 2] = (float)v[2]; dst[g][4 * q + 3] = (float)v[3];
+            }
+        } else {
+#pragma unroll
+            for (int pq = 0; pq < 2; ++pq) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>((p + g * 1024 + pq * 512) + 2 * off);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dst[g][8 * pq + e] = (float)v[e];
             }
         }
+    }
 }
 // Raw (unconverted) fragment block: prefetched two steps ahead and only converted to fp32 when it is
 // consumed -- a conversion at load time would force the wait for the data right at the prefetch.
 template <typename E> struct RawFrag;
 template <> struct RawFrag<float> { f32x4 v[16]; };
-template <> struct RawFrag<__bf16> { bf16x4 v[16]; };
+template <> struct RawFrag<__bf16> { bf16x8 v[8]; };
 
 template <typename E>
 __device__ __forceinline__ void load_raw(const E* p, unsigned off, RawFrag<E>& r) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+    for (int g = 0; g < 4; ++g) {
+        if constexpr (sizeof(E) == 4) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if constexpr (sizeof(E) == 4) r.v[4 * g + q] = *reinterpret_cast<const f32x4*>((p + g * 1024 + q * 256) + off);
-            else                          r.v[4 * g + q] = *reinterpret_cast<const bf16x4*>((p + g * 1024 + q * 256) + off);
+            for (int q = 0; q < 4; ++q) r.v[4 * g + q] = *reinterpret_cast<const f32x4*>((p + g * 1024 + q * 256) + off);
+        } else {
+#pragma unroll
+            for (int pq = 0; pq < 2; ++pq)
+                r.v[2 * g + pq] = *reinterpret_cast<const bf16x8*>((p + g * 1024 + pq * 512) + 2 * off);
         }
+    }
 }
 template <typename E>
 __device__ __forceinline__ void raw_to_acc(const RawFrag<E>& r, f32x16 (&dst)[4]) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+    for (int g = 0; g < 4; ++g) {
+        if constexpr (sizeof(E) == 4) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) dst[g][4 * q + e] = (float)r.v[4 * g + q][e];
+                for (int e = 0; e < 4; ++e) dst[g][4 * q + e] = r.v[4 * g + q][e];
+        } else {
+#pragma unroll
+            for (int pq = 0; pq < 2; ++pq)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dst[g][8 * pq + e] = (float)r.v[2 * g + pq][e];
+        }
+    }
 }
 
 template <typename E>
 __device__ __forceinline__ void store_frag4(E* p, unsigned off, const f32x16 (&src)[4]) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+    for (int g = 0; g < 4; ++g) {
+        if constexpr (sizeof(E) == 4) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if constexpr (sizeof(E) == 4) {
+            for (int q = 0; q < 4; ++q) {
                 f32x4 v = {src[g][4 * q + 0], src[g][4 * q + 1], src[g][4 * q + 2], src[g][4 * q + 3]};
                 *reinterpret_cast<f32x4*>((p + g * 1024 + q * 256) + off) = v;
-            } else {
-                bf16x4 v = {(__bf16)src[g][4 * q + 0], (__bf16)src[g][4 * q + 1],
-                            (__bf16)src[g][4 * q + 2], (__bf16)src[g][4 * q + 3]};
-                *reinterpret_cast<bf16x4*>((p + g * 1024 + q * 256) + off) = v;
+            }
+        } else {
+#pragma unroll
+            for (int pq = 0; pq < 2; ++pq) {
+                bf16x8 v;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (__bf16)src[g][8 * pq + e];
+                *reinterpret_cast<bf16x8*>((p + g * 1024 + pq * 512) + 2 * off) = v;
             }
         }
+    }
 }
 
 // Outputs: Y (fp32, scattered 128-B segments straight from the accumulator layout) when YF32; the bf16

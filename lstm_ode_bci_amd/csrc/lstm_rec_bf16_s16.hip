@@ -36,6 +36,15 @@ __device__ __forceinline__ bf16x8 cvt8(const float* p) {
 
 // One 16-row tile of a fragment block, per lane: [gate][cbu] groups of 4 consecutive elements (rows 4rq..4rq+3 of
 // one column).  Raw storage type (fp32 or bf16), converted when consumed.
+// Element offsets inside a wave's block (see lstm_rec_bf16.hip): fp32 [gate][q][lane'][4], bf16 [gate][q pair][lane'][8].
+// A 16-row tile s0 is q in {2 s0, 2 s0 + 1} = q pair s0; this lane's rows are q = 2 s0 + (rq >> 1), lane' =
+// (rq & 1) * 32 + 16 cbu + c16.  frag_lane<E>() = the lane's offset without the s0 / gate / cbu terms,
+// FRAG_CBU<E> = the step between the two unit blocks cbu.
+template <typename E> __device__ __forceinline__ unsigned frag_lane(int rq, int c16) {
+    if constexpr (sizeof(E) == 4) return (unsigned)((rq >> 1) * 256 + ((rq & 1) * 32 + c16) * 4);
+    else                          return (unsigned)(((rq & 1) * 32 + c16) * 8 + (rq >> 1) * 4);
+}
+template <typename E> constexpr int FRAG_CBU = sizeof(E) == 4 ? 64 : 128;
 template <typename E> struct Raw16;
 template <> struct Raw16<float> { f32x4 v[8]; };
 template <> struct Raw16<__bf16> { bf16x4 v[8]; };
@@ -47,7 +56,7 @@ __device__ __forceinline__ void load_raw16(const E* p, unsigned off, Raw16<E>& r
 #pragma unroll
         for (int cbu = 0; cbu < 2; ++cbu) {
             if constexpr (sizeof(E) == 4) r.v[2 * g + cbu] = *reinterpret_cast<const f32x4*>((p + g * 1024 + cbu * 64) + off);
-            else                          r.v[2 * g + cbu] = *reinterpret_cast<const bf16x4*>((p + g * 1024 + cbu * 64) + off);
+            else                          r.v[2 * g + cbu] = *reinterpret_cast<const bf16x4*>((p + g * 1024 + cbu * 128) + off);
         }
 }
 template <typename E>
@@ -60,7 +69,7 @@ __device__ __forceinline__ void store_frag16(E* p, unsigned off, const f32x4 (&s
                 *reinterpret_cast<f32x4*>((p + g * 1024 + cbu * 64) + off) = src[g][cbu];
             } else {
                 bf16x4 v = {(__bf16)src[g][cbu][0], (__bf16)src[g][cbu][1], (__bf16)src[g][cbu][2], (__bf16)src[g][cbu][3]};
-                *reinterpret_cast<bf16x4*>((p + g * 1024 + cbu * 64) + off) = v;
+                *reinterpret_cast<bf16x4*>((p + g * 1024 + cbu * 128) + off) = v;
             }
         }
 }
@@ -100,8 +109,8 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_fwd_h128_bf16_s16_kernel(
     const size_t pstep = (size_t)NBT * 16 * 1024, cstep = (size_t)NBT * 4096;
     PE* pblk = P + ((size_t)d * T * NBT + bt) * 16 * 1024 + (size_t)w * 4096 + s0 * 512;
     float* cblk = SAVE ? Csave + ((size_t)d * T * NBT + bt) * 4096 + (size_t)w * 1024 + s0 * 512 : nullptr;
-    // element (row 16 s0 + 4rq + j, col 16cbu + c16) sits at q = 2 s0 + (rq>>1), lane' = (rq&1)*32 + 16cbu + c16
-    const unsigned lane_p = (unsigned)((rq >> 1) * 256 + ((rq & 1) * 32 + c16) * 4);
+    const unsigned lane_p = frag_lane<PE>(rq, c16);        // P / saved gates (storage type PE)
+    const unsigned lane_c = frag_lane<float>(rq, c16);     // c (always fp32)
     const int DH = D * H;
     const unsigned y_off = (unsigned)(4 * rq * DH + c16);
     const int t_first = d ? T - 1 : 0, dt = d ? -1 : 1;
@@ -154,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_fwd_h128_bf16_s16_kernel(
 #pragma unroll
             for (int cbu = 0; cbu < 2; ++cbu) {
                 f32x4 v = {c[cbu][0], c[cbu][1], c[cbu][2], c[cbu][3]};
-                *reinterpret_cast<f32x4*>((cp + cbu * 64) + lane_p) = v;
+                *reinterpret_cast<f32x4*>((cp + cbu * 64) + lane_c) = v;
             }
         }
         __syncthreads();
@@ -213,7 +222,8 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_bwd_h128_bf16_s16_kernel(
     const size_t gstep = (size_t)NBT * 16 * 1024, cstep = (size_t)NBT * 4096;
     const PE* gwave = G + ((size_t)d * T * NBT + bt) * 16 * 1024 + (size_t)w * 4096 + s0 * 512;
     const float* cwave = Csave + ((size_t)d * T * NBT + bt) * 4096 + (size_t)w * 1024 + s0 * 512;
-    const unsigned lane_p = (unsigned)((rq >> 1) * 256 + ((rq & 1) * 32 + c16) * 4);
+    const unsigned lane_p = frag_lane<PE>(rq, c16);        // saved gates (storage type PE)
+    const unsigned lane_c = frag_lane<float>(rq, c16);     // c (always fp32)
     const int DH = D * H, D4H = D * 4 * H;
     const int row0 = bt * 32 + s0 * 16;
     const float* dywave = dY + (size_t)row0 * DH + d * H + 32 * w;
@@ -236,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_bwd_h128_bf16_s16_kernel(
         if (t >= 0 && t < T) {
             const float* cq = cwave + (size_t)t * cstep;
 #pragma unroll
-            for (int cbu = 0; cbu < 2; ++cbu) dst[cbu] = *reinterpret_cast<const f32x4*>((cq + cbu * 64) + lane_p);
+            for (int cbu = 0; cbu < 2; ++cbu) dst[cbu] = *reinterpret_cast<const f32x4*>((cq + cbu * 64) + lane_c);
         } else {
 #pragma unroll
             for (int cbu = 0; cbu < 2; ++cbu) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; dst[cbu] = z; }
@@ -362,7 +372,8 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_bwd_h128_bf16_s16_dma_kernel(
     const size_t gstep = (size_t)NBT * 16 * 1024, cstep = (size_t)NBT * 4096;
     const __bf16* gwave = G + ((size_t)d * T * NBT + bt) * 16 * 1024 + (size_t)w * 4096 + s0 * 512;
     const float* cwave = Csave + ((size_t)d * T * NBT + bt) * 4096 + (size_t)w * 1024 + s0 * 512;
-    const unsigned lane_p = (unsigned)((rq >> 1) * 256 + ((rq & 1) * 32 + c16) * 4);
+    const unsigned lane_g = 2 * frag_lane<__bf16>(rq, c16);   // byte offset of this lane's gates in a 1-KB gate chunk
+    const unsigned lane_c = frag_lane<float>(rq, c16);        // element offset of this lane's c values
     constexpr int DH = D * H, D4H = D * 4 * H;
     const int row0 = bt * 32 + s0 * 16;
     const float* dywave = dY + (size_t)row0 * DH + d * H + 32 * w;
@@ -382,7 +393,7 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_bwd_h128_bf16_s16_dma_kernel(
     {   // c of the first step: plain load
         const float* cq = cwave + (size_t)t_first * cstep;
 #pragma unroll
-        for (int cbu = 0; cbu < 2; ++cbu) ct[cbu] = *reinterpret_cast<const f32x4*>((cq + cbu * 64) + lane_p);
+        for (int cbu = 0; cbu < 2; ++cbu) ct[cbu] = *reinterpret_cast<const f32x4*>((cq + cbu * 64) + lane_c);
     }
     unsigned char* wring = ring + w * RING_WAVE;          // this wave's part of slot 0; slot 1 at + RING_SLOT
     const unsigned ring_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)wring;
@@ -452,13 +463,13 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_bwd_h128_bf16_s16_dma_kernel(
                              "ds_read_b64 %2, %5 offset:2048\n\tds_read_b64 %3, %5 offset:3072\n\t"
                              "ds_read_b128 %4, %6 offset:4096\n\ts_waitcnt lgkmcnt(0)"
                              : "=&v"(ri), "=&v"(rf), "=&v"(rc), "=&v"(ro), "=&v"(cpl)
-                             : "v"(ring_a + 2 * lane_p), "v"(ring_a + 4 * lane_p) : "memory");
+                             : "v"(ring_a + lane_g), "v"(ring_a + 4 * lane_c) : "memory");
             else
-                asm volatile("ds_read_b64 %0, %5 offset:128\n\tds_read_b64 %1, %5 offset:1152\n\t"
-                             "ds_read_b64 %2, %5 offset:2176\n\tds_read_b64 %3, %5 offset:3200\n\t"
+                asm volatile("ds_read_b64 %0, %5 offset:256\n\tds_read_b64 %1, %5 offset:1280\n\t"
+                             "ds_read_b64 %2, %5 offset:2304\n\tds_read_b64 %3, %5 offset:3328\n\t"
                              "ds_read_b128 %4, %6 offset:4352\n\ts_waitcnt lgkmcnt(0)"
                              : "=&v"(ri), "=&v"(rf), "=&v"(rc), "=&v"(ro), "=&v"(cpl)
-                             : "v"(ring_a + 2 * lane_p), "v"(ring_a + 4 * lane_p) : "memory");
+                             : "v"(ring_a + lane_g), "v"(ring_a + 4 * lane_c) : "memory");
             const bf16x4 gi = __builtin_bit_cast(bf16x4, ri), gf = __builtin_bit_cast(bf16x4, rf);
             const bf16x4 gc = __builtin_bit_cast(bf16x4, rc), go = __builtin_bit_cast(bf16x4, ro);
             if (step + 1 < T) cp[cbu] = cpl;
