@@ -239,6 +239,7 @@ def main():
     if mode == "train":
         # the reference's training-step body (04_lstm_model.py:482-512): fwd -> weighted CE -> bwd ->
         # [data-parallel: all-reduce of the flat gradient] -> clip 1.0 + AdamW, all inside the timed step
+        from lstm_ode_bci_amd.sharding import all_reduce_flat_grad_
         from lstm_ode_bci_amd.training import FusedAdamW, WeightedCrossEntropy
         criterion = WeightedCrossEntropy(class_w).to(dev)
         opt = FusedAdamW(model.parameters(), lr=3e-4, weight_decay=1e-4)
@@ -253,9 +254,8 @@ def main():
             opt.zero_grad()
             loss = criterion(model(x), y)
             loss.backward()
-            if world > 1:
-                dist.all_reduce(opt.flat_grad)
-            opt.step(clip_grad_norm=1.0, grad_scale=1.0 / world)
+            _, gscale = all_reduce_flat_grad_(opt.flat_grad)        # one 4.55 MB message; no-op at N = 1
+            opt.step(clip_grad_norm=1.0, grad_scale=gscale)
         elif mode == "fwd":
             model.eval()
             with torch.no_grad():

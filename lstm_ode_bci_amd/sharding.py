@@ -3,7 +3,10 @@ contiguously over ranks, no data-path collective (every window is independent th
 04_lstm_model.py:206-222 and 06_lstm_ode_integration.py:372-401), ONE all-gather at the end
 to collate per-window outputs (RCCL over xGMI when the backend is "nccl").
 
-The reference is single-process; this is the only collective the build adds.
+Data-parallel training adds one more: the all-reduce of the FLAT gradient buffer (4.55 MB, one
+message per step) before the fused clip + AdamW launch -- `all_reduce_flat_grad_`.
+
+The reference is single-process; these are the only collectives the build adds.
 """
 from __future__ import annotations
 
@@ -57,3 +60,15 @@ def predict_batch_sharded(integ, X_batch, forecast_steps=20, batch_size=512, gat
     def fn(Xs):
         return integ.predict_batch_device(Xs, forecast_steps, batch_size, want_traj=gather_trajectories)
     return sharded_apply(X_batch, fn, group)
+
+
+def all_reduce_flat_grad_(flat_grad, group=None):
+    """Sum the flat gradient buffer over the ranks in place and return ``(flat_grad, 1 / world)``: the factor is
+    handed to ``FusedAdamW.step(grad_scale=...)`` so that the mean is taken inside the optimizer launch instead of
+    in a separate pass over the buffer.  A no-op (factor 1) without an initialised process group."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return flat_grad, 1.0
+    world = dist.get_world_size(group)
+    if world > 1:
+        dist.all_reduce(flat_grad, group=group)
+    return flat_grad, 1.0 / world

@@ -25,6 +25,7 @@ import torch.nn as nn
 
 from . import ops
 from .model import AblationLSTMModel
+from .sharding import all_reduce_flat_grad_
 
 
 # ---------------------------------------------------------------------------------------------
@@ -261,7 +262,10 @@ def train_model(model, train_loader, val_loader, y_train, epochs=100, learning_r
                 loss = criterion(outputs, yb) / acc_steps
             loss.backward()
             if (batch_idx + 1) % acc_steps == 0:
-                optimizer.step(clip_grad_norm=1.0)            # clip_grad_norm_(…, 1.0) + optimizer.step(), 04:501-502
+                # data-parallel runs (one process per GPU, each with its own shard of the loader): one all-reduce of
+                # the flat gradient; single process: no-op
+                _, gscale = all_reduce_flat_grad_(optimizer.flat_grad)
+                optimizer.step(clip_grad_norm=1.0, grad_scale=gscale)     # clip_grad_norm_(…, 1.0) + optimizer.step(), 04:501-502
                 optimizer.zero_grad()
             loss_sum += loss.detach() * (acc_steps * xb.size(0))
             correct += criterion.last_correct[0]

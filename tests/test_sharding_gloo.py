@@ -51,3 +51,39 @@ def test_two_ranks_collate_bit_identical(n):
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res)
     assert sum(cnt for _, _, cnt in res) == n
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lstm_ode_bci_amd import sharding
+    g = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    out, scale = sharding.all_reduce_flat_grad_(g)
+    ok = out.data_ptr() == g.data_ptr() and torch.equal(out, torch.arange(1000, dtype=torch.float32) * 3) and scale == 0.5
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_all_reduce_two_ranks():
+    """Data-parallel training step: the flat gradient buffer is summed in place, the 1/world factor is returned for
+    the optimizer launch."""
+    from lstm_ode_bci_amd import sharding
+    g = torch.ones(5)
+    out, scale = sharding.all_reduce_flat_grad_(g)          # no process group: no-op
+    assert out is g and scale == 1.0
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)
