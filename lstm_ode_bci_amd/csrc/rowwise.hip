@@ -428,6 +428,114 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Vectorised attention pooling for the mixed path at H = 128, D = 2 (V bf16 [.,256], U fp32 [.,128]): the generic
+// kernels above walk a window's 256 rows with 2- and 4-byte scalar accesses from one thread per column (1.9 TB/s in
+// the backward); here a wave takes every 4th time step and moves whole rows per instruction (V: 8 B per lane, U:
+// 8 B per lane, dU: 4 B per lane), partial sums are combined through LDS at the end.
+// ------------------------------------------------------------------------------------------
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256) void attn_pool_fwd_vec_kernel(
+    const __bf16* __restrict__ V, const float* __restrict__ U, const float* __restrict__ w2,
+    const float* __restrict__ b2, float* __restrict__ ctx, float* __restrict__ attn, int T, int Bp) {
+    constexpr int W = 256, W2 = 128;
+    extern __shared__ __attribute__((aligned(16))) float sc[];   // [T] scores -> weights, then [4][W] partial contexts
+    __shared__ float red[8];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float bias2 = b2 ? b2[0] : 0.f;
+    const float2 wv = *reinterpret_cast<const float2*>(w2 + 2 * lane);
+    const size_t rs = (size_t)Bp;
+#pragma unroll 4
+    for (int t = wave; t < T; t += 4) {
+        const float2 u = *reinterpret_cast<const float2*>(U + ((size_t)t * rs + b) * W2 + 2 * lane);
+        const float s = wave_sum(fmaf(u.x, wv.x, u.y * wv.y));
+        if (lane == 0) sc[t] = s + bias2;
+    }
+    __syncthreads();
+    float m = -INFINITY;
+    for (int t = tid; t < T; t += 256) m = fmaxf(m, sc[t]);
+    m = wave_max(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float l = 0.f;
+    for (int t = tid; t < T; t += 256) { const float e = expf(sc[t] - m); sc[t] = e; l += e; }
+    l = wave_sum(l);
+    if (lane == 0) red[4 + wave] = l;
+    __syncthreads();
+    const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+    for (int t = tid; t < T; t += 256) { const float a = sc[t] * inv; sc[t] = a; attn[(size_t)b * T + t] = a; }
+    __syncthreads();
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int t = wave; t < T; t += 4) {
+        const bf16x4_t v = *reinterpret_cast<const bf16x4_t*>(V + ((size_t)t * rs + b) * W + 4 * lane);
+        const float a = sc[t];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = fmaf(a, (float)v[i], acc[i]);
+    }
+    float* part = sc + ((T + 3) & ~3);              // [4][W]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) part[wave * W + 4 * lane + i] = acc[i];
+    __syncthreads();
+    ctx[(size_t)b * W + tid] = part[tid] + part[W + tid] + part[2 * W + tid] + part[3 * W + tid];
+}
+
+// Backward, fused form (dV is NOT materialised: the a[t] dctx term goes into the LayerNorm backward): writes dPreU
+// (bf16) and accumulates dw2.
+__global__ __launch_bounds__(256) void attn_pool_bwd_vec_kernel(
+    const __bf16* __restrict__ V, const float* __restrict__ U, const float* __restrict__ attn,
+    const float* __restrict__ dctx, const float* __restrict__ w2, __bf16* __restrict__ dPreU,
+    float* __restrict__ dw2, int T, int Bp) {
+    constexpr int W = 256, W2 = 128;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* a = sm;                         // [T]
+    float* ds = sm + T;                    // [T]  (da, then ds)
+    float* part = sm + 2 * T;              // [4][W2] partial dw2
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t rs = (size_t)Bp;
+    for (int t = tid; t < T; t += 256) a[t] = attn[(size_t)b * T + t];
+    const f32x4 dc = *reinterpret_cast<const f32x4*>(dctx + (size_t)b * W + 4 * lane);
+#pragma unroll 4
+    for (int t = wave; t < T; t += 4) {
+        const bf16x4_t v = *reinterpret_cast<const bf16x4_t*>(V + ((size_t)t * rs + b) * W + 4 * lane);
+        float s = dc[0] * (float)v[0];
+        s = fmaf(dc[1], (float)v[1], s); s = fmaf(dc[2], (float)v[2], s); s = fmaf(dc[3], (float)v[3], s);
+        s = wave_sum(s);
+        if (lane == 0) ds[t] = s;
+    }
+    __syncthreads();
+    float dot = 0.f;
+    for (int t = tid; t < T; t += 256) dot = fmaf(a[t], ds[t], dot);
+    dot = wave_sum(dot);
+    if (lane == 0) red[wave] = dot;
+    __syncthreads();
+    dot = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    for (int t = tid; t < T; t += 256) ds[t] = a[t] * (ds[t] - dot);
+    __syncthreads();
+    const float2 wv = *reinterpret_cast<const float2*>(w2 + 2 * lane);
+    float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll 4
+    for (int t = wave; t < T; t += 4) {
+        const size_t ro = ((size_t)t * rs + b) * W2 + 2 * lane;
+        const float2 u = *reinterpret_cast<const float2*>(U + ro);
+        const float d = ds[t];
+        acc0 = fmaf(d, u.x, acc0);
+        acc1 = fmaf(d, u.y, acc1);
+        bf16x2_t o = {(__bf16)(d * wv.x * (1.f - u.x * u.x)), (__bf16)(d * wv.y * (1.f - u.y * u.y))};
+        *reinterpret_cast<bf16x2_t*>(dPreU + ro) = o;
+    }
+    part[wave * W2 + 2 * lane] = acc0;
+    part[wave * W2 + 2 * lane + 1] = acc1;
+    __syncthreads();
+    if (tid < W2) atomicAdd(dw2 + tid, part[tid] + part[W2 + tid] + part[2 * W2 + tid] + part[3 * W2 + tid]);
+}
+
 }  // namespace
 
 extern "C" int lob_dropout_f32(const float* in, float* out, int64_t n, float p, uint64_t seed, void* stream) {
@@ -476,6 +584,14 @@ extern "C" int lob_attn_pool_fwd_f32(const void* V, int v_bf16, const float* U, 
     if (!V || !ctx || !attn || T <= 0 || B <= 0 || Bp < B || W <= 0) return LOB_E_ARG;
     if (U && (!w2 || W2 <= 0)) return LOB_E_ARG;
     if ((size_t)T * sizeof(float) > 60 * 1024) return LOB_E_SHAPE;
+    const bool al8 = ((reinterpret_cast<uintptr_t>(V) | reinterpret_cast<uintptr_t>(U) | reinterpret_cast<uintptr_t>(w2)) & 7) == 0;
+    if (v_bf16 && U && W == 256 && W2 == 128 && al8) {
+        const size_t smem = ((size_t)((T + 3) & ~3) + 4 * 256) * sizeof(float);
+        hipLaunchKernelGGL(attn_pool_fwd_vec_kernel, dim3(B), dim3(256), smem, (hipStream_t)stream,
+                           reinterpret_cast<const __bf16*>(V), U, w2, b2, ctx, attn, T, Bp);
+        LOB_CHECK_LAUNCH();
+        return 0;
+    }
     if (v_bf16)
         hipLaunchKernelGGL((attn_pool_fwd_kernel<__bf16>), dim3(B), dim3(256), (size_t)T * sizeof(float), (hipStream_t)stream,
                            reinterpret_cast<const __bf16*>(V), U, w2, b2, ctx, attn, T, Bp, W, W2);
@@ -553,6 +669,15 @@ extern "C" int lob_attn_pool_bwd_f32(const void* V, int v_bf16, const float* U, 
     if (T <= 0 || B <= 0 || Bp < B || W <= 0) return LOB_E_ARG;
     const size_t smem = ((size_t)2 * T + W) * sizeof(float);
     if (smem > 60 * 1024) return LOB_E_SHAPE;
+    if (v_bf16 && du_bf16 && U && !dV && W == 256 && W2 == 128 &&
+        ((reinterpret_cast<uintptr_t>(V) | reinterpret_cast<uintptr_t>(U) | reinterpret_cast<uintptr_t>(w2) |
+          reinterpret_cast<uintptr_t>(dctx)) & 15) == 0 && (reinterpret_cast<uintptr_t>(dPreU) & 3) == 0) {
+        const size_t sm2 = ((size_t)2 * T + 4 * 128) * sizeof(float);
+        hipLaunchKernelGGL(attn_pool_bwd_vec_kernel, dim3(B), dim3(256), sm2, (hipStream_t)stream,
+                           reinterpret_cast<const __bf16*>(V), U, attn, dctx, w2, reinterpret_cast<__bf16*>(dPreU), dw2, T, Bp);
+        LOB_CHECK_LAUNCH();
+        return 0;
+    }
 #define LOB_APB(VE, UE) hipLaunchKernelGGL((attn_pool_bwd_kernel<VE, UE>), dim3(B), dim3(256), smem, (hipStream_t)stream, \
         reinterpret_cast<const VE*>(V), U, attn, dctx, w2, dV, reinterpret_cast<UE*>(dPreU), dw2, T, Bp, W, W2)
     if (v_bf16 && du_bf16) LOB_APB(__bf16, __bf16);
