@@ -96,8 +96,11 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad):
                     ops.gemm_tn(a_sl[:(T - 1) * Bp], y_sl[Bp:], dwhh, mixed=mixed)
             g[base + 4 * d + 0] = dwih[d * 4 * H:(d + 1) * 4 * H]
             g[base + 4 * d + 1] = dwhh
+            # b_ih and b_hh have the same gradient, but they must not receive the same tensor OBJECT: autograd may
+            # then install one tensor as the .grad of both parameters, and an in-place clip_grad_norm_ (04:501) would
+            # scale it twice
             g[base + 4 * d + 2] = dbias[d * 4 * H:(d + 1) * 4 * H]
-            g[base + 4 * d + 3] = dbias[d * 4 * H:(d + 1) * 4 * H]
+            g[base + 4 * d + 3] = dbias[d * 4 * H:(d + 1) * 4 * H].clone()
         # dX of this layer = dY of the layer below; when that layer's output dropout was fused into its
         # producer, its backward (the same mask) is fused into this GEMM's epilogue
         below_fused = layer > 0 and sv["layers"][layer - 1]["fused_drop"]

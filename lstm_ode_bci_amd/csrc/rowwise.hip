@@ -249,6 +249,20 @@ __device__ __forceinline__ void stv_bf16(__bf16* p, const float (&v)[VPL]) {
     *reinterpret_cast<bvec*>(p) = t;
 }
 
+// Row enumeration for the (b,t) -> (t,b) relayout: index g walks 8 x 8 (window, time) tiles, so that 64 consecutive
+// waves touch 8 runs of 8 consecutive rows on the (b,t)-ordered side AND 8 runs of 8 consecutive rows on the
+// time-major side (a plain row-by-row walk reads one side in 512-B pieces 2 MB apart).
+__device__ __forceinline__ bool tiled_row(int g, int T, int B, int Bp, int& row, int& orow) {
+    const int ntt = (T + 7) >> 3;
+    const int tile = g >> 6, r = g & 63;
+    const int b = (tile / ntt) * 8 + (r >> 3), t = (tile % ntt) * 8 + (r & 7);
+    if (b >= B || t >= T) return false;
+    row = b * T + t;
+    orow = t * Bp + b;
+    return true;
+}
+__device__ __forceinline__ int tiled_count(int T, int B) { return ((B + 7) >> 3) * ((T + 7) >> 3) * 64; }
+
 template <int VPL, bool OUT_BF16>
 __global__ __launch_bounds__(256) void layernorm_act_vec_kernel(
     const float* __restrict__ in, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -267,7 +281,10 @@ __global__ __launch_bounds__(256) void layernorm_act_vec_kernel(
         for (int i = 0; i < VPL; ++i) { gm[i] = 1.f; bt[i] = 0.f; }
     }
     const float invw = 1.0f / (float)width;
-    for (int row = wave; row < rows; row += nwaves) {
+    const int count = remap_T > 0 ? tiled_count(remap_T, remap_B) : rows;
+    for (int g = wave; g < count; g += nwaves) {
+        int row = g, orow = g;
+        if (remap_T > 0 && !tiled_row(g, remap_T, remap_B, remap_Bp, row, orow)) continue;
         float v[VPL];
         ldv<VPL>(in + (size_t)row * width + lane * VPL, v);
         float s = 0.f;
@@ -278,8 +295,6 @@ __global__ __launch_bounds__(256) void layernorm_act_vec_kernel(
 #pragma unroll
         for (int i = 0; i < VPL; ++i) { const float dl = v[i] - mean; q += dl * dl; }
         const float rstd = norm ? rsqrtf(wave_sum(q) * invw + eps) : 1.f;
-        int orow = row;
-        if (remap_T > 0) { const int b = row / remap_T, t = row % remap_T; orow = t * remap_Bp + b; }
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             float o = (v[i] - mean) * rstd * gm[i] + bt[i];
@@ -310,9 +325,10 @@ __global__ __launch_bounds__(256) void layernorm_act_bwd_vec_kernel(
 #pragma unroll
     for (int i = 0; i < VPL; ++i) { dga[i] = 0.f; dba[i] = 0.f; if (!norm) { gm[i] = 1.f; bt[i] = 0.f; } }
     const float invw = 1.0f / (float)width;
-    for (int row = wave; row < rows; row += nwaves) {
-        int orow = row;
-        if (remap_T > 0) { const int b = row / remap_T, t = row % remap_T; orow = t * remap_Bp + b; }
+    const int count = remap_T > 0 ? tiled_count(remap_T, remap_B) : rows;
+    for (int g = wave; g < count; g += nwaves) {
+        int row = g, orow = g;
+        if (remap_T > 0 && !tiled_row(g, remap_T, remap_B, remap_Bp, row, orow)) continue;
         float v[VPL], go[VPL];
         ldv<VPL>(x + (size_t)row * width + lane * VPL, v);
         ldv<VPL>(dy + (size_t)orow * width + lane * VPL, go);

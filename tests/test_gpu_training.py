@@ -298,3 +298,22 @@ def test_mixed_recurrent_kernels_short_sequences(dev, T, B, bi, L):
         # almost equal terms (max |grad| ~1e-5): the bf16 rounding of v shows up relatively larger there
         tol = 6e-2 if k.startswith("attention") else 2e-2
         assert np.abs(p.grad.cpu().numpy() - r).max() < tol * np.abs(r).max(), k
+
+
+def test_bias_gradients_are_distinct_tensors(dev):
+    """b_ih and b_hh share their gradient VALUE; if they shared the tensor, torch's in-place clip_grad_norm_
+    (the reference's loop, 04:501) would scale it twice."""
+    from lstm_ode_bci_amd import EnhancedLSTMModel
+    sd = syn.make_state_dict(5, 8, 2, 2, True, seed=3)
+    x, y = syn.make_windows(4, 6, 5, seed=1)
+    m = _load(EnhancedLSTMModel(5, 8, 2, 2, 0.0, True), sd, dev).train()
+    for _ in range(3):
+        m.zero_grad(set_to_none=True)
+        torch.nn.functional.cross_entropy(m(torch.from_numpy(x).to(dev)), torch.from_numpy(y).to(dev)).backward()
+        ptrs = [p.grad.data_ptr() for p in m.parameters()]
+        assert len(set(ptrs)) == len(ptrs)
+        before = {k: p.grad.clone() for k, p in m.named_parameters()}
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 1e-3)
+        ratio = {k: float((p.grad.norm() / before[k].norm()).item()) for k, p in m.named_parameters()
+                 if float(before[k].norm()) > 0}
+        assert max(ratio.values()) - min(ratio.values()) < 1e-5 * max(ratio.values()), ratio
