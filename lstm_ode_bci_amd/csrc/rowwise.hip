@@ -282,28 +282,43 @@ __global__ __launch_bounds__(256) void layernorm_act_vec_kernel(
     }
     const float invw = 1.0f / (float)width;
     const int count = remap_T > 0 ? tiled_count(remap_T, remap_B) : rows;
-    for (int g = wave; g < count; g += nwaves) {
-        int row = g, orow = g;
-        if (remap_T > 0 && !tiled_row(g, remap_T, remap_B, remap_Bp, row, orow)) continue;
-        float v[VPL];
-        ldv<VPL>(in + (size_t)row * width + lane * VPL, v);
-        float s = 0.f;
+    // RPW rows per wave in flight: with one 512-B / 1-KB row per wave the CU has too few bytes outstanding to cover the
+    // HBM latency (measured 2.1 TB/s at width 128 against 4.6 at width 256 with the same code)
+    constexpr int RPW = VPL <= 2 ? 4 : 2;
+    for (int g0 = wave * RPW; g0 < count; g0 += nwaves * RPW) {
+        float vv[RPW][VPL];
+        int rowv[RPW], orowv[RPW];
+        bool ok[RPW];
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) s += v[i];
-        const float mean = norm ? wave_sum(s) * invw : 0.f;
-        float q = 0.f;
-#pragma unroll
-        for (int i = 0; i < VPL; ++i) { const float dl = v[i] - mean; q += dl * dl; }
-        const float rstd = norm ? rsqrtf(wave_sum(q) * invw + eps) : 1.f;
-#pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-            float o = (v[i] - mean) * rstd * gm[i] + bt[i];
-            o = apply_act(o, act);
-            if (drop_p > 0.f) o *= lob_dropout_scale(seed, (uint64_t)orow * width + lane * VPL + i, drop_p);
-            v[i] = o;
+        for (int r = 0; r < RPW; ++r) {
+            const int g = g0 + r;
+            rowv[r] = g; orowv[r] = g;
+            ok[r] = g < count && (remap_T <= 0 || tiled_row(g, remap_T, remap_B, remap_Bp, rowv[r], orowv[r]));
+            if (ok[r]) ldv<VPL>(in + (size_t)rowv[r] * width + lane * VPL, vv[r]);
         }
-        if (OUT_BF16) stv_bf16<VPL>(reinterpret_cast<__bf16*>(outv) + (size_t)orow * width + lane * VPL, v);
-        else          stv<VPL>(reinterpret_cast<float*>(outv) + (size_t)orow * width + lane * VPL, v);
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            if (!ok[r]) continue;
+            float (&v)[VPL] = vv[r];
+            const int orow = orowv[r];
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) s += v[i];
+            const float mean = norm ? wave_sum(s) * invw : 0.f;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) { const float dl = v[i] - mean; q += dl * dl; }
+            const float rstd = norm ? rsqrtf(wave_sum(q) * invw + eps) : 1.f;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                float o = (v[i] - mean) * rstd * gm[i] + bt[i];
+                o = apply_act(o, act);
+                if (drop_p > 0.f) o *= lob_dropout_scale(seed, (uint64_t)orow * width + lane * VPL + i, drop_p);
+                v[i] = o;
+            }
+            if (OUT_BF16) stv_bf16<VPL>(reinterpret_cast<__bf16*>(outv) + (size_t)orow * width + lane * VPL, v);
+            else          stv<VPL>(reinterpret_cast<float*>(outv) + (size_t)orow * width + lane * VPL, v);
+        }
     }
 }
 
@@ -326,48 +341,64 @@ __global__ __launch_bounds__(256) void layernorm_act_bwd_vec_kernel(
     for (int i = 0; i < VPL; ++i) { dga[i] = 0.f; dba[i] = 0.f; if (!norm) { gm[i] = 1.f; bt[i] = 0.f; } }
     const float invw = 1.0f / (float)width;
     const int count = remap_T > 0 ? tiled_count(remap_T, remap_B) : rows;
-    for (int g = wave; g < count; g += nwaves) {
-        int row = g, orow = g;
-        if (remap_T > 0 && !tiled_row(g, remap_T, remap_B, remap_Bp, row, orow)) continue;
-        float v[VPL], go[VPL];
-        ldv<VPL>(x + (size_t)row * width + lane * VPL, v);
-        ldv<VPL>(dy + (size_t)orow * width + lane * VPL, go);
-        if (pool_attn) {     // rows are (t, b) time-major: dy += attn[b][t] * dctx[b][:] (Attention's context path)
-            const int t = row / pool_Bp, b = row % pool_Bp;
-            if (b < pool_B) {
-                const float a = pool_attn[(size_t)b * pool_T + t];
-                float dcv[VPL];
-                ldv<VPL>(pool_dctx + (size_t)b * width + lane * VPL, dcv);
+    constexpr int RPW = VPL <= 2 ? 4 : 2;       // rows per wave in flight (see the forward kernel)
+    for (int g0 = wave * RPW; g0 < count; g0 += nwaves * RPW) {
+        float vv[RPW][VPL], gov[RPW][VPL];
+        int rowv[RPW], orowv[RPW];
+        bool ok[RPW];
 #pragma unroll
-                for (int i = 0; i < VPL; ++i) go[i] = fmaf(a, dcv[i], go[i]);
+        for (int r = 0; r < RPW; ++r) {
+            const int g = g0 + r;
+            rowv[r] = g; orowv[r] = g;
+            ok[r] = g < count && (remap_T <= 0 || tiled_row(g, remap_T, remap_B, remap_Bp, rowv[r], orowv[r]));
+            if (ok[r]) {
+                ldv<VPL>(x + (size_t)rowv[r] * width + lane * VPL, vv[r]);
+                ldv<VPL>(dy + (size_t)orowv[r] * width + lane * VPL, gov[r]);
             }
         }
-        float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) s += v[i];
-        const float mean = norm ? wave_sum(s) * invw : 0.f;
-        float q = 0.f;
+        for (int r = 0; r < RPW; ++r) {
+            if (!ok[r]) continue;
+            float (&v)[VPL] = vv[r];
+            float (&go)[VPL] = gov[r];
+            const int row = rowv[r], orow = orowv[r];
+            if (pool_attn) {     // rows are (t, b) time-major: dy += attn[b][t] * dctx[b][:] (Attention's context path)
+                const int t = row / pool_Bp, b = row % pool_Bp;
+                if (b < pool_B) {
+                    const float a = pool_attn[(size_t)b * pool_T + t];
+                    float dcv[VPL];
+                    ldv<VPL>(pool_dctx + (size_t)b * width + lane * VPL, dcv);
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) { const float dl = v[i] - mean; q += dl * dl; }
-        const float rstd = norm ? rsqrtf(wave_sum(q) * invw + eps) : 1.f;
-        float m1 = 0.f, m2 = 0.f;
+                    for (int i = 0; i < VPL; ++i) go[i] = fmaf(a, dcv[i], go[i]);
+                }
+            }
+            float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-            const float xh = (v[i] - mean) * rstd;
-            float g = go[i];
-            if (drop_p > 0.f) g *= lob_dropout_scale(seed, (uint64_t)orow * width + lane * VPL + i, drop_p);
-            if (act == LOB_ACT_GELU) g *= gelu_grad(xh * gm[i] + bt[i]);
-            dga[i] += g * xh;
-            dba[i] += g;
-            const float dxh = g * gm[i];
-            v[i] = xh; go[i] = dxh;
-            m1 += dxh; m2 += dxh * xh;
+            for (int i = 0; i < VPL; ++i) s += v[i];
+            const float mean = norm ? wave_sum(s) * invw : 0.f;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) { const float dl = v[i] - mean; q += dl * dl; }
+            const float rstd = norm ? rsqrtf(wave_sum(q) * invw + eps) : 1.f;
+            float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                const float xh = (v[i] - mean) * rstd;
+                float g = go[i];
+                if (drop_p > 0.f) g *= lob_dropout_scale(seed, (uint64_t)orow * width + lane * VPL + i, drop_p);
+                if (act == LOB_ACT_GELU) g *= gelu_grad(xh * gm[i] + bt[i]);
+                dga[i] += g * xh;
+                dba[i] += g;
+                const float dxh = g * gm[i];
+                v[i] = xh; go[i] = dxh;
+                m1 += dxh; m2 += dxh * xh;
+            }
+            m1 = norm ? wave_sum(m1) * invw : 0.f;
+            m2 = norm ? wave_sum(m2) * invw : 0.f;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) v[i] = rstd * (go[i] - m1 - v[i] * m2);
+            stv<VPL>(dx + (size_t)row * width + lane * VPL, v);
         }
-        m1 = norm ? wave_sum(m1) * invw : 0.f;
-        m2 = norm ? wave_sum(m2) * invw : 0.f;
-#pragma unroll
-        for (int i = 0; i < VPL; ++i) v[i] = rstd * (go[i] - m1 - v[i] * m2);
-        stv<VPL>(dx + (size_t)row * width + lane * VPL, v);
     }
     // block-level reduction of the affine gradients, then ONE atomic per column per block
 #pragma unroll
