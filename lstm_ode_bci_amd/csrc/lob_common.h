@@ -43,10 +43,22 @@ __device__ __forceinline__ float apply_act(float x, int act) {
     return x;
 }
 
+// Sum over the 64 lanes, result in every lane.  DPP (data-parallel primitives: the cross-lane operand rides on the
+// VALU instruction) instead of six ds_bpermute round trips through the LDS pipeline -- the row-wise kernels do 2-4 of
+// these per 512-B row and were bound by them.  Steps: quad swaps, half-row / row mirrors (every lane of a 16-lane
+// row then holds the row's sum), row_bcast15 / row_bcast31 carry the running sum into the later rows, lane 63 ends
+// with the total, which is read back as a scalar.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+#define LOB_DPP_ADD(CTRL, ROWMASK)                                                                          \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xf, false))
+    LOB_DPP_ADD(0xB1, 0xf);      // quad_perm [1,0,3,2]
+    LOB_DPP_ADD(0x4E, 0xf);      // quad_perm [2,3,0,1]
+    LOB_DPP_ADD(0x141, 0xf);     // row_half_mirror
+    LOB_DPP_ADD(0x140, 0xf);     // row_mirror
+    LOB_DPP_ADD(0x142, 0xa);     // row_bcast:15 -> rows 1 and 3
+    LOB_DPP_ADD(0x143, 0xc);     // row_bcast:31 -> rows 2 and 3
+#undef LOB_DPP_ADD
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
