@@ -19,8 +19,10 @@ from . import ops
 def input_gradients(lstm_model, X_batch, target_class=None):
     """Per-window gradient of the chosen logit w.r.t. the window: ``(grad (B,T,C), pred_class (B,))``.
     ``target_class=None`` uses the predicted class of each window (07:245-246)."""
+    from .autograd import input_grad_only
     X_batch = X_batch.detach().clone().requires_grad_(True)
-    outputs = lstm_model(X_batch)
+    with input_grad_only():          # only d logit / d x is wanted: no weight-gradient GEMMs in the backward
+        outputs = lstm_model(X_batch)
     if isinstance(outputs, tuple):
         outputs = outputs[0]
     pred = outputs.argmax(dim=1) if target_class is None else target_class

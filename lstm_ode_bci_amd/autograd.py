@@ -146,7 +146,25 @@ class _LobModelFn(torch.autograd.Function):
         from .backward import backward_impl
         gx, gps = backward_impl(ctx.sv, ctx.ps, ctx.cfg, ctx.x_shape, dlogits.contiguous().float(),
                                 ctx.needs_input_grad)
-        return (gx, None) + tuple(gps)
+        need = ctx.needs_input_grad
+        return (gx, None) + tuple(g if need[2 + i] else None for i, g in enumerate(gps))
+
+
+_PARAM_GRADS = True
+
+
+class input_grad_only:
+    """Context manager: forwards run inside it track the gradient w.r.t. the input windows only -- the parameters
+    enter the autograd node detached, so its backward skips every weight-gradient GEMM (a third of the backward).
+    Used by the attribution path (07_explainability.py:239-263 reads X.grad, never a parameter gradient)."""
+
+    def __enter__(self):
+        global _PARAM_GRADS
+        self._old, _PARAM_GRADS = _PARAM_GRADS, False
+
+    def __exit__(self, *exc):
+        global _PARAM_GRADS
+        _PARAM_GRADS = self._old
 
 
 def lob_forward(model, x, drops, seed):
@@ -159,8 +177,11 @@ def lob_forward(model, x, drops, seed):
     mixed = bool(torch.is_autocast_enabled("cuda")) or getattr(model, "gate_gemm_dtype", "f32") == "bf16"
     cfg = (model.num_layers, model.num_directions, model.hidden_size, tuple(float(d) for d in drops), int(seed),
            mixed)
+    params = _collect(model)
+    if not _PARAM_GRADS:
+        params = [None if p is None else p.detach() for p in params]
     with torch.autocast(device_type="cuda", enabled=False):
-        return _LobModelFn.apply(x, cfg, *_collect(model))
+        return _LobModelFn.apply(x, cfg, *params)
 
 
 def attention_forward(lstm_output, w1, b1, w2, b2):

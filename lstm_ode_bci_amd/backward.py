@@ -18,11 +18,13 @@ def _t(w):
     return w.t().contiguous()
 
 
-def _linear_bwd(dy, x, w, need_dx=True):
+def _linear_bwd(dy, x, w, need_dx=True, need_w=True):
     """y = x w^T + b  ->  (dx, dw, db)."""
-    dw = torch.zeros_like(w)
-    ops.gemm_tn(dy, x, dw)
-    db = ops.colsum(dy)
+    dw = db = None
+    if need_w:
+        dw = torch.zeros_like(w)
+        ops.gemm_tn(dy, x, dw)
+        db = ops.colsum(dy)
     dx = ops.gemm_nt(dy, _t(w)) if need_dx else None
     return dx, dw, db
 
@@ -35,17 +37,20 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad):
     Bp = ceil32(B)
     n = len(ps)
     g = [None] * n
+    # torch.autograd.grad(outputs, inputs=[x]) (the attribution path, 07:239-263) asks for the input gradient
+    # only: the weight-gradient GEMMs (a third of the backward) are skipped then
+    need_w = any(needs_input_grad[2:])
     i_ln, i_a0w, i_a0b, i_a2w, i_a2b = n - 12, n - 10, n - 9, n - 8, n - 7
     i_c0w, i_c3w, i_c6w = n - 6, n - 4, n - 2
 
     # ---- classifier (04:196-204)
-    dz2d, g[i_c6w], g[i_c6w + 1] = _linear_bwd(dlogits, sv["z2d"], ps[i_c6w])
+    dz2d, g[i_c6w], g[i_c6w + 1] = _linear_bwd(dlogits, sv["z2d"], ps[i_c6w], need_w=need_w)
     dz2 = ops.dropout(dz2d, p_cls, _seed(seed, 21)) if p_cls > 0 else dz2d
     dz2p = ops.act_bwd(dz2, sv["z2p"], ACT_GELU)
-    dz1d, g[i_c3w], g[i_c3w + 1] = _linear_bwd(dz2p, sv["z1d"], ps[i_c3w])
+    dz1d, g[i_c3w], g[i_c3w + 1] = _linear_bwd(dz2p, sv["z1d"], ps[i_c3w], need_w=need_w)
     dz1 = ops.dropout(dz1d, p_cls, _seed(seed, 20)) if p_cls > 0 else dz1d
     dz1p = ops.act_bwd(dz1, sv["z1p"], ACT_GELU)
-    dctx, g[i_c0w], g[i_c0w + 1] = _linear_bwd(dz1p, sv["ctx"], ps[i_c0w])
+    dctx, g[i_c0w], g[i_c0w + 1] = _linear_bwd(dz1p, sv["ctx"], ps[i_c0w], need_w=need_w)
 
     # ---- attention pooling (04:123-128)
     v, u = sv["v"], sv["u"]
@@ -59,9 +64,10 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad):
                                         want_dv=not fused, du_bf16=fused)
         g[i_a2w] = dw2.reshape(1, -1)
         g[i_a2b] = torch.zeros_like(ps[i_a2b])            # b2 cancels in the softmax: exactly 0
-        g[i_a0w] = torch.zeros_like(a0w)
-        ops.gemm_tn(dU, v, g[i_a0w], mixed=mixed)
-        g[i_a0b] = ops.colsum(dU)
+        if need_w:
+            g[i_a0w] = torch.zeros_like(a0w)
+            ops.gemm_tn(dU, v, g[i_a0w], mixed=mixed)
+            g[i_a0b] = ops.colsum(dU)
         if fused:
             w1t = _t(a0w)
             if ops.dma_ok(dU.shape[1], w1t.shape[0], dU.shape[0]):
@@ -82,10 +88,11 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad):
             dY = ops.dropout(dY, p_lstm, _seed(seed, 10 + layer))
         dP, dbias = ops.lstm_rec_bwd(lay["G"], lay["C"], lay["whh"], dY, T, Bp, H, D, dp_bf16=mixed)
         inp, Y, wih = lay["inp"], lay["Y"], lay["wih"]
-        dwih = torch.zeros_like(wih)
-        ops.gemm_tn(dP, inp, dwih, mixed=mixed)
         base = 4 + layer * 4 * D
-        for d in range(D):
+        if need_w:
+            dwih = torch.zeros_like(wih)
+            ops.gemm_tn(dP, inp, dwih, mixed=mixed)
+        for d in range(D if need_w else 0):
             dwhh = torch.zeros_like(ps[base + 4 * d + 1])
             if T > 1:
                 a_sl = dP[:, d * 4 * H:(d + 1) * 4 * H]
@@ -114,6 +121,6 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad):
     # ---- input projection: Linear -> LayerNorm -> GELU -> Dropout (04:173-178)
     dpre, g[2], g[3] = ops.layernorm_act_bwd(sv["pre"], ps[2], ps[3], dY, act=ACT_GELU, remap=(T, B, Bp),
                                              drop_p=p_in, seed=_seed(seed, 0))
-    gx2d, g[0], g[1] = _linear_bwd(dpre, sv["x2d"], ps[0], need_dx=bool(needs_input_grad[0]))
+    gx2d, g[0], g[1] = _linear_bwd(dpre, sv["x2d"], ps[0], need_dx=bool(needs_input_grad[0]), need_w=need_w)
     gx = gx2d.reshape(B, T, C) if gx2d is not None else None
     return gx, g

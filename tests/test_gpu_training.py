@@ -317,3 +317,25 @@ def test_bias_gradients_are_distinct_tensors(dev):
         ratio = {k: float((p.grad.norm() / before[k].norm()).item()) for k, p in m.named_parameters()
                  if float(before[k].norm()) > 0}
         assert max(ratio.values()) - min(ratio.values()) < 1e-5 * max(ratio.values()), ratio
+
+
+def test_input_grad_only_skips_parameter_gradients_and_matches(dev):
+    from lstm_ode_bci_amd import EnhancedLSTMModel
+    from lstm_ode_bci_amd.attribution import input_gradients
+    from lstm_ode_bci_amd.autograd import input_grad_only
+    sd = syn.make_state_dict(61, 128, 3, 2, True)
+    x, _ = syn.make_windows(40, 24, 61, seed=2)
+    m = _load(EnhancedLSTMModel(61, 128, 3, 2, 0.4, True), sd, dev).eval()
+    xb = torch.from_numpy(x).to(dev)
+    g_fast, pred = input_gradients(m, xb)
+    assert all(p.grad is None for p in m.parameters())
+    xr = xb.clone().requires_grad_(True)
+    out = m(xr)
+    out.gather(1, pred.reshape(-1, 1)).sum().backward()        # the full backward (weight gradients included)
+    assert all(p.grad is not None for p in m.parameters())
+    assert (xr.grad - g_fast).abs().max().item() <= 1e-6 * xr.grad.abs().max().item()
+    with input_grad_only():
+        pass
+    m.zero_grad(set_to_none=True)
+    m(xb.clone().requires_grad_(True)).sum().backward()         # the flag is restored after the context
+    assert m.classifier[6].weight.grad is not None
