@@ -160,20 +160,24 @@ int lob_layernorm_act_bwd_f32(const float* x, const float* gamma, const float* b
                               float* dx, float* dgamma, float* dbeta, int rows, int width, float eps,
                               int act, int remap_T, int remap_B, int remap_Bp, float drop_p,
                               uint64_t seed, const float* pool_attn, const float* pool_dctx,
-                              int pool_T, int pool_B, int pool_Bp, void* stream);
+                              int pool_T, int pool_B, int pool_Bp, float* dx_colsum, void* stream);
 /*   pool_attn != NULL (time-major rows, widths 128/256/512): dy[t*Bp+b][:] += pool_attn[b][t] * pool_dctx[b][:]
  *   before the LayerNorm backward -- the context path of the attention pooling, fused here instead of
- *   being written to HBM by lob_attn_pool_bwd_f32.                                              */
+ *   being written to HBM by lob_attn_pool_bwd_f32.
+ *   dx_colsum != NULL (same widths): dx_colsum[c] += sum_rows dx[row][c] -- the bias gradient of the Linear that
+ *   feeds this LayerNorm (input_proj.0.bias, 04:174), instead of a separate pass over dx.             */
 
 /* Backward of lob_attn_pool_fwd_f32.  dV [T*Bp][W] and dPreU [T*Bp][W2] are WRITTEN for rows
  * b < B (pad rows untouched); dw2 [W2] is accumulated (atomics).  dPreU is the gradient w.r.t.
  * the pre-tanh hidden W1 v + b1; the caller adds dPreU W1 into dV with lob_gemm_nt_f32.   */
 int lob_attn_pool_bwd_f32(const void* V, int v_bf16, const float* U, const float* attn, const float* dctx,
                           const float* w2, float* dV, void* dPreU, int du_bf16, float* dw2,
-                          int T, int B, int Bp, int W, int W2, void* stream);
+                          float* du_colsum, int T, int B, int Bp, int W, int W2, void* stream);
 /*   v_bf16 / du_bf16: V read / dPreU written as bf16 (mixed mode).  dV == NULL: the direct term
  *   a[t] * dctx is not materialised; pass pool_attn / pool_dctx to lob_layernorm_act_bwd_f32 instead.
- *   U == NULL (mean pooling): only dV = a[t] * dctx is written; w2, dPreU, dw2 are ignored.          */
+ *   U == NULL (mean pooling): only dV = a[t] * dctx is written; w2, dPreU, dw2 are ignored.
+ *   du_colsum != NULL (bf16 V and dPreU, dV == NULL, W = 256, W2 = 128 only): du_colsum[j] += sum_t dPreU[t][j]
+ *   -- the gradient of the score MLP's first bias (04:118) -- instead of a separate pass over dPreU.   */
 
 /* ------------------------------------------------------------------------------------
  * Row-wise LayerNorm (biased variance, eps) with affine, optional GELU, optional

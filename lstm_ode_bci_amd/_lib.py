@@ -42,8 +42,8 @@ _SIGS = {
     "lob_act_bwd_f32": ([_f32p, _f32p, _f32p, C.c_int64, C.c_int, C.c_void_p], C.c_int),
     "lob_layernorm_act_bwd_f32": ([_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_float,
                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, _f32p, _f32p,
-                                   C.c_int, C.c_int, C.c_int, C.c_void_p], C.c_int),
-    "lob_attn_pool_bwd_f32": ([_f32p, C.c_int, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, _f32p] +
+                                   C.c_int, C.c_int, C.c_int, _f32p, C.c_void_p], C.c_int),
+    "lob_attn_pool_bwd_f32": ([_f32p, C.c_int, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, _f32p, _f32p] +
                               [C.c_int] * 5 + [C.c_void_p], C.c_int),
     "lob_dropout_f32": ([_f32p, _f32p, C.c_int64, C.c_float, C.c_uint64, C.c_void_p], C.c_int),
     "lob_attn_pool_fwd_f32": ([_f32p, C.c_int, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -18,13 +18,14 @@ def _t(w):
     return w.t().contiguous()
 
 
-def _linear_bwd(dy, x, w, need_dx=True, need_w=True):
-    """y = x w^T + b  ->  (dx, dw, db)."""
-    dw = db = None
+def _linear_bwd(dy, x, w, need_dx=True, need_w=True, db=None):
+    """y = x w^T + b  ->  (dx, dw, db); db may be handed in when a producer of dy already summed its columns."""
+    dw = None
     if need_w:
         dw = torch.zeros_like(w)
         ops.gemm_tn(dy, x, dw)
-        db = ops.colsum(dy)
+        if db is None:
+            db = ops.colsum(dy)
     dx = ops.gemm_nt(dy, _t(w)) if need_dx else None
     return dx, dw, db
 
@@ -60,14 +61,17 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad):
         pool = None
     else:
         fused = v.dtype == torch.bfloat16        # mixed mode: bf16 v / dU, context path folded into the LN backward
+        # the score MLP's first-bias gradient = column sums of dU: emitted by the pooling backward itself where it can
+        cs_fused = need_w and ops.attn_bwd_fuses_colsum(v, u, not fused, fused)
+        du_cs = torch.zeros((u.shape[1],), device=u.device, dtype=torch.float32) if cs_fused else None
         dV, dU, dw2 = ops.attn_pool_bwd(v, u, sv["attn"], dctx, ps[i_a2w].reshape(-1), T, B, Bp,
-                                        want_dv=not fused, du_bf16=fused)
+                                        want_dv=not fused, du_bf16=fused, du_colsum=du_cs)
         g[i_a2w] = dw2.reshape(1, -1)
         g[i_a2b] = torch.zeros_like(ps[i_a2b])            # b2 cancels in the softmax: exactly 0
         if need_w:
             g[i_a0w] = torch.zeros_like(a0w)
             ops.gemm_tn(dU, v, g[i_a0w], mixed=mixed)
-            g[i_a0b] = ops.colsum(dU)
+            g[i_a0b] = du_cs if cs_fused else ops.colsum(dU)
         if fused:
             w1t = _t(a0w)
             if ops.dma_ok(dU.shape[1], w1t.shape[0], dU.shape[0]):
@@ -119,8 +123,12 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad):
         del dP
 
     # ---- input projection: Linear -> LayerNorm -> GELU -> Dropout (04:173-178)
+    # input_proj.0.bias gradient = column sums of dpre: emitted by the LayerNorm backward itself where it can
+    db_fused = need_w and ops.can_fuse_colsum(sv["pre"].shape[1])
+    db0 = torch.zeros((sv["pre"].shape[1],), device=dY.device, dtype=torch.float32) if db_fused else None
     dpre, g[2], g[3] = ops.layernorm_act_bwd(sv["pre"], ps[2], ps[3], dY, act=ACT_GELU, remap=(T, B, Bp),
-                                             drop_p=p_in, seed=_seed(seed, 0))
-    gx2d, g[0], g[1] = _linear_bwd(dpre, sv["x2d"], ps[0], need_dx=bool(needs_input_grad[0]), need_w=need_w)
+                                             drop_p=p_in, seed=_seed(seed, 0), dx_colsum=db0)
+    gx2d, g[0], g[1] = _linear_bwd(dpre, sv["x2d"], ps[0], need_dx=bool(needs_input_grad[0]), need_w=need_w,
+                                   db=db0)
     gx = gx2d.reshape(B, T, C) if gx2d is not None else None
     return gx, g

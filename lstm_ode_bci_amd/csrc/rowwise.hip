@@ -327,18 +327,19 @@ __global__ __launch_bounds__(256) void layernorm_act_bwd_vec_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
     int rows, float eps, int act, int remap_T, int remap_B, int remap_Bp, float drop_p, uint64_t seed,
-    const float* __restrict__ pool_attn, const float* __restrict__ pool_dctx, int pool_T, int pool_B, int pool_Bp) {
+    const float* __restrict__ pool_attn, const float* __restrict__ pool_dctx, int pool_T, int pool_B, int pool_Bp,
+    float* __restrict__ dx_colsum) {
     constexpr int width = 64 * VPL;
     __shared__ float red[2][4][width];
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    float gm[VPL], bt[VPL], dga[VPL], dba[VPL];
+    float gm[VPL], bt[VPL], dga[VPL], dba[VPL], dxs[VPL];
     const bool norm = !(act & LOB_LN_IDENTITY);
     act &= 0xff;
     if (norm) { ldv<VPL>(gamma + lane * VPL, gm); ldv<VPL>(beta + lane * VPL, bt); }
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) { dga[i] = 0.f; dba[i] = 0.f; if (!norm) { gm[i] = 1.f; bt[i] = 0.f; } }
+    for (int i = 0; i < VPL; ++i) { dga[i] = 0.f; dba[i] = 0.f; dxs[i] = 0.f; if (!norm) { gm[i] = 1.f; bt[i] = 0.f; } }
     const float invw = 1.0f / (float)width;
     const int count = remap_T > 0 ? tiled_count(remap_T, remap_B) : rows;
     constexpr int RPW = VPL <= 2 ? 4 : 2;       // rows per wave in flight (see the forward kernel)
@@ -396,9 +397,18 @@ __global__ __launch_bounds__(256) void layernorm_act_bwd_vec_kernel(
             m1 = norm ? wave_sum(m1) * invw : 0.f;
             m2 = norm ? wave_sum(m2) * invw : 0.f;
 #pragma unroll
-            for (int i = 0; i < VPL; ++i) v[i] = rstd * (go[i] - m1 - v[i] * m2);
+            for (int i = 0; i < VPL; ++i) { v[i] = rstd * (go[i] - m1 - v[i] * m2); dxs[i] += v[i]; }
             stv<VPL>(dx + (size_t)row * width + lane * VPL, v);
         }
+    }
+    if (dx_colsum) {      // column sums of dx = the bias gradient of the Linear that feeds this LayerNorm (04:174-175)
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) red[0][wib][lane * VPL + i] = dxs[i];
+        __syncthreads();
+        for (int c = threadIdx.x; c < width; c += 256)
+            atomicAdd(dx_colsum + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+        __syncthreads();
     }
     // block-level reduction of the affine gradients, then ONE atomic per column per block
 #pragma unroll
@@ -536,7 +546,7 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_vec_kernel(
 __global__ __launch_bounds__(256) void attn_pool_bwd_vec_kernel(
     const __bf16* __restrict__ V, const float* __restrict__ U, const float* __restrict__ attn,
     const float* __restrict__ dctx, const float* __restrict__ w2, __bf16* __restrict__ dPreU,
-    float* __restrict__ dw2, int T, int Bp) {
+    float* __restrict__ dw2, float* __restrict__ du_colsum, int T, int Bp) {
     constexpr int W = 256, W2 = 128;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* a = sm;                         // [T]
@@ -566,7 +576,7 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_vec_kernel(
     for (int t = tid; t < T; t += 256) ds[t] = a[t] * (ds[t] - dot);
     __syncthreads();
     const float2 wv = *reinterpret_cast<const float2*>(w2 + 2 * lane);
-    float acc0 = 0.f, acc1 = 0.f;
+    float acc0 = 0.f, acc1 = 0.f, cs0 = 0.f, cs1 = 0.f;
 #pragma unroll 4
     for (int t = wave; t < T; t += 4) {
         const size_t ro = ((size_t)t * rs + b) * W2 + 2 * lane;
@@ -574,13 +584,22 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_vec_kernel(
         const float d = ds[t];
         acc0 = fmaf(d, u.x, acc0);
         acc1 = fmaf(d, u.y, acc1);
-        bf16x2_t o = {(__bf16)(d * wv.x * (1.f - u.x * u.x)), (__bf16)(d * wv.y * (1.f - u.y * u.y))};
+        const float o0 = d * wv.x * (1.f - u.x * u.x), o1 = d * wv.y * (1.f - u.y * u.y);
+        cs0 += o0; cs1 += o1;
+        bf16x2_t o = {(__bf16)o0, (__bf16)o1};
         *reinterpret_cast<bf16x2_t*>(dPreU + ro) = o;
     }
     part[wave * W2 + 2 * lane] = acc0;
     part[wave * W2 + 2 * lane + 1] = acc1;
     __syncthreads();
     if (tid < W2) atomicAdd(dw2 + tid, part[tid] + part[W2 + tid] + part[2 * W2 + tid] + part[3 * W2 + tid]);
+    if (du_colsum) {      // column sums of dPreU = the gradient of the score MLP's first bias (04:118)
+        __syncthreads();
+        part[wave * W2 + 2 * lane] = cs0;
+        part[wave * W2 + 2 * lane + 1] = cs1;
+        __syncthreads();
+        if (tid < W2) atomicAdd(du_colsum + tid, part[tid] + part[W2 + tid] + part[2 * W2 + tid] + part[3 * W2 + tid]);
+    }
 }
 
 }  // namespace
@@ -679,7 +698,7 @@ extern "C" int lob_layernorm_act_bwd_f32(const float* x, const float* gamma, con
                                          float* dx, float* dgamma, float* dbeta, int rows, int width, float eps,
                                          int act, int remap_T, int remap_B, int remap_Bp, float drop_p,
                                          uint64_t seed, const float* pool_attn, const float* pool_dctx,
-                                         int pool_T, int pool_B, int pool_Bp, void* stream) {
+                                         int pool_T, int pool_B, int pool_Bp, float* dx_colsum, void* stream) {
     const bool ident = (act & LOB_LN_IDENTITY) != 0;
     if (!x || !dy || !dx || rows <= 0 || width <= 0) return LOB_E_ARG;
     if (!ident && (!gamma || !beta || !dgamma || !dbeta)) return LOB_E_ARG;
@@ -693,14 +712,14 @@ extern "C" int lob_layernorm_act_bwd_f32(const float* x, const float* gamma, con
         if (blocks > 256 * 8) blocks = 256 * 8;
 #define LOB_LNB_VEC(V) hipLaunchKernelGGL((layernorm_act_bwd_vec_kernel<V>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, \
                        x, gamma, beta, dy, dx, dgamma, dbeta, rows, eps, act, remap_T, remap_B, remap_Bp, drop_p, seed, \
-                       pool_attn, pool_dctx, pool_T, pool_B, pool_Bp)
+                       pool_attn, pool_dctx, pool_T, pool_B, pool_Bp, dx_colsum)
         if (pool_attn && (!pool_dctx || pool_T <= 0 || pool_Bp <= 0 || rows != pool_T * pool_Bp || remap_T)) return LOB_E_SHAPE;
         if (width == 128) LOB_LNB_VEC(2); else if (width == 256) LOB_LNB_VEC(4); else LOB_LNB_VEC(8);
 #undef LOB_LNB_VEC
         LOB_CHECK_LAUNCH();
         return 0;
     }
-    if (pool_attn) return LOB_E_SHAPE;        // the fused pooling term exists on the vectorised path only
+    if (pool_attn || dx_colsum) return LOB_E_SHAPE;        // the fused pooling term / column sums exist on the vectorised path only
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(layernorm_act_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, dy,
                        dx, dgamma, dbeta, rows, width, eps, act, remap_T, remap_B, remap_Bp, drop_p, seed);
@@ -710,7 +729,7 @@ extern "C" int lob_layernorm_act_bwd_f32(const float* x, const float* gamma, con
 
 extern "C" int lob_attn_pool_bwd_f32(const void* V, int v_bf16, const float* U, const float* attn, const float* dctx,
                                      const float* w2, float* dV, void* dPreU, int du_bf16, float* dw2,
-                                     int T, int B, int Bp, int W, int W2, void* stream) {
+                                     float* du_colsum, int T, int B, int Bp, int W, int W2, void* stream) {
     if (!V || !attn || !dctx) return LOB_E_ARG;
     if (U ? (!w2 || !dPreU || !dw2 || W2 <= 0) : !dV) return LOB_E_ARG;
     if (T <= 0 || B <= 0 || Bp < B || W <= 0) return LOB_E_ARG;
@@ -721,10 +740,11 @@ extern "C" int lob_attn_pool_bwd_f32(const void* V, int v_bf16, const float* U, 
           reinterpret_cast<uintptr_t>(dctx)) & 15) == 0 && (reinterpret_cast<uintptr_t>(dPreU) & 3) == 0) {
         const size_t sm2 = ((size_t)2 * T + 4 * 128) * sizeof(float);
         hipLaunchKernelGGL(attn_pool_bwd_vec_kernel, dim3(B), dim3(256), sm2, (hipStream_t)stream,
-                           reinterpret_cast<const __bf16*>(V), U, attn, dctx, w2, reinterpret_cast<__bf16*>(dPreU), dw2, T, Bp);
+                           reinterpret_cast<const __bf16*>(V), U, attn, dctx, w2, reinterpret_cast<__bf16*>(dPreU), dw2, du_colsum, T, Bp);
         LOB_CHECK_LAUNCH();
         return 0;
     }
+    if (du_colsum) return LOB_E_SHAPE;        // fused column sums exist on the vectorised path only
 #define LOB_APB(VE, UE) hipLaunchKernelGGL((attn_pool_bwd_kernel<VE, UE>), dim3(B), dim3(256), smem, (hipStream_t)stream, \
         reinterpret_cast<const VE*>(V), U, attn, dctx, w2, dV, reinterpret_cast<UE*>(dPreU), dw2, T, Bp, W, W2)
     if (v_bf16 && du_bf16) LOB_APB(__bf16, __bf16);

@@ -310,9 +310,11 @@ def act_bwd(dy, pre, kind):
     return dx
 
 
-def layernorm_act_bwd(x, gamma, beta, dy, act=ACT_NONE, eps=1e-5, remap=None, drop_p=0.0, seed=0, pool=None):
+def layernorm_act_bwd(x, gamma, beta, dy, act=ACT_NONE, eps=1e-5, remap=None, drop_p=0.0, seed=0, pool=None,
+                      dx_colsum=None):
     """Returns (dx [rows,width] in INPUT row order, dgamma, dbeta).  pool=(attn [B,T], dctx [B,width], T, B, Bp)
-    adds attn[b][t] * dctx[b] to dy on the fly (context path of the attention pooling)."""
+    adds attn[b][t] * dctx[b] to dy on the fly (context path of the attention pooling).  dx_colsum [width]
+    (widths 128/256/512): += column sums of dx (see ``can_fuse_colsum``)."""
     _chk(x, "x"); _chk(gamma, "gamma"); _chk(beta, "beta"); _chk(dy, "dy")
     rows, width = x.shape
     rT, rB, rBp = (0, 0, 0) if remap is None else remap
@@ -326,12 +328,17 @@ def layernorm_act_bwd(x, gamma, beta, dy, act=ACT_NONE, eps=1e-5, remap=None, dr
     pa, pd, pT, pB, pBp = (None, None, 0, 0, 0) if pool is None else pool
     rc = _lib.lib().lob_layernorm_act_bwd_f32(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(dy), _ptr(dx), _ptr(dg), _ptr(db),
                                               rows, width, eps, act, rT, rB, rBp, float(drop_p), C.c_uint64(seed),
-                                              _ptr(pa), _ptr(pd), pT, pB, pBp, _stream())
+                                              _ptr(pa), _ptr(pd), pT, pB, pBp, _ptr(dx_colsum), _stream())
     _lib.check(rc, "lob_layernorm_act_bwd_f32")
     return dx, dg, db
 
 
-def attn_pool_bwd(v, u, attn, dctx, w2, T, B, Bp, want_dv=True, du_bf16=False):
+def can_fuse_colsum(width):
+    """The vectorised LayerNorm backward (these widths) can emit the column sums of dx itself."""
+    return width in (128, 256, 512)
+
+
+def attn_pool_bwd(v, u, attn, dctx, w2, T, B, Bp, want_dv=True, du_bf16=False, du_colsum=None):
     """Returns (dV [T*Bp,W] fp32 or None, dPreU [T*Bp,W2] fp32|bf16, dw2 [W2]); pad rows are zero.
     want_dv=False: the direct term a[t]*dctx is left to layernorm_act_bwd(pool=...)."""
     v16 = v.dtype == torch.bfloat16
@@ -341,7 +348,7 @@ def attn_pool_bwd(v, u, attn, dctx, w2, T, B, Bp, want_dv=True, du_bf16=False):
     if u is None:                # mean pooling: dV = dctx / T only
         dV = alloc((T * Bp, W), device=v.device, dtype=torch.float32)
         rc = _lib.lib().lob_attn_pool_bwd_f32(_ptr(v), int(v16), None, _ptr(attn), _ptr(dctx), None, _ptr(dV), None, 0,
-                                              None, T, B, Bp, W, 0, _stream())
+                                              None, None, T, B, Bp, W, 0, _stream())
         _lib.check(rc, "lob_attn_pool_bwd_f32")
         return dV, None, None
     W2 = u.shape[1]
@@ -349,9 +356,15 @@ def attn_pool_bwd(v, u, attn, dctx, w2, T, B, Bp, want_dv=True, du_bf16=False):
     dU = alloc((T * Bp, W2), device=v.device, dtype=torch.bfloat16 if du_bf16 else torch.float32)
     dw2 = torch.zeros((W2,), device=v.device, dtype=torch.float32)
     rc = _lib.lib().lob_attn_pool_bwd_f32(_ptr(v), int(v16), _ptr(u), _ptr(attn), _ptr(dctx), _ptr(w2), _ptr(dV),
-                                          _ptr(dU), int(du_bf16), _ptr(dw2), T, B, Bp, W, W2, _stream())
+                                          _ptr(dU), int(du_bf16), _ptr(dw2), _ptr(du_colsum), T, B, Bp, W, W2, _stream())
     _lib.check(rc, "lob_attn_pool_bwd_f32")
     return dV, dU, dw2
+
+
+def attn_bwd_fuses_colsum(v, u, want_dv, du_bf16):
+    """Shapes for which lob_attn_pool_bwd_f32 can accumulate the column sums of dPreU itself."""
+    return (v.dtype == torch.bfloat16 and du_bf16 and not want_dv and u is not None and v.shape[1] == 256
+            and u.shape[1] == 128)
 
 
 # ---------------------------------------------------------------------------------------------
