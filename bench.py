@@ -91,7 +91,7 @@ def kernel_roofline(dev, B, mode, precision):
 
     rows, N = T * Bp, D * 4 * H
     K = D * H
-    bf16_rec = mixed and H == 128                       # bf16-MFMA recurrent kernels exist at H = 128
+    bf16_rec = mixed and ops.bf16_rec(H, ops.PG_BF16)   # bf16-MFMA recurrent kernels: H = 128 and 256
     pe = 2.0 if (bf16_rec and ops.PG_BF16) else 4.0     # bytes per stored pre-activation / saved gate
     de = 2.0 if mixed else 4.0                          # bytes per dP element
     # operand storage types as the step itself uses them: in mixed mode at H = 128 the layer below hands

@@ -135,17 +135,21 @@ int lob_gate_gemm_x_bf16(const void* X, int x_bf16, int ldx, const void* Wih, in
 int lob_gemm_tn_bf16(const void* A, int a_bf16, int lda, const void* B, int b_bf16, int ldb,
                      float* C, int ldc, int M, int N, int Kc, void* stream);
 
-/* Recurrent kernels with the hidden-state gate GEMM on bf16 MFMA (H == 128 only; everything
- * stored and carried through time stays fp32).  Same arguments as lob_lstm_rec_fwd_f32 /
- * lob_lstm_rec_bwd_f32; dP is always bf16 here.                                            */
-int lob_lstm_rec_fwd_bf16(void* P, int pg_bf16, const float* Whh, float* Y, float* Csave,
+/* Recurrent kernels with the hidden-state gate GEMM on bf16 MFMA (H == 128 and H == 256; cell state and
+ * everything carried through time stay fp32).  Same arguments as lob_lstm_rec_fwd_f32 / lob_lstm_rec_bwd_f32;
+ * dP is always bf16 here.  H == 128: W_hh (fp32, [D][4H][H]) is converted and kept in registers.  H == 256: the
+ * weights are streamed from L2 every step and must ALSO be handed over pre-converted to bf16 -- Whh16 [D][4H][H]
+ * for the forward, WhhT16 = per-direction transpose [D][H][4H] for BPTT -- and P / saved gates must be bf16
+ * (pg_bf16 = 1).  Whh16 / WhhT16 are ignored (may be NULL) at H == 128.                                   */
+int lob_lstm_rec_fwd_bf16(void* P, int pg_bf16, const float* Whh, const void* Whh16, float* Y, float* Csave,
                           void* Y16, void* Yd, float drop_p, uint64_t seed,
                           int T, int Bp, int H, int D, int save, void* stream);
 /*   Outputs, any non-empty subset with Y or Y16 present: Y (fp32 [T*Bp][D*H]), Y16 = bf16(Y) and
  *   Yd = bf16(dropout(Y; drop_p, seed)) (element index = position in Y) -- nn.LSTM's inter-layer dropout
  *   (04_lstm_model.py:186) fused into the producer.  In mixed mode the bf16 GEMMs of the next layer read
  *   Yd (or Y16 without dropout) and dW_hh reads Y16, so layers below the last never write fp32 Y.  */
-int lob_lstm_rec_bwd_bf16(const void* G, int pg_bf16, const float* Csave, const float* Whh, const float* dY,
+int lob_lstm_rec_bwd_bf16(const void* G, int pg_bf16, const float* Csave, const float* Whh, const void* WhhT16,
+                          const float* dY,
                           void* dP, float* dbias, int T, int Bp, int H, int D, void* stream);
 
 /* Element-wise activation and its backward (dx = dy * act'(pre)); classifier GELUs

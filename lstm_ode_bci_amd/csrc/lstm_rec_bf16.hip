@@ -338,18 +338,30 @@ int lob_rec_fwd_bf16_s16(void* P, int pg_bf16, const float* Whh, float* Y, float
                          float drop_p, uint64_t seed, int T, int Bp, int D, int save, hipStream_t s);
 int lob_rec_bwd_bf16_s16(const void* G, int pg_bf16, const float* Csave, const float* Whh, const float* dY, void* dP,
                          float* dbias, int T, int Bp, int D, hipStream_t s);
+// H = 256: W_hh streamed from L2 (lstm_rec_h256_bf16.hip); bf16 P / saved gates only
+int lob_rec_fwd_h256_bf16(void* P, const void* Whh16, float* Y, float* Csave, void* Y16, void* Yd, float drop_p,
+                          uint64_t seed, int T, int Bp, int D, int save, hipStream_t s);
+int lob_rec_bwd_h256_bf16(const void* G, const float* Csave, const void* WhhT16, const float* dY, void* dP,
+                          float* dbias, int T, int Bp, int D, hipStream_t s);
 static bool use_s16() {
     static const bool v = [] { const char* e = getenv("LOB_REC_BF16"); return !(e && atoi(e) == 32); }();
     return v;
 }
 
-extern "C" int lob_lstm_rec_fwd_bf16(void* P, int pg_bf16, const float* Whh, float* Y, float* Csave,
+extern "C" int lob_lstm_rec_fwd_bf16(void* P, int pg_bf16, const float* Whh, const void* Whh16, float* Y, float* Csave,
                                      void* Y16, void* Yd, float drop_p, uint64_t seed,
                                      int T, int Bp, int Hh, int D, int save, void* stream) {
     if (!P || !Whh || T <= 0 || Bp <= 0 || (D != 1 && D != 2)) return LOB_E_ARG;
     if (!Y && !Y16) return LOB_E_ARG;
     if (save && !Csave) return LOB_E_ARG;
     if (Yd && (drop_p <= 0.f || drop_p >= 1.f)) return LOB_E_ARG;
+    if (Hh == 256) {
+        if (!pg_bf16 || (Bp % 32)) return LOB_E_SHAPE;
+        if (!Whh16) return LOB_E_ARG;
+        if ((reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(Whh16) | reinterpret_cast<uintptr_t>(Csave) |
+             reinterpret_cast<uintptr_t>(Y16) | reinterpret_cast<uintptr_t>(Yd)) & 15) return LOB_E_ALIGN;
+        return lob_rec_fwd_h256_bf16(P, Whh16, Y, Csave, Y16, Yd, drop_p, seed, T, Bp, D, save, (hipStream_t)stream);
+    }
     if (Hh != 128 || (Bp % 32)) return LOB_E_SHAPE;
     if ((reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(Whh) | reinterpret_cast<uintptr_t>(Csave) |
          reinterpret_cast<uintptr_t>(Y16) | reinterpret_cast<uintptr_t>(Yd)) & 15) return LOB_E_ALIGN;
@@ -376,9 +388,16 @@ extern "C" int lob_lstm_rec_fwd_bf16(void* P, int pg_bf16, const float* Whh, flo
     return 0;
 }
 
-extern "C" int lob_lstm_rec_bwd_bf16(const void* G, int pg_bf16, const float* Csave, const float* Whh, const float* dY,
-                                     void* dP, float* dbias, int T, int Bp, int Hh, int D, void* stream) {
+extern "C" int lob_lstm_rec_bwd_bf16(const void* G, int pg_bf16, const float* Csave, const float* Whh, const void* WhhT16,
+                                     const float* dY, void* dP, float* dbias, int T, int Bp, int Hh, int D, void* stream) {
     if (!G || !Csave || !Whh || !dY || !dP || T <= 0 || Bp <= 0 || (D != 1 && D != 2)) return LOB_E_ARG;
+    if (Hh == 256) {
+        if (!pg_bf16 || (Bp % 32)) return LOB_E_SHAPE;
+        if (!WhhT16) return LOB_E_ARG;
+        if ((reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(Csave) | reinterpret_cast<uintptr_t>(WhhT16) |
+             reinterpret_cast<uintptr_t>(dP)) & 15) return LOB_E_ALIGN;
+        return lob_rec_bwd_h256_bf16(G, Csave, WhhT16, dY, dP, dbias, T, Bp, D, (hipStream_t)stream);
+    }
     if (Hh != 128 || (Bp % 32)) return LOB_E_SHAPE;
     if ((reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(Csave) |
          reinterpret_cast<uintptr_t>(dP)) & 15) return LOB_E_ALIGN;

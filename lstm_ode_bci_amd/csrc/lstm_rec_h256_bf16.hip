@@ -1,0 +1,307 @@
+// Mixed-precision recurrent kernels for H = 256 (the size of the reference's real checkpoints, 04_lstm_model.py:877).
+//
+// W_hh of one direction is 1024 x 256: 512 KB in bf16 -- more than a CU's registers + LDS can hold beside the
+// accumulators, so (unlike H = 128) the B operand of h W_hh^T is STREAMED from L2 every step: a workgroup is 32 batch
+// rows x one direction, 8 waves (two per SIMD), wave w owns hidden units [32w, 32w+32) = 128 gate columns, and per
+// step each lane loads its 64 fragments (16 B each, straight global -> VGPR, no LDS) in 8 groups of 8, one group in
+// flight ahead of the MFMAs that consume the previous one.  The weights arrive pre-converted to bf16 (the host
+// casts them once per call), in the orientation each kernel reads with 16 contiguous bytes per lane: [4H][H] for
+// the forward (k = h index contiguous), [H][4H] (W_hh^T) for BPTT (k = gate index contiguous).
+// The fp32 streaming kernels this replaces in mixed mode (lstm_rec_stream.hip) moved 1 MB per step per CU with one
+// k-block in flight and ran 12.9 ms (forward) / 17.1 ms (BPTT) per launch at B = 4096.
+// Everything else -- fragment-order P / saved gates (bf16, [gate][q pair][lane][8]) / c (fp32), fp32 cell state and
+// gradient carries, the bf16 dgates tile that is both MFMA operand and dP image, fused dropout copy -- is as in
+// lstm_rec_bf16.hip.
+#include "lob_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int HH = 256, NW = 8;
+constexpr int HB_LD = 264;         // h tile row stride in bf16 (528 B = 33 x 16 B, odd -> conflict-free b128)
+constexpr int DGB_LD = 1032;       // dgates tile row stride in bf16 (2064 B = 129 x 16 B)
+
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+struct Raw { bf16x8 v[8]; };       // one wave's [4 gates][2 q pairs] x 8 elements per lane, unconverted
+
+__device__ __forceinline__ void load_raw(const __bf16* p, unsigned off8, Raw& r) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int pq = 0; pq < 2; ++pq) r.v[2 * g + pq] = *reinterpret_cast<const bf16x8*>((p + g * 1024 + pq * 512) + off8);
+}
+
+template <bool SAVE, bool YF32, bool Y16, bool DROP>
+__global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h256_bf16_kernel(
+    __bf16* __restrict__ P, const __bf16* __restrict__ Wb, float* __restrict__ Y, float* __restrict__ Csave,
+    __bf16* __restrict__ Y16p, __bf16* __restrict__ Yd, float drop_p, uint64_t seed, int T, int Bp) {
+    __shared__ __attribute__((aligned(16))) __bf16 hs[2 * 32 * HB_LD];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bt = blockIdx.x, d = blockIdx.y, D = gridDim.y, NBT = gridDim.x;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    for (int i = tid; i < 2 * 32 * HB_LD; i += 512) hs[i] = (__bf16)0.f;
+    float c[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[r] = 0.f;
+
+    const size_t pstep = (size_t)NBT * NW * 4096, cstep = (size_t)NBT * NW * 1024;
+    __bf16* pblk = P + (((size_t)d * T * NBT + bt) * NW + w) * 4096;
+    float* cblk = SAVE ? Csave + (((size_t)d * T * NBT + bt) * NW + w) * 1024 : nullptr;
+    const unsigned off8 = lane * 8, off4 = lane * 4;
+    const int DH = D * HH;
+    const unsigned y_off = (unsigned)(4 * hi * DH + l31);
+    // B fragments: W_hh[n = g*H + 32w + l31][k = 16 ks + 8 hi .. +7]
+    const __bf16* wwave = Wb + ((size_t)d * 4 * HH + 32 * w) * HH;
+    unsigned w_off = (unsigned)(l31 * HH + 8 * hi);
+    const int t_first = d ? T - 1 : 0, dt = d ? -1 : 1;
+
+    Raw pn;
+    load_raw(pblk + (size_t)t_first * pstep, off8, pn);
+    // W stream: group q = k-steps {2q, 2q+1} x 4 gates = 8 fragments; buffer q & 1; group q+1 (cyclic: the weights are
+    // the same every step, so the last group of a step prefetches the first of the next) loads while group q computes
+    bf16x8 wb[2][8];
+    auto load_w = [&](int q, bf16x8 (&dst)[8]) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
+                dst[2 * g + k2] = *reinterpret_cast<const bf16x8*>((wwave + (size_t)g * HH * HH + 16 * (2 * q + k2)) + w_off);
+    };
+    load_w(0, wb[0]);
+    __syncthreads();
+
+    int cur = 0;
+    for (int step = 0; step < T; ++step) {
+        const int t = t_first + dt * step;
+        f32x16 acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int pq = 0; pq < 2; ++pq)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[g][8 * pq + e] = (float)pn.v[2 * g + pq][e];
+        if (step + 1 < T) load_raw(pblk + (size_t)(t + dt) * pstep, off8, pn);
+        const __bf16* hrow = hs + cur * 32 * HB_LD + l31 * HB_LD + 8 * hi;
+        // the weights are loop-invariant, and hipcc would hoist all 64 fragment loads out of the time loop (256
+        // registers -> scratch); an opaque no-op on the lane offset ties every step's loads to that step
+        asm volatile("" : "+v"(w_off));
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            load_w((q + 1) & 7, wb[(q + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);          // keep exactly one group of W in flight ahead of its use
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(hrow + 16 * (2 * q + k2));
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = mfma_bf16(a, wb[q & 1][2 * g + k2], acc[g]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __bf16* hnext = hs + (cur ^ 1) * 32 * HB_LD + 32 * w + l31 + 4 * hi * HB_LD;
+        float* yrow = Y + ((size_t)t * Bp + bt * 32) * DH + d * HH + 32 * w;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float ig = fast_sigmoid(acc[0][r]);
+            const float fg = fast_sigmoid(acc[1][r]);
+            const float gg = fast_tanh(acc[2][r]);
+            const float og = fast_sigmoid(acc[3][r]);
+            c[r] = fg * c[r] + ig * gg;
+            const float h = og * fast_tanh(c[r]);
+            const int row = (r & 3) + 8 * (r >> 2);
+            hnext[row * HB_LD] = (__bf16)h;
+            if (YF32) (yrow + (size_t)row * DH)[y_off] = h;
+            if (SAVE) { acc[0][r] = ig; acc[1][r] = fg; acc[2][r] = gg; acc[3][r] = og; }
+        }
+        if (SAVE) {
+            __bf16* gp = pblk + (size_t)t * pstep;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int pq = 0; pq < 2; ++pq) {
+                    bf16x8 v;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (__bf16)acc[g][8 * pq + e];
+                    *reinterpret_cast<bf16x8*>((gp + g * 1024 + pq * 512) + off8) = v;
+                }
+            float* cp = cblk + (size_t)t * cstep;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v = {c[4 * q + 0], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]};
+                *reinterpret_cast<f32x4*>((cp + q * 256) + off4) = v;
+            }
+        }
+        __syncthreads();
+        if (Y16 || DROP) {       // h_t is complete in hs[cur ^ 1]: emit the bf16 row segments (32 rows x 512 B)
+            const __bf16* hsrc = hs + (cur ^ 1) * 32 * HB_LD;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int idx = tid + 512 * i, row = idx >> 5, c8 = (idx & 31) * 8;
+                const bf16x8 hv = *reinterpret_cast<const bf16x8*>(hsrc + row * HB_LD + c8);
+                const size_t o = ((size_t)t * Bp + bt * 32 + row) * DH + d * HH + c8;
+                if (Y16) *reinterpret_cast<bf16x8*>(Y16p + o) = hv;
+                if (DROP) {
+                    bf16x8 dv;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        dv[j] = (__bf16)((float)hv[j] * lob_dropout_scale(seed, (uint64_t)o + j, drop_p));
+                    *reinterpret_cast<bf16x8*>(Yd + o) = dv;
+                }
+            }
+        }
+        cur ^= 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// BPTT.  dh = dgates[32 x 1024] * W_hh[1024 x 256]: wave w owns the 32 hidden units [32w, 32w+32) of dh; its B
+// fragments W_hh^T[unit][n = 16 ks + 8 hi .. +7] (ks < 64) are streamed from the pre-transposed bf16 copy, 8 per
+// group, one group ahead.  The bf16 dgates tile (32 x 1024) is the MFMA A operand and the dP image.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void lstm_rec_bwd_h256_bf16_kernel(
+    const __bf16* __restrict__ G, const float* __restrict__ Csave, const __bf16* __restrict__ WTb,
+    const float* __restrict__ dY, __bf16* __restrict__ dP, float* __restrict__ dbias, int T, int Bp) {
+    __shared__ __attribute__((aligned(16))) __bf16 dgs[32 * DGB_LD];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bt = blockIdx.x, d = blockIdx.y, D = gridDim.y, NBT = gridDim.x;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    const size_t gstep = (size_t)NBT * NW * 4096, cstep = (size_t)NBT * NW * 1024;
+    const __bf16* gwave = G + (((size_t)d * T * NBT + bt) * NW + w) * 4096;
+    const float* cwave = Csave + (((size_t)d * T * NBT + bt) * NW + w) * 1024;
+    const unsigned off8 = lane * 8, off4 = lane * 4;
+    const int DH = D * HH, D4H = D * 4 * HH;
+    const float* dywave = dY + (size_t)(bt * 32) * DH + d * HH + 32 * w;
+    const unsigned dy_off = (unsigned)(4 * hi * DH + l31);
+    // B fragments: W_hh^T[unit = 32w + l31][n = 16 ks + 8 hi .. +7]
+    const __bf16* wtwave = WTb + ((size_t)d * HH + 32 * w) * (4 * HH);
+    unsigned wt_off = (unsigned)(l31 * 4 * HH + 8 * hi);
+
+    const int t_first = d ? 0 : T - 1, dt = d ? 1 : -1;
+    f32x16 ct, cp, dhrec;
+    float dy[16], dcarry[16];
+    float dbsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dcarry[r] = 0.f; dhrec[r] = 0.f; }
+
+    auto load_c = [&](int t, f32x16& dst) {
+        if (t >= 0 && t < T) {
+            const float* cq = cwave + (size_t)t * cstep;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>((cq + q * 256) + off4);
+                dst[4 * q] = v[0]; dst[4 * q + 1] = v[1]; dst[4 * q + 2] = v[2]; dst[4 * q + 3] = v[3];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[r] = 0.f;
+        }
+    };
+    Raw graw;
+    auto load_step = [&](int t) {
+        load_raw(gwave + (size_t)t * gstep, off8, graw);
+        load_c(t + dt, cp);
+        const float* dp = dywave + (size_t)t * Bp * DH;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dy[r] = (dp + ((r & 3) + 8 * (r >> 2)) * DH)[dy_off];
+    };
+    bf16x8 wb[2][8];              // group q = k-steps 8q .. 8q+7 (64 k-steps of 16 gate rows in 8 groups)
+    auto load_w = [&](int q, bf16x8 (&dst)[8]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dst[j] = *reinterpret_cast<const bf16x8*>((wtwave + 16 * (8 * q + j)) + wt_off);
+    };
+    load_c(t_first, ct);
+    load_step(t_first);
+    load_w(0, wb[0]);
+
+    for (int step = 0; step < T; ++step) {
+        const int t = t_first + dt * step;
+        __bf16* dgw = dgs + 32 * w + l31 + 4 * hi * DGB_LD;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int g8 = r >> 3, e8 = r & 7;     // element r of the 32x32 block = q pair r>>3, position r&7
+            const float ig = (float)graw.v[0 + g8][e8], fg = (float)graw.v[2 + g8][e8];
+            const float gg = (float)graw.v[4 + g8][e8], og = (float)graw.v[6 + g8][e8];
+            const float dh = dy[r] + dhrec[r];
+            const float tc = fast_tanh(ct[r]);
+            const float dc = dcarry[r] + dh * og * (1.f - tc * tc);
+            dcarry[r] = dc * fg;
+            __bf16* p = dgw + ((r & 3) + 8 * (r >> 2)) * DGB_LD;
+            const float v0 = dc * gg * ig * (1.f - ig), v1 = dc * cp[r] * fg * (1.f - fg);
+            const float v2 = dc * ig * (1.f - gg * gg), v3 = dh * tc * og * (1.f - og);
+            p[0 * HH] = (__bf16)v0; p[1 * HH] = (__bf16)v1; p[2 * HH] = (__bf16)v2; p[3 * HH] = (__bf16)v3;
+            dbsum[0] += v0; dbsum[1] += v1; dbsum[2] += v2; dbsum[3] += v3;
+        }
+        ct = cp;
+        __syncthreads();
+        if (step + 1 < T) load_step(t + dt);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dhrec[r] = 0.f;
+        const __bf16* arow = dgs + l31 * DGB_LD + 8 * hi;
+        asm volatile("" : "+v"(wt_off));           // see the forward kernel: keeps the W stream inside the time loop
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            load_w((q + 1) & 7, wb[(q + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                dhrec = mfma_bf16(*reinterpret_cast<const bf16x8*>(arow + 16 * (8 * q + j)), wb[q & 1][j], dhrec);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- the bf16 tile IS the dP image: 32 rows x 2 KB; 128 lanes x 16 B per row, 4 rows per pass
+        __bf16* dpb = dP + ((size_t)t * Bp + bt * 32) * D4H + d * 4 * HH;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = 4 * i + (tid >> 7), c8 = (tid & 127) * 8;
+            *reinterpret_cast<bf16x8*>(dpb + (size_t)row * D4H + c8) =
+                *reinterpret_cast<const bf16x8*>(dgs + row * DGB_LD + c8);
+        }
+        __syncthreads();
+    }
+    if (dbias) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float v = dbsum[g] + __shfl_xor(dbsum[g], 32, 64);
+            if (hi == 0) atomicAdd(dbias + (size_t)d * 4 * HH + g * HH + 32 * w + l31, v);
+        }
+    }
+}
+
+}  // namespace
+
+// Internal entry points used by lob_lstm_rec_fwd_bf16 / lob_lstm_rec_bwd_bf16 (lstm_rec_bf16.hip) at H = 256.
+int lob_rec_fwd_h256_bf16(void* P, const void* Whh16, float* Y, float* Csave, void* Y16, void* Yd, float drop_p,
+                          uint64_t seed, int T, int Bp, int D, int save, hipStream_t s) {
+    const dim3 grid(Bp / 32, D), block(512);
+    __bf16* y16 = reinterpret_cast<__bf16*>(Y16);
+    __bf16* yd = reinterpret_cast<__bf16*>(Yd);
+#define LOB_FWD(SV, YF, Y6, DR) hipLaunchKernelGGL((lstm_rec_fwd_h256_bf16_kernel<SV, YF, Y6, DR>), grid, block, 0, s, \
+        reinterpret_cast<__bf16*>(P), reinterpret_cast<const __bf16*>(Whh16), Y, Csave, y16, yd, drop_p, seed, T, Bp)
+#define LOB_FWD_OUT(SV) do {                                                     \
+        if (Y && !y16 && !yd) LOB_FWD(SV, true, false, false);                   \
+        else if (Y && y16 && !yd) LOB_FWD(SV, true, true, false);                \
+        else if (Y && !y16 && yd) LOB_FWD(SV, true, false, true);                \
+        else if (Y && y16 && yd) LOB_FWD(SV, true, true, true);                  \
+        else if (!Y && y16 && !yd) LOB_FWD(SV, false, true, false);              \
+        else LOB_FWD(SV, false, true, true); } while (0)
+    if (save) LOB_FWD_OUT(true); else LOB_FWD_OUT(false);
+#undef LOB_FWD_OUT
+#undef LOB_FWD
+    LOB_CHECK_LAUNCH();
+    return 0;
+}
+
+int lob_rec_bwd_h256_bf16(const void* G, const float* Csave, const void* WhhT16, const float* dY, void* dP,
+                          float* dbias, int T, int Bp, int D, hipStream_t s) {
+    hipLaunchKernelGGL(lstm_rec_bwd_h256_bf16_kernel, dim3(Bp / 32, D), dim3(512), 0, s,
+                       reinterpret_cast<const __bf16*>(G), Csave, reinterpret_cast<const __bf16*>(WhhT16), dY,
+                       reinterpret_cast<__bf16*>(dP), dbias, T, Bp);
+    LOB_CHECK_LAUNCH();
+    return 0;
+}

@@ -111,8 +111,14 @@ def dma_ok(K, N, M):
 PG_BF16 = True
 
 
+def bf16_rec(H, p16=True):
+    """Hidden sizes with bf16-MFMA recurrent kernels: 128 (W_hh in registers; fp32 or bf16 P) and 256 (W_hh streamed
+    from L2; bf16 P / saved gates only)."""
+    return H == 128 or (H == 256 and bool(p16))
+
+
 def gate_gemm_x(x, wih, bias, T, Bp, H, D, frag, mixed=False):
-    """P = x[T*Bp,K] @ wih[D*4H,K]^T + bias, fragment order when frag.  In mixed mode at H == 128 P is
+    """P = x[T*Bp,K] @ wih[D*4H,K]^T + bias, fragment order when frag.  In mixed mode at H == 128 / 256 P is
     bf16 when ``ops.PG_BF16`` (it is only ever read by the bf16 recurrent kernel)."""
     x16 = x.dtype == torch.bfloat16
     w16 = wih.dtype == torch.bfloat16
@@ -123,7 +129,7 @@ def gate_gemm_x(x, wih, bias, T, Bp, H, D, frag, mixed=False):
     if (mixed or x16) and not frag:
         return gemm_nt(x, wih, bias, mixed=True)
     if (mixed or x16) and _bf16_ok(x, K, K):
-        p16 = PG_BF16 and H == 128
+        p16 = PG_BF16 and H in (128, 256)
         P = torch.empty((T * Bp, D * 4 * H), device=x.device, dtype=torch.bfloat16 if p16 else torch.float32)
         rc = _lib.lib().lob_gate_gemm_x_bf16(_ptr(x), int(x16), K, _ptr(wih), int(w16), _ptr(bias), _ptr(P), int(p16),
                                              T, Bp, H, D, K, _stream())
@@ -139,8 +145,9 @@ def gate_gemm_x(x, wih, bias, T, Bp, H, D, frag, mixed=False):
 
 
 def can_fuse_dropout(H, mixed):
-    """The bf16-MFMA recurrent kernel (mixed mode, H == 128) can emit the dropped bf16 copy itself."""
-    return bool(mixed) and H == 128
+    """The bf16-MFMA recurrent kernels (mixed mode, H == 128; H == 256 with bf16 P) can emit the dropped bf16 copy
+    themselves."""
+    return bool(mixed) and bf16_rec(H, PG_BF16)
 
 
 def lstm_rec_fwd(P, whh, T, Bp, H, D, save, mixed=False, drop_p=0.0, seed=0, want_f32=True, want_bf16=False):
@@ -153,14 +160,16 @@ def lstm_rec_fwd(P, whh, T, Bp, H, D, save, mixed=False, drop_p=0.0, seed=0, wan
     dev = P.device
     Cs = torch.empty((D * T * Bp * H,), device=dev, dtype=torch.float32) if save else None
     Y = Y16 = Yd = None
-    if mixed and H == 128:
+    if mixed and bf16_rec(H, p16):
+        # H == 256 streams the weights from L2: hand them over as bf16 (cast once per call, 1 MB)
+        whh16 = whh.to(torch.bfloat16) if H == 256 else None
         if want_f32 or not want_bf16:
             Y = torch.empty((T * Bp, D * H), device=dev, dtype=torch.float32)
         if want_bf16:
             Y16 = torch.empty((T * Bp, D * H), device=dev, dtype=torch.bfloat16)
         if drop_p > 0:
             Yd = torch.empty((T * Bp, D * H), device=dev, dtype=torch.bfloat16)
-        rc = _lib.lib().lob_lstm_rec_fwd_bf16(_ptr(P), int(p16), _ptr(whh), _ptr(Y), _ptr(Cs), _ptr(Y16), _ptr(Yd),
+        rc = _lib.lib().lob_lstm_rec_fwd_bf16(_ptr(P), int(p16), _ptr(whh), _ptr(whh16), _ptr(Y), _ptr(Cs), _ptr(Y16), _ptr(Yd),
                                               float(drop_p), C.c_uint64(seed), T, Bp, H, D, 1 if save else 0,
                                               _stream())
     else:
@@ -266,12 +275,13 @@ def lstm_rec_bwd(G, Cs, whh, dY, T, Bp, H, D, dp_bf16=False):
     """BPTT through one layer; returns (dP[T*Bp, D*4H] row-major fp32|bf16, dbias[D*4H])."""
     g16 = G.dtype == torch.bfloat16
     _chk(G, "G", G.dtype if g16 else torch.float32); _chk(Cs, "Csave"); _chk(whh, "whh"); _chk(dY, "dY")
-    assert dY.shape == (T * Bp, D * H) and (not g16 or (dp_bf16 and H == 128))
+    assert dY.shape == (T * Bp, D * H) and (not g16 or (dp_bf16 and bf16_rec(H, g16)))
     dP = torch.empty((T * Bp, D * 4 * H), device=G.device, dtype=torch.bfloat16 if dp_bf16 else torch.float32)
     fused_bias = uses_frag(H)
     dbias = torch.zeros((D * 4 * H,), device=G.device, dtype=torch.float32)
-    if dp_bf16 and H == 128:
-        rc = _lib.lib().lob_lstm_rec_bwd_bf16(_ptr(G), int(g16), _ptr(Cs), _ptr(whh), _ptr(dY), _ptr(dP),
+    if dp_bf16 and bf16_rec(H, g16):
+        whht16 = whh.transpose(1, 2).contiguous().to(torch.bfloat16) if H == 256 else None     # [D][H][4H]
+        rc = _lib.lib().lob_lstm_rec_bwd_bf16(_ptr(G), int(g16), _ptr(Cs), _ptr(whh), _ptr(whht16), _ptr(dY), _ptr(dP),
                                               _ptr(dbias), T, Bp, H, D, _stream())
     else:
         rc = _lib.lib().lob_lstm_rec_bwd_f32(_ptr(G), _ptr(Cs), _ptr(whh), _ptr(dY), _ptr(dP), int(dp_bf16),
