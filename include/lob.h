@@ -138,9 +138,11 @@ int lob_gemm_tn_bf16(const void* A, int a_bf16, int lda, const void* B, int b_bf
 /* Recurrent kernels with the hidden-state gate GEMM on bf16 MFMA (H == 128 and H == 256; cell state and
  * everything carried through time stay fp32).  Same arguments as lob_lstm_rec_fwd_f32 / lob_lstm_rec_bwd_f32;
  * dP is always bf16 here.  H == 128: W_hh (fp32, [D][4H][H]) is converted and kept in registers.  H == 256: the
- * weights are streamed from L2 every step and must ALSO be handed over pre-converted to bf16 -- Whh16 [D][4H][H]
- * for the forward, WhhT16 = per-direction transpose [D][H][4H] for BPTT -- and P / saved gates must be bf16
- * (pg_bf16 = 1).  Whh16 / WhhT16 are ignored (may be NULL) at H == 128.                                   */
+ * weights are streamed from L2 every step and must ALSO be handed over as bf16 in MFMA FRAGMENT ORDER (every
+ * wave-load 1 KB contiguous), and P / saved gates must be bf16 (pg_bf16 = 1):
+ *   Whh16  [D][w 8][ks 16][gate 4][lane 64][8]: W_hh[d][gate*H + 32w + (lane&31)][16ks + 8(lane>>5) + j]   (forward)
+ *   WhhT16 [D][w 8][ks 64][lane 64][8]:         W_hh[d][16ks + 8(lane>>5) + j][32w + (lane&31)]            (BPTT)
+ * Whh16 / WhhT16 are ignored (may be NULL) at H == 128.                                                  */
 int lob_lstm_rec_fwd_bf16(void* P, int pg_bf16, const float* Whh, const void* Whh16, float* Y, float* Csave,
                           void* Y16, void* Yd, float drop_p, uint64_t seed,
                           int T, int Bp, int H, int D, int save, void* stream);

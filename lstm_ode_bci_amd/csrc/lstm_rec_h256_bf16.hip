@@ -3,8 +3,7 @@
 // W_hh of one direction is 1024 x 256: 512 KB in bf16 -- more than a CU's registers + LDS can hold beside the
 // accumulators, so (unlike H = 128) the B operand of h W_hh^T is STREAMED from L2 every step: a workgroup is 32 batch
 // rows x one direction, 8 waves (two per SIMD), wave w owns hidden units [32w, 32w+32) = 128 gate columns, and per
-// step each lane loads its 64 fragments (16 B each, straight global -> VGPR, no LDS) in 8 groups of 8, one group in
-// flight ahead of the MFMAs that consume the previous one.  The weights arrive pre-converted to bf16 (the host
+// step each lane loads its 64 fragments (16 B each, straight global -> VGPR, no LDS) in 16 groups of 4, three groups  The weights arrive pre-converted to bf16 (the host
 // casts them once per call), in the orientation each kernel reads with 16 contiguous bytes per lane: [4H][H] for
 // the forward (k = h index contiguous), [H][4H] (W_hh^T) for BPTT (k = gate index contiguous).
 // The fp32 streaming kernels this replaces in mixed mode (lstm_rec_stream.hip) moved 1 MB per step per CU with one
@@ -56,24 +55,28 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h256_bf16_kernel(
     const unsigned off8 = lane * 8, off4 = lane * 4;
     const int DH = D * HH;
     const unsigned y_off = (unsigned)(4 * hi * DH + l31);
-    // B fragments: W_hh[n = g*H + 32w + l31][k = 16 ks + 8 hi .. +7]
-    const __bf16* wwave = Wb + ((size_t)d * 4 * HH + 32 * w) * HH;
-    unsigned w_off = (unsigned)(l31 * HH + 8 * hi);
+    // B fragments, pre-arranged by the host in FRAGMENT ORDER [D][wave][ks 16][gate 4][lane 64][8]: element =
+    // W_hh[g*H + 32w + (lane & 31)][16 ks + 8 (lane >> 5) + j].  A wave-load is then 1 KB contiguous (8 whole cache
+    // lines); read straight from the [4H][H] matrix each load touched 32 lines for 32 B each, the lines did not
+    // survive in L1 until their next k-step, and L2 delivered 4x the bytes (18 us per step)
+    const __bf16* wwave = Wb + ((size_t)d * NW + w) * (16 * 4 * 64 * 8);
+    unsigned w_off = (unsigned)(lane * 8);
     const int t_first = d ? T - 1 : 0, dt = d ? -1 : 1;
 
     Raw pn;
     load_raw(pblk + (size_t)t_first * pstep, off8, pn);
-    // W stream: group q = k-steps {2q, 2q+1} x 4 gates = 8 fragments; buffer q & 1; group q+1 (cyclic: the weights are
-    // the same every step, so the last group of a step prefetches the first of the next) loads while group q computes
-    bf16x8 wb[2][8];
-    auto load_w = [&](int q, bf16x8 (&dst)[8]) {
+    // W stream: group q = k-step q x 4 gates = 4 fragments; buffer q & 3; THREE groups in flight ahead of the one
+    // being consumed (cyclic: the weights are the same every step, so the tail of a step prefetches the head of the
+    // next).  The stream is latency-bound: what counts is bytes in flight per CU (12 KB per wave here).
+    bf16x8 wb[4][4];
+    auto load_w = [&](int q, bf16x8 (&dst)[4]) {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2)
-                dst[2 * g + k2] = *reinterpret_cast<const bf16x8*>((wwave + (size_t)g * HH * HH + 16 * (2 * q + k2)) + w_off);
+            dst[g] = *reinterpret_cast<const bf16x8*>((wwave + (q * 4 + g) * 512) + w_off);
     };
     load_w(0, wb[0]);
+    load_w(1, wb[1]);
+    load_w(2, wb[2]);
     __syncthreads();
 
     int cur = 0;
@@ -92,15 +95,12 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h256_bf16_kernel(
         // registers -> scratch); an opaque no-op on the lane offset ties every step's loads to that step
         asm volatile("" : "+v"(w_off));
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            load_w((q + 1) & 7, wb[(q + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);          // keep exactly one group of W in flight ahead of its use
+        for (int q = 0; q < 16; ++q) {
+            load_w((q + 3) & 15, wb[(q + 3) & 3]);
+            __builtin_amdgcn_sched_barrier(0);          // pin the order: issue the prefetch, then consume group q
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(hrow + 16 * q);
 #pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(hrow + 16 * (2 * q + k2));
-#pragma unroll
-                for (int g = 0; g < 4; ++g) acc[g] = mfma_bf16(a, wb[q & 1][2 * g + k2], acc[g]);
-            }
+            for (int g = 0; g < 4; ++g) acc[g] = mfma_bf16(a, wb[q & 3][g], acc[g]);
             __builtin_amdgcn_sched_barrier(0);
         }
         __bf16* hnext = hs + (cur ^ 1) * 32 * HB_LD + 32 * w + l31 + 4 * hi * HB_LD;
@@ -179,9 +179,9 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_bwd_h256_bf16_kernel(
     const int DH = D * HH, D4H = D * 4 * HH;
     const float* dywave = dY + (size_t)(bt * 32) * DH + d * HH + 32 * w;
     const unsigned dy_off = (unsigned)(4 * hi * DH + l31);
-    // B fragments: W_hh^T[unit = 32w + l31][n = 16 ks + 8 hi .. +7]
-    const __bf16* wtwave = WTb + ((size_t)d * HH + 32 * w) * (4 * HH);
-    unsigned wt_off = (unsigned)(l31 * 4 * HH + 8 * hi);
+    // B fragments in fragment order [D][wave][ks 64][lane 64][8]: element = W_hh[n = 16 ks + 8 (lane >> 5) + j][32w + (lane & 31)]
+    const __bf16* wtwave = WTb + ((size_t)d * NW + w) * (64 * 64 * 8);
+    unsigned wt_off = (unsigned)(lane * 8);
 
     const int t_first = d ? 0 : T - 1, dt = d ? 1 : -1;
     f32x16 ct, cp, dhrec;
@@ -211,10 +211,11 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_bwd_h256_bf16_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) dy[r] = (dp + ((r & 3) + 8 * (r >> 2)) * DH)[dy_off];
     };
-    bf16x8 wb[2][8];              // group q = k-steps 8q .. 8q+7 (64 k-steps of 16 gate rows in 8 groups)
-    auto load_w = [&](int q, bf16x8 (&dst)[8]) {
+    bf16x8 wb[2][4];              // group q = k-steps 4q .. 4q+3 (64 k-steps of 16 gate rows in 16 groups), one group ahead
+                                  // (three ahead as in the forward kernel spills here: 4.7 ms; this is HBM-bound anyway)
+    auto load_w = [&](int q, bf16x8 (&dst)[4]) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dst[j] = *reinterpret_cast<const bf16x8*>((wtwave + 16 * (8 * q + j)) + wt_off);
+        for (int j = 0; j < 4; ++j) dst[j] = *reinterpret_cast<const bf16x8*>((wtwave + (4 * q + j) * 512) + wt_off);
     };
     load_c(t_first, ct);
     load_step(t_first);
@@ -246,12 +247,12 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_bwd_h256_bf16_kernel(
         const __bf16* arow = dgs + l31 * DGB_LD + 8 * hi;
         asm volatile("" : "+v"(wt_off));           // see the forward kernel: keeps the W stream inside the time loop
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            load_w((q + 1) & 7, wb[(q + 1) & 1]);
+        for (int q = 0; q < 16; ++q) {
+            load_w((q + 1) & 15, wb[(q + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                dhrec = mfma_bf16(*reinterpret_cast<const bf16x8*>(arow + 16 * (8 * q + j)), wb[q & 1][j], dhrec);
+            for (int j = 0; j < 4; ++j)
+                dhrec = mfma_bf16(*reinterpret_cast<const bf16x8*>(arow + 16 * (4 * q + j)), wb[q & 1][j], dhrec);
             __builtin_amdgcn_sched_barrier(0);
         }
         // ---- the bf16 tile IS the dP image: 32 rows x 2 KB; 128 lanes x 16 B per row, 4 rows per pass

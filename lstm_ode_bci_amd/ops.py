@@ -161,8 +161,11 @@ def lstm_rec_fwd(P, whh, T, Bp, H, D, save, mixed=False, drop_p=0.0, seed=0, wan
     Cs = torch.empty((D * T * Bp * H,), device=dev, dtype=torch.float32) if save else None
     Y = Y16 = Yd = None
     if mixed and bf16_rec(H, p16):
-        # H == 256 streams the weights from L2: hand them over as bf16 (cast once per call, 1 MB)
-        whh16 = whh.to(torch.bfloat16) if H == 256 else None
+        # H == 256 streams the weights from L2: hand them over as bf16 in MFMA fragment order (include/lob.h), so
+        # that every wave-load is 1 KB contiguous; one 1-MB permute per call
+        whh16 = None
+        if H == 256:       # [D, g 4, w 8, l31 32, ks 16, hi 2, j 8] -> [D, w, ks, g, hi, l31, j]
+            whh16 = (whh.to(torch.bfloat16).reshape(D, 4, 8, 32, 16, 2, 8).permute(0, 2, 4, 1, 5, 3, 6).contiguous())
         if want_f32 or not want_bf16:
             Y = torch.empty((T * Bp, D * H), device=dev, dtype=torch.float32)
         if want_bf16:
@@ -280,7 +283,9 @@ def lstm_rec_bwd(G, Cs, whh, dY, T, Bp, H, D, dp_bf16=False):
     fused_bias = uses_frag(H)
     dbias = torch.zeros((D * 4 * H,), device=G.device, dtype=torch.float32)
     if dp_bf16 and bf16_rec(H, g16):
-        whht16 = whh.transpose(1, 2).contiguous().to(torch.bfloat16) if H == 256 else None     # [D][H][4H]
+        whht16 = None
+        if H == 256:       # [D, ks 64, hi 2, j 8, w 8, l31 32] -> [D, w, ks, hi, l31, j]  (fragment order, lob.h)
+            whht16 = (whh.to(torch.bfloat16).reshape(D, 64, 2, 8, 8, 32).permute(0, 4, 1, 2, 5, 3).contiguous())
         rc = _lib.lib().lob_lstm_rec_bwd_bf16(_ptr(G), int(g16), _ptr(Cs), _ptr(whh), _ptr(whht16), _ptr(dY), _ptr(dP),
                                               _ptr(dbias), T, Bp, H, D, _stream())
     else:
