@@ -260,18 +260,31 @@ __device__ __forceinline__ void dma_rows16(const __bf16* G, int ld, int row0, in
     __builtin_amdgcn_global_load_lds((gbl_cvoid*)src, (lds_void*)lds_rows, 16, 0, 0);
 }
 
+// 64-wide k-slots: one wave-instruction = 8 rows x 8 chunks of 16 B = 8 WHOLE 128-B cache lines (the 32-wide form
+// above fetches half a line per row, and the other half one k-tile later, when L1 has lost it).  LDS rows are 128 B;
+// chunk c of row r is stored at chunk slot c ^ (r & 7) (conflict-free ds_read_b128 of 16 rows x one chunk).
+__device__ __forceinline__ void dma_rows8(const __bf16* G, int ld, int row0, int nrows, int k0, __bf16* lds_rows,
+                                          int lane) {
+    const int r = row0 + (lane >> 3), p = lane & 7;
+    const int c = p ^ (r & 7);
+    const int rr = r < nrows ? r : nrows - 1;
+    const __bf16* src = G + (size_t)rr * ld + k0 + c * 8;
+    __builtin_amdgcn_global_load_lds((gbl_cvoid*)src, (lds_void*)lds_rows, 16, 0, 0);
+}
+
 // Output tile BTM x BTN per workgroup, one wave per 64x64 block of it (4 waves at 128x128, 16 at
 // 256x256).  The bigger tile halves the bytes that cross the L2 -> LDS path per FLOP (every operand
 // tile is re-read once per tile of the OTHER dimension) -- at 128x128 that path carried 3x the
 // algorithmic bytes and, not HBM, set the rate.
 // NDS = ring depth, BIASF = floats of the bias image.  <256,128,3,1024>: 76 KB of LDS -> TWO workgroups per CU, so
 // one workgroup's epilogue (stores at HBM rate) overlaps the other's main loop.
-template <int EPI, int BTM, int BTN, int NDS = DS, int BIASF = 2048>
+template <int EPI, int BTM, int BTN, int NDS = DS, int BIASF = 2048, int KT = DTK>
 __global__ __launch_bounds__((BTM / 64) * (BTN / 64) * 64, (BTM * BTN > 128 * 128) ? 4 : 2)
 void gemm_nt_dma_kernel(NTArgs g) {
     constexpr int WR = BTM / 64, WC = BTN / 64, NWV = WR * WC, NTHR = NWV * 64;
-    constexpr int NA = BTM / 16 / NWV, NB = BTN / 16 / NWV;      // 1-KB DMA instructions per wave per k-tile
-    constexpr int ASLOT = BTM * DTK, WSLOT = BTN * DTK, SLOT = ASLOT + WSLOT;
+    constexpr int RPI = KT == 32 ? 16 : 8;                        // rows per 1-KB DMA instruction
+    constexpr int NA = BTM / RPI / NWV, NB = BTN / RPI / NWV;     // 1-KB DMA instructions per wave per k-tile
+    constexpr int ASLOT = BTM * KT, WSLOT = BTN * KT, SLOT = ASLOT + WSLOT;
     constexpr int VM_STEADY = (NDS - 2) * (NA + NB), VM_EPI = VM_STEADY + 16;   // (bf16 P: 8 stores; 16 covers fp32 P)
     static_assert(NA >= 1 && NB >= 1 && VM_EPI < 64, "tile / wave configuration");
     __shared__ __attribute__((aligned(1024))) __bf16 ring[NDS * SLOT + 2 * BIASF];     // ring + bias image
@@ -284,7 +297,7 @@ void gemm_nt_dma_kernel(NTArgs g) {
     const int ntn = (g.N + BTN - 1) / BTN, ntm = (g.M + BTM - 1) / BTM;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
     const int panels = (ntm - xcd + 7) / 8, ntile = panels * ntn;
-    const int nk = g.K / DTK;
+    const int nk = g.K / KT;
     if (slot >= ntile) return;
     const int my_tiles = (ntile - slot + nslot - 1) / nslot;
     const int total = my_tiles * nk;
@@ -304,13 +317,15 @@ void gemm_nt_dma_kernel(NTArgs g) {
         __bf16* ws = as + ASLOT;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-            const int rb = (wave * NA + j) * 16;
-            dma_rows16(A, g.lda, m0 + rb, g.M, p_kt * DTK, as + rb * DTK, lane);
+            const int rb = (wave * NA + j) * RPI;
+            if constexpr (KT == 32) dma_rows16(A, g.lda, m0 + rb, g.M, p_kt * KT, as + rb * KT, lane);
+            else                    dma_rows8(A, g.lda, m0 + rb, g.M, p_kt * KT, as + rb * KT, lane);
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            const int rb = (wave * NB + j) * 16;
-            dma_rows16(W, g.ldw, n0 + rb, g.N, p_kt * DTK, ws + rb * DTK, lane);
+            const int rb = (wave * NB + j) * RPI;
+            if constexpr (KT == 32) dma_rows16(W, g.ldw, n0 + rb, g.N, p_kt * KT, ws + rb * KT, lane);
+            else                    dma_rows8(W, g.ldw, n0 + rb, g.N, p_kt * KT, ws + rb * KT, lane);
         }
         ++p_q;
         if (++p_kt == nk) { p_kt = 0; p_it += nslot; }
@@ -345,14 +360,14 @@ void gemm_nt_dma_kernel(NTArgs g) {
 
         const __bf16* as = ring + (q % NDS) * SLOT;
         const __bf16* ws = as + ASLOT;
-        const int r31 = lane & 31, hi = lane >> 5, sw = (r31 >> 2) & 3;
+        const int r31 = lane & 31, hi = lane >> 5, sw = KT == 32 ? (r31 >> 2) & 3 : r31 & 7;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < KT / 16; ++s) {
             const int pc = ((2 * s + hi) ^ sw) * 8;
-            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(as + (64 * wr + r31) * DTK + pc);
-            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(as + (64 * wr + 32 + r31) * DTK + pc);
-            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(ws + (64 * wc + r31) * DTK + pc);
-            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(ws + (64 * wc + 32 + r31) * DTK + pc);
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(as + (64 * wr + r31) * KT + pc);
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(as + (64 * wr + 32 + r31) * KT + pc);
+            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(ws + (64 * wc + r31) * KT + pc);
+            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(ws + (64 * wc + 32 + r31) * KT + pc);
             acc[0][0] = mfma_bf16(a0, b0, acc[0][0]);
             acc[0][1] = mfma_bf16(a0, b1, acc[0][1]);
             acc[1][0] = mfma_bf16(a1, b0, acc[1][0]);
@@ -754,7 +769,12 @@ inline void launch_nt_dma(const NTArgs& g_, hipStream_t s) {
         if (gsz > tiles) gsz = ((tiles + 7) / 8) * 8;
         hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI, 256, 128, 3, 1024>), dim3((unsigned)gsz), dim3(512), 0, s, g);
     };
-    if (nt_dma_tile() == 2 && two_wg)
+    // 64-wide k-slots (two of them) by default: every DMA instruction fetches whole cache lines.  Measured against
+    // four 32-wide slots (half a line per row per k-tile): gate GEMM K=256 0.96 -> 0.92 ms, dX N=256 0.84 -> 0.77 ms.
+    static const int kt64 = [] { const char* e = getenv("LOB_DMA_KT"); return e ? atoi(e) : 64; }();
+    if (kt64 == 64 && g.N % 256 == 0 && g.K % 64 == 0 && g.K / 64 >= 2)
+        hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI, 256, 256, 2, 2048, 64>), dim3((unsigned)nt_dma_grid(g.M, g.N, 256)), dim3(1024), 0, s, g);
+    else if (nt_dma_tile() == 2 && two_wg)
         launch_2wg();
     else if (nt_dma_tile() != 128 && g.N % 256 == 0)
         hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI, 256, 256>), dim3((unsigned)nt_dma_grid(g.M, g.N, 256)), dim3(1024), 0, s, g);
