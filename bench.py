@@ -289,7 +289,7 @@ def main():
         kr = kernel_roofline(dev, B, mode, precision)
         roof = roofline_of(kr)
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # HBM bytes per launch from rocprofv3 --pmc
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and H == 128:           # the committed PMC table is for the H = 128 kernels
             try:
                 roof["traffic"] = json.load(open(tpath)).get(f"{roof['kernel']}|{precision}|B{B}")
             except Exception:
