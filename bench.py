@@ -166,8 +166,20 @@ def roofline_of(kr):
             "sec_per_launch": v["sec"], "all": allk}
 
 
-def cpu_baseline(mode, sd):
-    """The reference's CPU path (same torch layer stack -> aten::lstm -> oneDNN), bounded sample."""
+def _cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(mode, sd, forecast_steps=300):
+    """The reference's CPU path (same torch layer stack -> aten::lstm -> oneDNN), bounded sample.  Coupled mode adds
+    the reference's step 2 as it runs it: one scipy odeint (LSODA) solve per window in a Python loop, single-threaded
+    by construction (06_lstm_ode_integration.py:372-401)."""
     from oracle import torch_cpu_path as TP
     from lstm_ode_bci_amd import synthetic as syn
     ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -188,9 +200,21 @@ def cpu_baseline(mode, sd):
             best, med, nthreads = b, md, nt
     what = (f"fwd+bwd train-mode (dropout on, weighted CE), B={Bc}" if mode == "train"
             else f"fwd eval-mode no_grad, B={Bc}") + ", best over 8/16/32/64 threads"
-    return {"value": best, "median": med, "unit": "windows/s", "cores": nthreads, "kind": "port",
-            "sample": what + f"; torch {torch.__version__} CPU (oneDNN), {time.perf_counter() - t0:.1f}s wall",
-            "host_cpus": os.cpu_count()}
+    out = {"value": best, "median": med, "unit": "windows/s", "cores": nthreads, "kind": "port", "host_cpus": os.cpu_count(),
+           "cpu_model": _cpu_model_name()}
+    if mode == "coupled":
+        from oracle import restatement as R
+        n = 256
+        probs = syn.make_probs(n, seed=7)
+        t1 = time.perf_counter()
+        R.predict_from_probs(probs, syn.DEFAULT_RATES, 0.5, forecast_steps)          # scipy.integrate.odeint per window
+        ode_rate = n / (time.perf_counter() - t1)
+        out["lstm_windows_per_s"] = best
+        out["ode_solves_per_s_1thread"] = ode_rate
+        out["value"] = 1.0 / (1.0 / best + 1.0 / ode_rate)          # LSTM chunk loop, then the per-window ODE loop
+        what += f" + {n} odeint solves of {forecast_steps} points on 1 thread"
+    out["sample"] = what + f"; torch {torch.__version__} CPU (oneDNN), {time.perf_counter() - t0:.1f}s wall"
+    return out
 
 
 def main():
@@ -315,7 +339,7 @@ def main():
             "roofline": roof,
         }
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(mode, sd)
+            res["cpu_baseline"] = cpu_baseline(mode, sd, a.forecast_steps)
             res["speedup_vs_cpu_baseline"] = value / res["cpu_baseline"]["value"]
         print(json.dumps(res))
     if world > 1:
