@@ -262,11 +262,14 @@ __device__ __forceinline__ void dma_rows16(const __bf16* G, int ld, int row0, in
 
 // 64-wide k-slots: one wave-instruction = 8 rows x 8 chunks of 16 B = 8 WHOLE 128-B cache lines (the 32-wide form
 // above fetches half a line per row, and the other half one k-tile later, when L1 has lost it).  LDS rows are 128 B;
-// chunk c of row r is stored at chunk slot c ^ (r & 7) (conflict-free ds_read_b128 of 16 rows x one chunk).
+// chunk c of row r is stored at chunk slot c ^ ((r >> 1) & 7): the bank of a 16-B piece is 32 (r & 1) + 4 slot, and
+// the 16 lanes that a ds_read_b128 services together hold rows whose (r >> 1) & 7 takes every value twice, once per
+// parity -> 16 distinct pieces of the 256-B bank row.  (c ^ (r & 7) was 2-way conflicted: SQ_LDS_BANK_CONFLICT
+// equal to the active LDS cycles.)
 __device__ __forceinline__ void dma_rows8(const __bf16* G, int ld, int row0, int nrows, int k0, __bf16* lds_rows,
                                           int lane) {
     const int r = row0 + (lane >> 3), p = lane & 7;
-    const int c = p ^ (r & 7);
+    const int c = p ^ ((r >> 1) & 7);
     const int rr = r < nrows ? r : nrows - 1;
     const __bf16* src = G + (size_t)rr * ld + k0 + c * 8;
     __builtin_amdgcn_global_load_lds((gbl_cvoid*)src, (lds_void*)lds_rows, 16, 0, 0);
@@ -360,7 +363,7 @@ void gemm_nt_dma_kernel(NTArgs g) {
 
         const __bf16* as = ring + (q % NDS) * SLOT;
         const __bf16* ws = as + ASLOT;
-        const int r31 = lane & 31, hi = lane >> 5, sw = KT == 32 ? (r31 >> 2) & 3 : r31 & 7;
+        const int r31 = lane & 31, hi = lane >> 5, sw = KT == 32 ? (r31 >> 2) & 3 : (r31 >> 1) & 7;
 #pragma unroll
         for (int s = 0; s < KT / 16; ++s) {
             const int pc = ((2 * s + hi) ^ sw) * 8;
