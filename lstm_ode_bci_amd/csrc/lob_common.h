@@ -26,13 +26,15 @@ __device__ __forceinline__ int acc_row(int r, int lane) {
 }
 
 // Activations.  v_exp_f32 / v_rcp_f32 are ~1 ulp; the absolute error of the results
-// (<= ~1.5e-7) is what the 1e-5 logit parity budget sees.
+// (<= ~1.5e-7) is what the 1e-5 logit parity budget sees.  The reciprocal is the raw v_rcp_f32
+// (__builtin_amdgcn_rcpf): __frcp_rn expands to the full IEEE division sequence (v_div_scale x2, v_rcp, four FMAs,
+// v_div_fmas, v_div_fixup -- a third of all instructions of a recurrent step, and those kernels are issue-bound).
 __device__ __forceinline__ float fast_sigmoid(float x) {
-    return __frcp_rn(1.0f + __expf(-x));
+    return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
 }
 __device__ __forceinline__ float fast_tanh(float x) {
     // 1 - 2/(1+e^{2x}): saturates cleanly to +-1, no inf/inf.
-    return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x));
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x));
 }
 __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
