@@ -278,6 +278,10 @@ int lob_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float
                   float beta2, float eps, float weight_decay, int64_t step, const float* normsq,
                   float max_norm, float grad_scale, void* stream);
 
+/* out[row][0..Cp) = bf16(in[row][0..C)), columns C..Cp zero: the (B*T, 61) input windows as a 16-B-aligned bf16
+ * operand (Cp = 64) for the mixed path's projection GEMMs (nn.Linear under autocast, 04:174, 04:487).   */
+int lob_pad_cast_bf16(const float* in, void* out, int64_t rows, int C, int Cp, void* stream);
+
 /* out[c] += scale * sum_{rows} |gx[row][c]|: the |input gradient| reduction of the gradient attribution
  * (07_explainability.py:257-258: X.grad[i].abs().mean(dim=0), summed over windows), gx [rows][C].    */
 int lob_abs_colsum_f32(const float* gx, int64_t rows, int C, float scale, float* out, void* stream);

@@ -58,6 +58,7 @@ _SIGS = {
     "lob_clip_scale_f32": ([_f32p, C.c_int64, _f32p, C.c_float, C.c_void_p], C.c_int),
     "lob_adamw_f32": ([_f32p, _f32p, _f32p, _f32p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                        C.c_int64, _f32p, C.c_float, C.c_float, C.c_void_p], C.c_int),
+    "lob_pad_cast_bf16": ([_f32p, _f32p, C.c_int64, C.c_int, C.c_int, C.c_void_p], C.c_int),
     "lob_abs_colsum_f32": ([_f32p, C.c_int64, C.c_int, C.c_float, _f32p, C.c_void_p], C.c_int),
 }
 

@@ -58,11 +58,22 @@ def _forward_impl(x, ps, cfg, save):
     proj_w, proj_b, ln0_g, ln0_b = next(it), next(it), next(it), next(it)
     sv = {} if save else None
 
-    pre = ops.gemm_nt(x2d, proj_w, proj_b)                                   # (B*T, H), rows (b,t)
+    # mixed mode: the windows as a padded bf16 operand (61 -> 64 columns: 16-B aligned rows) for the projection GEMM
+    # and, in the backward, its weight gradient -- nn.Linear under autocast (04:174, 04:487); the fp32 kernels walk the
+    # unaligned 244-B rows at a third of the rate
+    xb = None
+    if mixed and C % 8 != 0 and H % 8 == 0:
+        Cp = (C + 7) // 8 * 8
+        xb = ops.pad_cast_bf16(x2d, Cp)
+        wpad = torch.zeros((proj_w.shape[0], Cp), device=x.device, dtype=torch.float32)
+        wpad[:, :C] = proj_w
+        pre = ops.gemm_nt(xb, wpad, proj_b, mixed=True)                      # (B*T, H), rows (b,t)
+    else:
+        pre = ops.gemm_nt(x2d, proj_w, proj_b)                               # (B*T, H), rows (b,t)
     a = ops.layernorm_act(pre, ln0_g, ln0_b, act=ACT_GELU, remap=(T, B, Bp), drop_p=p_in, seed=_seed(seed, 0),
                           out_bf16=mixed and frag)   # (T*Bp, H) time-major; bf16 when only bf16 GEMMs read it
     if save:
-        sv["x2d"], sv["pre"], sv["a"] = x2d, pre, a
+        sv["x2d"], sv["pre"], sv["a"], sv["xb"] = x2d, pre, a, xb
         sv["layers"] = []
     inp = a
     for layer in range(L):

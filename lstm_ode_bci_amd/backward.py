@@ -128,7 +128,15 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad):
     db0 = torch.zeros((sv["pre"].shape[1],), device=dY.device, dtype=torch.float32) if db_fused else None
     dpre, g[2], g[3] = ops.layernorm_act_bwd(sv["pre"], ps[2], ps[3], dY, act=ACT_GELU, remap=(T, B, Bp),
                                              drop_p=p_in, seed=_seed(seed, 0), dx_colsum=db0)
-    gx2d, g[0], g[1] = _linear_bwd(dpre, sv["x2d"], ps[0], need_dx=bool(needs_input_grad[0]), need_w=need_w,
-                                   db=db0)
+    if sv.get("xb") is not None and need_w:      # mixed: dW through the bf16 TN kernel on the padded bf16 windows
+        xb = sv["xb"]
+        dwp = torch.zeros((ps[0].shape[0], xb.shape[1]), device=dY.device, dtype=torch.float32)
+        ops.gemm_tn(dpre, xb, dwp, mixed=True)
+        g[0] = dwp[:, :C].contiguous()
+        g[1] = db0 if db0 is not None else ops.colsum(dpre)
+        gx2d = ops.gemm_nt(dpre, _t(ps[0])) if needs_input_grad[0] else None
+    else:
+        gx2d, g[0], g[1] = _linear_bwd(dpre, sv["x2d"], ps[0], need_dx=bool(needs_input_grad[0]), need_w=need_w,
+                                       db=db0)
     gx = gx2d.reshape(B, T, C) if gx2d is not None else None
     return gx, g

@@ -130,7 +130,35 @@ __global__ __launch_bounds__(256) void abs_colsum_kernel(const float* __restrict
     }
 }
 
+// out[row][0..Cp) = bf16(in[row][0..C)), zero-padded: one thread per 8 output elements (one 16-B store).
+__global__ __launch_bounds__(256) void pad_cast_bf16_kernel(const float* __restrict__ in, __bf16* __restrict__ out,
+                                                            size_t rows, int C, int Cp) {
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    const int cpr = Cp >> 3;                                   // chunks per row
+    const size_t total = rows * cpr, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const size_t row = i / cpr;
+        const int c0 = (int)(i % cpr) * 8;
+        const float* src = in + row * C + c0;
+        bf16x8_t v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (__bf16)(c0 + j < C ? src[j] : 0.f);
+        *reinterpret_cast<bf16x8_t*>(out + row * Cp + c0) = v;
+    }
+}
+
 }  // namespace
+
+extern "C" int lob_pad_cast_bf16(const float* in, void* out, int64_t rows, int C, int Cp, void* stream) {
+    if (!in || !out || rows <= 0 || C <= 0 || Cp < C || (Cp & 7)) return LOB_E_ARG;
+    if (reinterpret_cast<uintptr_t>(out) & 15) return LOB_E_ALIGN;
+    int64_t blocks = (rows * (Cp >> 3) + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(pad_cast_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in,
+                       reinterpret_cast<__bf16*>(out), (size_t)rows, C, Cp);
+    LOB_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int lob_weighted_ce_f32(const float* logits, const int64_t* target, const float* class_weight,
                                    float* loss, float* dlogits, int* correct, int B, int C, float scale,

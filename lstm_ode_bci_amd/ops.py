@@ -437,3 +437,13 @@ def abs_colsum(gx2d, out, scale=1.0):
     rc = _lib.lib().lob_abs_colsum_f32(_ptr(gx2d), rows, Cn, float(scale), _ptr(out), _stream())
     _lib.check(rc, "lob_abs_colsum_f32")
     return out
+
+
+def pad_cast_bf16(x, Cp):
+    """bf16 copy of x[rows, C] with the columns zero-padded to Cp (a multiple of 8)."""
+    _chk(x, "x")
+    rows, Cn = x.shape
+    out = torch.empty((rows, Cp), device=x.device, dtype=torch.bfloat16)
+    rc = _lib.lib().lob_pad_cast_bf16(_ptr(x), _ptr(out), rows, Cn, Cp, _stream())
+    _lib.check(rc, "lob_pad_cast_bf16")
+    return out
