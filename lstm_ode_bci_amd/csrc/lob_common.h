@@ -85,10 +85,22 @@ __device__ __forceinline__ uint32_t lob_hash32(uint64_t seed, uint64_t idx) {
     x ^= x >> 12;
     return x;
 }
+// One 32-bit hash decides TWO neighbouring elements (idx >> 1; the even element reads bits 0..15, the odd one bits
+// 16..31), against a 16-bit threshold: p is quantised to 1/65536 (0.4 -> 0.399994).  Kernels that own both elements
+// of a pair call lob_dropout_scale2 and pay for one hash; everything else calls lob_dropout_scale -- the same mask.
+__device__ __forceinline__ uint32_t lob_dropout_thr16(float p) { return (uint32_t)(p * 65536.0f); }
 __device__ __forceinline__ float lob_dropout_scale(uint64_t seed, uint64_t idx, float p) {
     // returns 0 (dropped) or 1/(1-p) (kept); p in [0,1)
-    const uint32_t thr = (uint32_t)(p * 4294967296.0);
-    return lob_hash32(seed, idx) >= thr ? 1.0f / (1.0f - p) : 0.0f;
+    const uint32_t h = lob_hash32(seed, idx >> 1);
+    const uint32_t bits = (idx & 1) ? (h >> 16) : (h & 0xffffu);
+    return bits >= lob_dropout_thr16(p) ? 1.0f / (1.0f - p) : 0.0f;
+}
+// idx_even must be even: scales of elements idx_even and idx_even + 1
+__device__ __forceinline__ void lob_dropout_scale2(uint64_t seed, uint64_t idx_even, float p, float& s0, float& s1) {
+    const uint32_t h = lob_hash32(seed, idx_even >> 1), thr = lob_dropout_thr16(p);
+    const float keep = 1.0f / (1.0f - p);
+    s0 = (h & 0xffffu) >= thr ? keep : 0.0f;
+    s1 = (h >> 16) >= thr ? keep : 0.0f;
 }
 
 // LDS read that the compiler cannot see (inline asm): used next to in-flight LDS-DMA (global_load_lds),

@@ -148,8 +148,12 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h256_bf16_kernel(
                 if (DROP) {
                     bf16x8 dv;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        dv[j] = (__bf16)((float)hv[j] * lob_dropout_scale(seed, (uint64_t)o + j, drop_p));
+                    for (int j = 0; j < 8; j += 2) {          // o is a multiple of 8: (o+j, o+j+1) share one hash
+                        float s0, s1;
+                        lob_dropout_scale2(seed, (uint64_t)o + j, drop_p, s0, s1);
+                        dv[j] = (__bf16)((float)hv[j] * s0);
+                        dv[j + 1] = (__bf16)((float)hv[j + 1] * s1);
+                    }
                     *reinterpret_cast<bf16x8*>(Yd + o) = dv;
                 }
             }

@@ -309,12 +309,16 @@ __global__ __launch_bounds__(256) void layernorm_act_vec_kernel(
 #pragma unroll
             for (int i = 0; i < VPL; ++i) { const float dl = v[i] - mean; q += dl * dl; }
             const float rstd = norm ? rsqrtf(wave_sum(q) * invw + eps) : 1.f;
+            float ds[VPL];              // dropout scales: one hash per pair of neighbouring columns
+#pragma unroll
+            for (int i = 0; i < VPL; i += 2) {
+                if (drop_p > 0.f) lob_dropout_scale2(seed, (uint64_t)orow * width + lane * VPL + i, drop_p, ds[i], ds[i + 1]);
+                else { ds[i] = 1.f; ds[i + 1] = 1.f; }
+            }
 #pragma unroll
             for (int i = 0; i < VPL; ++i) {
                 float o = (v[i] - mean) * rstd * gm[i] + bt[i];
-                o = apply_act(o, act);
-                if (drop_p > 0.f) o *= lob_dropout_scale(seed, (uint64_t)orow * width + lane * VPL + i, drop_p);
-                v[i] = o;
+                v[i] = apply_act(o, act) * ds[i];
             }
             if (OUT_BF16) stv_bf16<VPL>(reinterpret_cast<__bf16*>(outv) + (size_t)orow * width + lane * VPL, v);
             else          stv<VPL>(reinterpret_cast<float*>(outv) + (size_t)orow * width + lane * VPL, v);
@@ -382,11 +386,16 @@ __global__ __launch_bounds__(256) void layernorm_act_bwd_vec_kernel(
             for (int i = 0; i < VPL; ++i) { const float dl = v[i] - mean; q += dl * dl; }
             const float rstd = norm ? rsqrtf(wave_sum(q) * invw + eps) : 1.f;
             float m1 = 0.f, m2 = 0.f;
+            float ds[VPL];
+#pragma unroll
+            for (int i = 0; i < VPL; i += 2) {
+                if (drop_p > 0.f) lob_dropout_scale2(seed, (uint64_t)orow * width + lane * VPL + i, drop_p, ds[i], ds[i + 1]);
+                else { ds[i] = 1.f; ds[i + 1] = 1.f; }
+            }
 #pragma unroll
             for (int i = 0; i < VPL; ++i) {
                 const float xh = (v[i] - mean) * rstd;
-                float g = go[i];
-                if (drop_p > 0.f) g *= lob_dropout_scale(seed, (uint64_t)orow * width + lane * VPL + i, drop_p);
+                float g = go[i] * ds[i];
                 if (act == LOB_ACT_GELU) g *= gelu_grad(xh * gm[i] + bt[i]);
                 dga[i] += g * xh;
                 dba[i] += g;
