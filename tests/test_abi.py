@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -39,3 +41,12 @@ def test_argument_errors_without_a_gpu():
     assert L.lob_softmax_rows_f32(None, None, 0, 0, None) == -1
     rates = (ctypes.c_double * 6)(*[0.1] * 6)
     assert L.lob_ode_rk4_f64(None, None, rates, 0.5, 10, 0.0, 10.0, 16, None, None, None, 4, 0, None) == -1
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No CPU fallback anywhere: without liblob.so every entry into the product path raises LobError."""
+    from lstm_ode_bci_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "no_such_liblob.so"))
+    with pytest.raises(_lib.LobError, match="not built|not found"):
+        _lib.lib()
