@@ -109,3 +109,24 @@ def multistep_forecast(probs, ode_params, horizons=[5, 10, 20]):
         results[h]["predictions"] = np.clip(traj[:, h, 2] + traj[:, h, 1] * 0.5, 0, 1)
         results[h]["actuals"] = probs[h:h + n, 1].copy()
     return results
+
+
+def rolling_forecast_evaluation(probs, ode_params, window_size=50, horizon=10):
+    """08_forecasting.py:346-392: accuracy and MAE of the `horizon`-step forecast per rolling window; returns the same
+    pandas DataFrame (columns window, accuracy, mae).  All windows' trajectories come from ONE batched device solve
+    (the reference solves one odeint per sample)."""
+    import pandas as pd
+    probs = np.asarray(probs)
+    n_windows = (len(probs) - window_size - horizon) // window_size
+    rows = []
+    if n_windows <= 0:
+        return pd.DataFrame(rows)
+    n = n_windows * window_size                   # every i < n has i + horizon < len(probs) (n_windows' definition)
+    traj = forecast_trajectories(probs[:n], ode_params, horizon).cpu().numpy()
+    preds = np.clip(traj[:, horizon, 2] + traj[:, horizon, 1] * 0.5, 0, 1)
+    actuals = probs[horizon:horizon + n, 1]
+    for w in range(n_windows):
+        sl = slice(w * window_size, (w + 1) * window_size)
+        rows.append({"window": w, "accuracy": np.mean((preds[sl] > 0.5) == (actuals[sl] > 0.5)),
+                     "mae": np.mean(np.abs(preds[sl] - actuals[sl]))})
+    return pd.DataFrame(rows)

@@ -280,6 +280,23 @@ def multistep_forecast(probs, p, horizons=(5, 10, 20)):
     return {h: {k: np.array(v) for k, v in r.items()} for h, r in res.items()}
 
 
+def rolling_forecast(probs, p, window_size=50, horizon=10):
+    """08_forecasting.py:346-392: [(window, accuracy, mae)] per rolling window."""
+    out = []
+    for w in range((len(probs) - window_size - horizon) // window_size):
+        preds, acts = [], []
+        for i in range(w * window_size, (w + 1) * window_size):
+            if i + horizon >= len(probs):
+                break
+            traj = forecast_raw(prob_to_ode_state(probs[i, 1]), p, horizon)
+            preds.append(np.clip(traj[horizon, 2] + traj[horizon, 1] * 0.5, 0, 1))
+            acts.append(probs[i + horizon, 1])
+        if preds:
+            preds, acts = np.array(preds), np.array(acts)
+            out.append((w, np.mean((preds > 0.5) == (acts > 0.5)), np.mean(np.abs(preds - acts))))
+    return out
+
+
 def three_state_from_probs(probs, base):
     """Step 2 of 10_three_state_probabilities.py:239-290 (alpha = 0.5, 20 points over [0,20])."""
     traj, _ = predict_from_probs(probs, base, 0.5, 20)

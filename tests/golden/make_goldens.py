@@ -235,6 +235,13 @@ def g5_consumers(g6, g8, g10):
             out[f"fc_act_{pname}_h{h}"] = res[h]["actuals"]
         out[f"fc_traj_{pname}"] = g8["predict_trajectory"](g8["prob_to_ode_state"](probs[5, 1]), dict(rates), 20)
     out["fc_state_grid"] = np.array([g8["prob_to_ode_state"](np.float32(p)) for p in np.linspace(0, 1, 21)])
+    # 08: rolling_forecast_evaluation (window accuracy / MAE) on a longer probability series
+    probs_r = syn.make_probs(150, seed=9)
+    out["roll_probs"] = probs_r
+    for pname, rates in (("default", syn.DEFAULT_RATES), ("fitted", syn.FITTED_RATES)):
+        with contextlib.redirect_stdout(io.StringIO()):
+            df = g8["rolling_forecast_evaluation"](probs_r, dict(rates), window_size=20, horizon=10)
+        out[f"roll_{pname}"] = df[["window", "accuracy", "mae"]].to_numpy(np.float64)
     np.savez_compressed(os.path.join(HERE, "g5_consumers.npz"), **out)
     print("g5 three_pred", out["three_pred_fitted"][:12], "fc", out["fc_pred_fitted_h20"][:3])
 
@@ -337,6 +344,9 @@ if __name__ == "__main__":
             g7_channel_importance(load_ref("07_explainability.py"))
         if "g8" in only:
             g8_ablation(load_ref("09_sensitivity_analysis.py"))
+        if "g5" in only:
+            g5_consumers(load_ref("06_lstm_ode_integration.py"), load_ref("08_forecasting.py"),
+                         load_ref("10_three_state_probabilities.py"))
         sys.exit(0)
     g5 = load_ref("05_ode_model.py")
     g6 = load_ref("06_lstm_ode_integration.py")

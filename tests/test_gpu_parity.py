@@ -531,6 +531,13 @@ def test_consumers_vs_reference(dev):
         for h in (5, 10, 20):
             assert np.abs(res[h]["predictions"] - d[f"fc_pred_{pname}_h{h}"]).max() < 1e-6
             assert np.array_equal(res[h]["actuals"], d[f"fc_act_{pname}_h{h}"])
+        df = consumers.rolling_forecast_evaluation(d["roll_probs"], dict(rates), window_size=20, horizon=10)
+        gold = d[f"roll_{pname}"]
+        assert list(df.columns) == ["window", "accuracy", "mae"] and len(df) == len(gold)
+        assert np.array_equal(df["window"].to_numpy(), gold[:, 0])
+        assert np.abs(df["mae"].to_numpy() - gold[:, 2]).max() < 1e-6
+        assert np.abs(df["accuracy"].to_numpy() - gold[:, 1]).max() <= 1 / 20 + 1e-12   # one 0.5-boundary flip at most
+        assert len(consumers.rolling_forecast_evaluation(d["roll_probs"][:25], dict(rates), 20, 10)) == 0
         tr = consumers.predict_trajectory(consumers.prob_to_ode_state(d["fc_probs"][5, 1]), dict(rates), 20)
         assert tr.shape == (21, 3) and np.abs(tr - d[f"fc_traj_{pname}"]).max() < 1e-6
     pr = consumers.get_lstm_probabilities(m, x, batch_size=8)

@@ -134,6 +134,8 @@ def test_consumer_signatures():
     assert list(inspect.signature(consumers.get_three_state_probabilities).parameters) == \
         ["lstm_model", "ode_model", "X", "batch_size"]
     assert list(inspect.signature(consumers.multistep_forecast).parameters) == ["probs", "ode_params", "horizons"]
+    assert list(inspect.signature(consumers.rolling_forecast_evaluation).parameters) == \
+        ["probs", "ode_params", "window_size", "horizon"]
     assert list(inspect.signature(consumers.predict_trajectory).parameters)[:4] == \
         ["initial_state", "params", "n_steps", "dt"]
     grid = np.load(os.path.join(GOLDEN, "g5_consumers.npz"))["fc_state_grid"]

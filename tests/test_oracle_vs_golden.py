@@ -139,6 +139,8 @@ def test_consumers_08_and_10():
             assert np.array_equal(res[h]["predictions"], d[f"fc_pred_{pname}_h{h}"])
             assert np.array_equal(res[h]["actuals"], d[f"fc_act_{pname}_h{h}"])
         assert np.array_equal(R.forecast_raw(R.prob_to_ode_state(d["fc_probs"][5, 1]), rates, 20), d[f"fc_traj_{pname}"])
+        roll = np.array(R.rolling_forecast(d["roll_probs"], rates, window_size=20, horizon=10), np.float64)
+        assert np.array_equal(roll, d[f"roll_{pname}"])
     grid = np.array([R.prob_to_ode_state(np.float32(p)) for p in np.linspace(0, 1, 21)])
     assert np.array_equal(grid, d["fc_state_grid"])
     assert set(np.unique(d["three_pred_fitted"])) >= {0, 1}
