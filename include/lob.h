@@ -134,6 +134,13 @@ int lob_gate_gemm_x_bf16(const void* X, int x_bf16, int ldx, const void* Wih, in
  *   they save for BPTT in bf16.  Accumulation, cell state and everything else stay fp32.          */
 int lob_gemm_tn_bf16(const void* A, int a_bf16, int lda, const void* B, int b_bf16, int ldb,
                      float* C, int ldc, int M, int N, int Kc, void* stream);
+/*   Both weight gradients of one LSTM layer (the dW_ih / dW_hh that loss.backward() accumulates for
+ *   lstm.weight_ih_l* / weight_hh_l*, 04_lstm_model.py:490) from ONE pass over the bf16 gate gradients:
+ *   dWih[D*4H][nx] += dP^T X and dWhh[D][4H][H] += dP[:, d]^T h_prev_d, where h_prev is Y one step (Bp rows)
+ *   earlier (d = 0) or later (d = 1).  dP [T*Bp][ldp], X [T*Bp][ldx], Y [T*Bp][ldy] bf16 time-major; outputs
+ *   fp32, zeroed by the caller.  H == 128, nx in {128, 256}, Bp % 32 == 0, T >= 2; else LOB_E_SHAPE.   */
+int lob_lstm_dw_bf16(const void* dP, int ldp, const void* X, int ldx, int nx, const void* Y, int ldy,
+                     float* dWih, float* dWhh, int T, int Bp, int H, int D, void* stream);
 
 /* Recurrent kernels with the hidden-state gate GEMM on bf16 MFMA (H == 128 and H == 256; cell state and
  * everything carried through time stay fp32).  Same arguments as lob_lstm_rec_fwd_f32 / lob_lstm_rec_bwd_f32;

@@ -37,6 +37,8 @@ _SIGS = {
                               C.c_int, C.c_int, C.c_int, C.c_void_p], C.c_int),
     "lob_gemm_tn_bf16": ([_f32p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.c_int, C.c_int,
                           C.c_void_p], C.c_int),
+    "lob_lstm_dw_bf16": ([_f32p, C.c_int, _f32p, C.c_int, C.c_int, _f32p, C.c_int, _f32p, _f32p, C.c_int, C.c_int,
+                          C.c_int, C.c_int, C.c_void_p], C.c_int),
     "lob_colsum_f32": ([_f32p, C.c_int, C.c_int, C.c_int, _f32p, C.c_void_p], C.c_int),
     "lob_act_f32": ([_f32p, _f32p, C.c_int64, C.c_int, C.c_void_p], C.c_int),
     "lob_act_bwd_f32": ([_f32p, _f32p, _f32p, C.c_int64, C.c_int, C.c_void_p], C.c_int),

@@ -93,12 +93,15 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad):
         dP, dbias = ops.lstm_rec_bwd(lay["G"], lay["C"], lay["whh"], dY, T, Bp, H, D, dp_bf16=mixed)
         inp, Y, wih = lay["inp"], lay["Y"], lay["wih"]
         base = 4 + layer * 4 * D
-        if need_w:
+        fused_dw = need_w and ops.can_fuse_dw(dP, inp, Y, T, Bp, H, D)
+        if fused_dw:
+            dwih, dwhh_all = ops.lstm_dw(dP, inp, Y, T, Bp, H, D)
+        elif need_w:
             dwih = torch.zeros_like(wih)
             ops.gemm_tn(dP, inp, dwih, mixed=mixed)
         for d in range(D if need_w else 0):
-            dwhh = torch.zeros_like(ps[base + 4 * d + 1])
-            if T > 1:
+            dwhh = dwhh_all[d] if fused_dw else torch.zeros_like(ps[base + 4 * d + 1])
+            if T > 1 and not fused_dw:
                 a_sl = dP[:, d * 4 * H:(d + 1) * 4 * H]
                 y_sl = Y[:, d * H:(d + 1) * H]
                 if d == 0:      # h_prev(t) = h(t-1)

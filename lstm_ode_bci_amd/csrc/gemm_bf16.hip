@@ -697,6 +697,198 @@ __global__ __launch_bounds__((BTM / 64) * (BTN / 64) * 64, (BTM / 64) * (BTN / 6
         }
 }
 
+// ------------------------------------------------------------------------------------------
+// Both weight gradients of one LSTM layer in ONE pass over dP (H = 128):
+//     dW_ih[d] (4H x NX)  = sum_rows dP[row, d]^T X[row]
+//     dW_hh[d] (4H x H)   = sum_rows dP[row, d]^T h_prev_d[row],   h_prev_0[t] = Y[t-1, 0:H], h_prev_1[t] = Y[t+1, H:2H]
+// dP (bf16, 2 KB per row) is by far the widest operand; as two GEMM launches it was read from HBM twice
+// per layer.  Output tile 128 (dP columns) x (NX + 128): the contraction tile of dP is paired with the same
+// rows of X and with the rows of Y one time step (Bp rows) earlier / later; k-tiles that lie in the step
+// without a predecessor (t = 0 forward, t = T-1 reverse) skip the Y products (Bp % 32 == 0: a k-tile never
+// straddles two steps).  16 waves as 4 x 4, wave tile 32 x (NX + 128) / 4; same ring / swizzle / split-k /
+// XCD map as gemm_tn_dma_kernel.
+// ------------------------------------------------------------------------------------------
+constexpr int DWDS = 4;          // ring slots of the fused dW kernel (40 KB each at NX = 256: all 160 KB of LDS)
+struct DWArgs {
+    const __bf16* dP; const __bf16* X; const __bf16* Y; float* dWih; float* dWhh;
+    int ldp, ldx, ldy, T, Bp, kchunk, tiles;
+};
+
+template <int COLS>
+__device__ __forceinline__ bf16x8 tr_pair(const __bf16* a) {       // k-rows r .. r+3 and r+4 .. r+7 of one fragment
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a + 4 * COLS));
+    bf16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return f;
+}
+
+template <int NX>
+__global__ __launch_bounds__(512, 2) void lstm_dw_h128_kernel(DWArgs g) {
+    constexpr int BTM = 256, NBW = (NX + 128) / 64, XB = NX / 32;       // 32-col blocks per wave; X blocks in all
+    constexpr int ASLOT = 32 * BTM, XSLOT = 32 * NX, YSLOT = 32 * 128, SLOT = ASLOT + XSLOT + YSLOT;
+    constexpr int NDS = DWDS;
+    constexpr int NDMA = 2 + NX / 128 + 1;                              // DMA instructions per wave per k-tile
+    constexpr int VM_STEADY = (NDS - 2) * NDMA;
+    __shared__ __attribute__((aligned(1024))) __bf16 ring[NDS * SLOT];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+    const int tile = rest % g.tiles, chunk = (rest / g.tiles) * 8 + xcd;
+    const int m0 = tile * BTM, d = m0 / 512;
+    const int Kc = g.T * g.Bp;
+    const int kbeg = chunk * g.kchunk, kend = min(Kc, kbeg + g.kchunk);
+    if (kbeg >= kend) return;
+    const int total = (kend - kbeg) / 32;
+    // rows [ex_lo, ex_hi) of dP have no h_prev
+    const int ex_lo = d == 0 ? 0 : (g.T - 1) * g.Bp, ex_hi = ex_lo + g.Bp;
+    const int yshift = d == 0 ? -g.Bp : g.Bp;
+
+    // DMA sources: wave-uniform 64-bit base (advances by k-tile) + 32-bit lane byte offsets, so that the instruction
+    // takes the base from SGPRs.  One instruction covers 2 k-rows of a 256-column tile (4 of a 128-column one); k-row
+    // kr's 16-B chunk ch comes from source chunk ch ^ 4 (kr & 3) (dma_krows).
+    const int l5 = lane >> 5, c5 = lane & 31, l4 = lane >> 4, c4 = lane & 15;
+    unsigned da_off[2], dx_off[2], dy_off;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int kr = wave * 4 + 2 * e + l5;
+        da_off[e] = 2 * (kr * g.ldp + ((c5 ^ ((kr & 3) << 2)) * 8));
+        dx_off[e] = 2 * (kr * g.ldx + ((c5 ^ ((kr & 3) << 2)) * 8));
+    }
+    {
+        const int kr = wave * 4 + l4;
+        dy_off = 2 * (kr * g.ldy + ((c4 ^ ((kr & 3) << 2)) * 8));
+        if (NX == 128) dx_off[0] = 2 * (kr * g.ldx + ((c4 ^ ((kr & 3) << 2)) * 8));
+    }
+    const char* dP_b = reinterpret_cast<const char*>(g.dP + m0);
+    const char* X_b = reinterpret_cast<const char*>(g.X);
+    const char* Y_b = reinterpret_cast<const char*>(g.Y + d * 128);
+    int p_q = 0;
+    auto issue = [&]() {            // per wave and k-tile: 4 k-rows of dP (2 instructions), 4 of X (2 or 1), 4 of h_prev (1)
+        __bf16* as = ring + (p_q % NDS) * SLOT;
+        __bf16* xs = as + ASLOT;
+        __bf16* ys = xs + XSLOT;
+        const int k0 = kbeg + p_q * 32;
+        const char* pa = dP_b + (size_t)k0 * g.ldp * 2;
+        const char* px = X_b + (size_t)k0 * g.ldx * 2;
+        __builtin_amdgcn_global_load_lds((gbl_cvoid*)(pa + da_off[0]), (lds_void*)(as + wave * 4 * 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_cvoid*)(pa + da_off[1]), (lds_void*)(as + (wave * 4 + 2) * 256), 16, 0, 0);
+        if (NX == 256) {
+            __builtin_amdgcn_global_load_lds((gbl_cvoid*)(px + dx_off[0]), (lds_void*)(xs + wave * 4 * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_cvoid*)(px + dx_off[1]), (lds_void*)(xs + (wave * 4 + 2) * 256), 16, 0, 0);
+        } else {
+            __builtin_amdgcn_global_load_lds((gbl_cvoid*)(px + dx_off[0]), (lds_void*)(xs + wave * 4 * 128), 16, 0, 0);
+        }
+        // rows of the step without a predecessor are fetched unshifted and never used
+        const int ky = (k0 >= ex_lo && k0 < ex_hi) ? k0 : k0 + yshift;
+        const char* py = Y_b + (size_t)ky * g.ldy * 2;
+        __builtin_amdgcn_global_load_lds((gbl_cvoid*)(py + dy_off), (lds_void*)(ys + wave * 4 * 128), 16, 0, 0);
+        ++p_q;
+    };
+#pragma unroll 1
+    for (int i = 0; i < NDS - 1 && i < total; ++i) issue();
+
+    f32x16 acc[2][NBW];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NBW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // tr-read addressing (see tr_frag_sw): element (k-row 8 h + q, column cb + 16 mh + 4 p) of a [k][COLS] tile sits at
+    // column (cb ^ 32 q) + 16 mh + 4 p.  Of a 32-column block index only the two low bits meet the swizzle: this wave's
+    // row blocks 2 wr + i and column blocks 2 j + wc need two lane offsets per operand, the rest is a compile-time
+    // offset in the DS instruction.  Byte addresses, relative to the slot.
+    const int fh = lane >> 5, fmh = (lane >> 4) & 1, fq = (lane >> 2) & 3, fp = lane & 3;
+    const int frow = 8 * fh + fq, fcol = 16 * fmh + 4 * fp;
+    const unsigned ring_b = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const __bf16*)ring;
+    // (block + 1 of an even block = address ^ 64 B, block + 2 of a block < 2 = address ^ 128 B; slots are 1-KB aligned)
+    const unsigned a_off = ring_b + 2 * (frow * 256 + 32 * ((((2 * wr) & 3) ^ fq) + ((2 * wr) & ~3)) + fcol);
+    const unsigned x_off = ring_b + 2 * (frow * NX + 32 * (wc ^ fq) + fcol);
+    const unsigned y_off = ring_b + 2 * (frow * 128 + 32 * (wc ^ fq) + fcol);
+    // The fragment reads are inline asm: hipcc cannot tell which ring slot a ds_read_b64_tr_b16 touches and puts an
+    // s_waitcnt vmcnt(0) in front of compiler-visible ones -- that waits for the DMA issued a moment ago, i.e. it
+    // serialises the ring.  Asm reads are invisible to that pass; their own completion is counted here (LDS operations
+    // return in order): the s_waitcnt lgkmcnt(n) that releases a fragment carries its registers as "+v" operands, so no
+    // MFMA can be scheduled above it.
+#define LOB_TR2(f, addr, OFF, HI)                                                                              \
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"                   \
+                 : "=&v"(f##l), "=&v"(f##h) : "v"(addr), "n"(OFF), "n"((OFF) + (HI)) : "memory")
+#define LOB_LGKM(n, f) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(f##l), "+v"(f##h))
+#define LOB_FRAG(f) bf16x8{f##l[0], f##l[1], f##l[2], f##l[3], f##h[0], f##h[1], f##h[2], f##h[3]}
+    constexpr int XO = 2 * ASLOT, YO = 2 * (ASLOT + XSLOT);             // byte offsets of the X / h_prev tiles in a slot
+    constexpr int XS = 2 * 16 * NX, XH = 2 * 4 * NX;                    // bytes per k-step / to the upper 4 k-rows
+
+    for (int q = 0; q < total; ++q) {
+        if (q + NDS - 1 > total) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_STEADY) : "memory");
+        __builtin_amdgcn_s_barrier();
+        if (p_q < total) issue();
+        const unsigned sb = (q % NDS) * (2 * SLOT);
+        const unsigned va0 = sb + a_off, va1 = va0 ^ 64;
+        const unsigned vx0 = sb + x_off, vx1 = vx0 ^ 128, vy0 = sb + y_off, vy1 = vy0 ^ 128;
+        const int k0 = kbeg + q * 32;
+        const bool has_prev = !(k0 >= ex_lo && k0 < ex_hi);
+        bf16x4 a0l, a0h, a1l, a1h, b0l, b0h, b1l, b1h, b2l, b2h, b3l, b3h;
+#define LOB_KSTEP(S)                                                                                           \
+        LOB_TR2(a0, va0, 8192 * S, 2048);                                                                      \
+        LOB_TR2(a1, va1, 8192 * S, 2048);                                                                      \
+        LOB_TR2(b0, vx0, XO + XS * S, XH);                                                                     \
+        LOB_TR2(b1, vx1, XO + XS * S, XH);                                                                     \
+        if constexpr (NX == 256) {                                                                             \
+            LOB_TR2(b2, vx0, XO + XS * S + 256, XH);                                                           \
+            LOB_TR2(b3, vx1, XO + XS * S + 256, XH);                                                           \
+            asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a0l), "+v"(a0h), "+v"(a1l), "+v"(a1h), "+v"(b0l), "+v"(b0h)); \
+        } else {                                                                                               \
+            asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a0l), "+v"(a0h), "+v"(a1l), "+v"(a1h), "+v"(b0l), "+v"(b0h)); \
+        }                                                                                                      \
+        acc[0][0] = mfma_bf16(LOB_FRAG(a0), LOB_FRAG(b0), acc[0][0]);                                          \
+        acc[1][0] = mfma_bf16(LOB_FRAG(a1), LOB_FRAG(b0), acc[1][0]);                                          \
+        if constexpr (NX == 256) { LOB_LGKM(4, b1); } else { LOB_LGKM(0, b1); }                                \
+        acc[0][1] = mfma_bf16(LOB_FRAG(a0), LOB_FRAG(b1), acc[0][1]);                                          \
+        acc[1][1] = mfma_bf16(LOB_FRAG(a1), LOB_FRAG(b1), acc[1][1]);                                          \
+        if constexpr (NX == 256) {                                                                             \
+            LOB_LGKM(2, b2);                                                                                   \
+            acc[0][2] = mfma_bf16(LOB_FRAG(a0), LOB_FRAG(b2), acc[0][2]);                                      \
+            acc[1][2] = mfma_bf16(LOB_FRAG(a1), LOB_FRAG(b2), acc[1][2]);                                      \
+            LOB_LGKM(0, b3);                                                                                   \
+            acc[0][3] = mfma_bf16(LOB_FRAG(a0), LOB_FRAG(b3), acc[0][3]);                                      \
+            acc[1][3] = mfma_bf16(LOB_FRAG(a1), LOB_FRAG(b3), acc[1][3]);                                      \
+        }                                                                                                      \
+        if (has_prev) {                                                                                        \
+            LOB_TR2(b0, vy0, YO + 4096 * S, 1024);                                                             \
+            LOB_TR2(b1, vy1, YO + 4096 * S, 1024);                                                             \
+            LOB_LGKM(2, b0);                                                                                   \
+            acc[0][XB / 2] = mfma_bf16(LOB_FRAG(a0), LOB_FRAG(b0), acc[0][XB / 2]);                            \
+            acc[1][XB / 2] = mfma_bf16(LOB_FRAG(a1), LOB_FRAG(b0), acc[1][XB / 2]);                            \
+            LOB_LGKM(0, b1);                                                                                   \
+            acc[0][XB / 2 + 1] = mfma_bf16(LOB_FRAG(a0), LOB_FRAG(b1), acc[0][XB / 2 + 1]);                    \
+            acc[1][XB / 2 + 1] = mfma_bf16(LOB_FRAG(a1), LOB_FRAG(b1), acc[1][XB / 2 + 1]);                    \
+        }
+        LOB_KSTEP(0)
+        LOB_KSTEP(1)
+#undef LOB_KSTEP
+    }
+#undef LOB_TR2
+#undef LOB_LGKM
+#undef LOB_FRAG
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+            const bool isx = j < XB / 2;
+            float* C = isx ? g.dWih : g.dWhh;
+            const int ldc = isx ? NX : 128;
+            const int col = 32 * (2 * j + wc - (isx ? 0 : XB)) + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + 64 * wr + 32 * i + acc_row(r, lane);
+                atomicAdd(C + (size_t)row * ldc + col, acc[i][j][r]);
+            }
+        }
+}
+
 __global__ __launch_bounds__(256) void colsum_bf16_kernel(const __bf16* __restrict__ A, int lda, int M, int N,
                                                           int rows_per_block, float* __restrict__ out) {
     __shared__ float red[4][64];
@@ -873,6 +1065,30 @@ extern "C" int lob_gemm_tn_bf16(const void* A, int a_bf16, int lda, const void* 
     else if (a_bf16)            hipLaunchKernelGGL((gemm_tn_bf16_kernel<true, false>), grid, dim3(256), 0, s, g);
     else if (b_bf16)            hipLaunchKernelGGL((gemm_tn_bf16_kernel<false, true>), grid, dim3(256), 0, s, g);
     else                        hipLaunchKernelGGL((gemm_tn_bf16_kernel<false, false>), grid, dim3(256), 0, s, g);
+    LOB_CHECK_LAUNCH();
+    return 0;
+}
+
+// dW_ih (D*4H x nx) and dW_hh (D x 4H x H) of one layer from one pass over dP; both outputs must be zeroed by the
+// caller (split-k partial sums are added atomically).  H = 128, nx in {128, 256}, Bp % 32 == 0, T >= 2.
+extern "C" int lob_lstm_dw_bf16(const void* dP, int ldp, const void* X, int ldx, int nx, const void* Y, int ldy,
+                                float* dWih, float* dWhh, int T, int Bp, int H, int D, void* stream) {
+    if (!dP || !X || !Y || !dWih || !dWhh || T < 2 || Bp <= 0 || (D != 1 && D != 2)) return LOB_E_ARG;
+    if (H != 128 || (nx != 128 && nx != 256) || (Bp % 32)) return LOB_E_SHAPE;
+    if (ldp < D * 4 * H || ldx < nx || ldy < D * H) return LOB_E_SHAPE;
+    if ((ldp % 8) || (ldx % 8) || (ldy % 8) || !al16(dP) || !al16(X) || !al16(Y)) return LOB_E_ALIGN;
+    const int tiles = D * 2;                                  // 256 columns of dP each
+    const long Kc = (long)T * Bp;
+    int nchunk = (256 + tiles - 1) / tiles;                   // one workgroup per CU
+    long kchunk = (Kc + nchunk - 1) / nchunk;
+    kchunk = ((kchunk + 31) / 32) * 32;
+    if (kchunk < 512) kchunk = 512;
+    nchunk = (int)((Kc + kchunk - 1) / kchunk);
+    const int nchunk8 = ((nchunk + 7) / 8) * 8;
+    DWArgs g{(const __bf16*)dP, (const __bf16*)X, (const __bf16*)Y, dWih, dWhh, ldp, ldx, ldy, T, Bp, (int)kchunk, tiles};
+    const dim3 grid((unsigned)(tiles * nchunk8));
+    if (nx == 256) hipLaunchKernelGGL((lstm_dw_h128_kernel<256>), grid, dim3(512), 0, (hipStream_t)stream, g);
+    else           hipLaunchKernelGGL((lstm_dw_h128_kernel<128>), grid, dim3(512), 0, (hipStream_t)stream, g);
     LOB_CHECK_LAUNCH();
     return 0;
 }

@@ -5,6 +5,8 @@ from __future__ import annotations
 import ctypes as C
 
 import numpy as np
+import os
+
 import torch
 
 from . import _lib
@@ -95,6 +97,29 @@ def gemm_tn(a, b, out, mixed=False):
                                     M, N, Kc, _stream())
     _lib.check(rc, "lob_gemm_tn_f32")
     return out
+
+
+#: dW_ih and dW_hh of a layer from one pass over dP (LOB_FUSED_DW=0: two/three separate TN GEMMs)
+FUSED_DW = os.environ.get("LOB_FUSED_DW", "1") != "0"
+
+
+def can_fuse_dw(dP, inp, Y, T, Bp, H, D):
+    bf = torch.bfloat16
+    return (FUSED_DW and H == 128 and T >= 2 and Bp % 32 == 0 and dP.dtype == bf and inp.dtype == bf and Y.dtype == bf
+            and inp.shape[1] in (128, 256) and dP.shape[1] == D * 4 * H and Y.shape[1] == D * H
+            and dP.stride(1) == 1 and inp.stride(1) == 1 and Y.stride(1) == 1
+            and dP.stride(0) % 8 == 0 and inp.stride(0) % 8 == 0 and Y.stride(0) % 8 == 0
+            and dP.data_ptr() % 16 == 0 and inp.data_ptr() % 16 == 0 and Y.data_ptr() % 16 == 0)
+
+
+def lstm_dw(dP, inp, Y, T, Bp, H, D):
+    """(dW_ih (D*4H, nx), dW_hh (D, 4H, H)) fp32 from one pass over the bf16 gate gradients dP."""
+    dwih = torch.zeros((D * 4 * H, inp.shape[1]), device=dP.device, dtype=torch.float32)
+    dwhh = torch.zeros((D, 4 * H, H), device=dP.device, dtype=torch.float32)
+    rc = _lib.lib().lob_lstm_dw_bf16(_ptr(dP), dP.stride(0), _ptr(inp), inp.stride(0), inp.shape[1], _ptr(Y),
+                                     Y.stride(0), _ptr(dwih), _ptr(dwhh), T, Bp, H, D, _stream())
+    _lib.check(rc, "lob_lstm_dw_bf16")
+    return dwih, dwhh
 
 
 #: bf16 x bf16 NT GEMMs with K >= 128, K % 32 == 0 go through the LDS-DMA kernel (pass bf16 weights)

@@ -388,3 +388,54 @@ def test_mixed_h256_train_mode_is_reproducible_and_finite(dev):
     assert outs[0][0] == outs[1][0] and np.isfinite(outs[0][0])
     assert (outs[0][1] - outs[1][1]).abs().max().item() <= 1e-6 * outs[0][1].abs().max().item()
     assert (outs[0][2] - outs[1][2]).abs().max().item() <= 1e-5 * outs[0][2].abs().max().item()
+
+
+@pytest.mark.parametrize("T,Bp,nx,D", [(5, 32, 256, 2), (3, 64, 128, 2), (40, 96, 256, 2), (2, 32, 128, 1), (7, 4096, 256, 2)])
+def test_fused_layer_weight_gradients(dev, T, Bp, nx, D):
+    """dW_ih and dW_hh of a layer from one pass over dP == the exact products of the same bf16 operands (fp64 here),
+    including the time shift of h_prev (t-1 forward, t+1 reverse) and the step without a predecessor."""
+    from lstm_ode_bci_amd import ops
+    H = 128
+    rng = np.random.default_rng(T * Bp + nx)
+    bf = torch.bfloat16
+    dP = torch.from_numpy(rng.standard_normal((T * Bp, D * 4 * H), dtype=np.float32)).to(dev).to(bf)
+    Xw = torch.from_numpy(rng.standard_normal((T * Bp, nx + 64), dtype=np.float32)).to(dev).to(bf)
+    X = Xw[:, :nx]                                          # a column slice of a wider tensor: ld != nx
+    Y = torch.from_numpy(rng.standard_normal((T * Bp, D * H), dtype=np.float32)).to(dev).to(bf)
+    assert ops.can_fuse_dw(dP, X, Y, T, Bp, H, D)
+    dwih, dwhh = ops.lstm_dw(dP, X, Y, T, Bp, H, D)
+    p64, x64, y64 = dP.double(), X.double(), Y.double()
+    ref_ih = p64.T @ x64
+    tol = 2e-5 * (T * Bp) ** 0.5 * 4
+    assert (dwih.double() - ref_ih).abs().max().item() < tol
+    for d in range(D):
+        a = p64[:, d * 4 * H:(d + 1) * 4 * H]
+        y = y64[:, d * H:(d + 1) * H]
+        ref = a[Bp:].T @ y[:(T - 1) * Bp] if d == 0 else a[:(T - 1) * Bp].T @ y[Bp:]
+        assert (dwhh[d].double() - ref).abs().max().item() < tol, d
+    # shapes the kernel refuses are reported, not computed wrongly
+    assert not ops.can_fuse_dw(dP, X, Y, T, Bp, 64, D)
+    assert not ops.can_fuse_dw(dP.float(), X, Y, T, Bp, H, D)
+
+
+def test_fused_weight_gradients_same_step_as_separate_gemms(dev, monkeypatch):
+    """The whole mixed backward with the fused dW kernel == with the separate TN GEMMs (fp32 accumulation order differs)."""
+    from lstm_ode_bci_amd import ops, EnhancedLSTMModel
+    torch.manual_seed(0)
+    m = EnhancedLSTMModel(input_size=61, hidden_size=128, num_layers=3, dropout=0.0).to(dev)
+    x = torch.randn(48, 24, 61, device=dev)
+    y = torch.randint(0, 2, (48,), device=dev)
+
+    def grads():
+        m.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = torch.nn.functional.cross_entropy(m(x).float(), y)
+        loss.backward()
+        return {k: p.grad.clone() for k, p in m.named_parameters()}
+    monkeypatch.setattr(ops, "FUSED_DW", True)
+    g1 = grads()
+    monkeypatch.setattr(ops, "FUSED_DW", False)
+    g0 = grads()
+    for k in g0:
+        sc = g0[k].abs().max().item() + 1e-12
+        assert (g1[k] - g0[k]).abs().max().item() <= 1e-4 * sc + 1e-7, k
