@@ -128,11 +128,19 @@ def kernel_roofline(dev, B, mode, precision):
                                "mfma": "bf16" if bf16_rec else "f32",
                                "bytes": rows * (pe * N + 8.0 * K + de * N)}   # gates in, c in, dY in, dP out
         dP, _ = ops.lstm_rec_bwd(Pk, Cs, whh, dY, T, Bp, H, D, dp_bf16=mixed)
-        dw = torch.zeros((N, K), device=dev)
-        sec = timeit(lambda: ops.gemm_tn(dP, x, dw, mixed=mixed))
-        out["gemm_tn(dW_ih)"] = {"sec": sec, "flop": 2.0 * rows * N * K, "per_step": L - 1,
-                                 "mfma": "bf16" if mixed else "f32",
-                                 "bytes": de * rows * N + xe * rows * K}
+        Y16 = Y.to(torch.bfloat16) if (Y is not None and dP.dtype == torch.bfloat16) else None
+        if Y16 is not None and ops.can_fuse_dw(dP, x, Y16, T, Bp, H, D):
+            # what the step runs: dW_ih and dW_hh of a layer from one pass over dP
+            sec = timeit(lambda: ops.lstm_dw(dP, x, Y16, T, Bp, H, D))
+            out["lstm_dw(dW_ih+dW_hh)"] = {"sec": sec, "flop": 2.0 * rows * N * (K + H), "per_step": L - 1,
+                                           "mfma": "bf16",
+                                           "bytes": de * rows * N + xe * rows * K + 2.0 * rows * D * H}
+        else:
+            dw = torch.zeros((N, K), device=dev)
+            sec = timeit(lambda: ops.gemm_tn(dP, x, dw, mixed=mixed))
+            out["gemm_tn(dW_ih)"] = {"sec": sec, "flop": 2.0 * rows * N * K, "per_step": L - 1,
+                                     "mfma": "bf16" if mixed else "f32",
+                                     "bytes": de * rows * N + xe * rows * K}
         wt = wih.t().contiguous()
         if dP.dtype == torch.bfloat16 and ops.dma_ok(N, K, rows):
             wt = wt.to(torch.bfloat16)

@@ -667,23 +667,42 @@ __global__ __launch_bounds__((BTM / 64) * (BTN / 64) * 64, (BTM / 64) * (BTN / 6
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // Fragment reads as inline asm with hand-counted lgkmcnt (see lstm_dw_h128_kernel below: compiler-visible
+    // ds_read_b64_tr_b16 of the ring get an s_waitcnt vmcnt(0) in front, which waits for the DMA just issued).
+    // Lane addresses: block 64 wr (+32: address ^ 64 B) of the A tile, block 64 wc of the B tile.
+    const int fh = lane >> 5, fmh = (lane >> 4) & 1, fq = (lane >> 2) & 3, fp = lane & 3;
+    const unsigned ring_b = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const __bf16*)ring;
+    const unsigned a_off = ring_b + 2 * ((8 * fh + fq) * BTM + ((64 * wr) ^ (32 * fq)) + 16 * fmh + 4 * fp);
+    const unsigned b_off = ring_b + 2 * ((8 * fh + fq) * BTN + ((64 * wc) ^ (32 * fq)) + 16 * fmh + 4 * fp);
+#define LOB_TR2(f, addr, OFF, HI)                                                                              \
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"                   \
+                 : "=&v"(f##l), "=&v"(f##h) : "v"(addr), "n"(OFF), "n"((OFF) + (HI)) : "memory")
+#define LOB_FRAG(f) bf16x8{f##l[0], f##l[1], f##l[2], f##l[3], f##h[0], f##h[1], f##h[2], f##h[3]}
     for (int q = 0; q < total; ++q) {
         if (q + DS - 1 > total) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_STEADY) : "memory");
         __builtin_amdgcn_s_barrier();
         if (p_q < total) issue();
-        const __bf16* as = ring + (q % DS) * SLOT;
-        const __bf16* bs = as + ASLOT;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const bf16x8 a0 = tr_frag_sw<BTM>(as, 64 * wr, s, lane), a1 = tr_frag_sw<BTM>(as, 64 * wr + 32, s, lane);
-            const bf16x8 b0 = tr_frag_sw<BTN>(bs, 64 * wc, s, lane), b1 = tr_frag_sw<BTN>(bs, 64 * wc + 32, s, lane);
-            acc[0][0] = mfma_bf16(a0, b0, acc[0][0]);
-            acc[0][1] = mfma_bf16(a0, b1, acc[0][1]);
-            acc[1][0] = mfma_bf16(a1, b0, acc[1][0]);
-            acc[1][1] = mfma_bf16(a1, b1, acc[1][1]);
-        }
+        const unsigned sb = (q % DS) * (2 * SLOT);
+        const unsigned va0 = sb + a_off, va1 = va0 ^ 64, vb0 = sb + b_off, vb1 = vb0 ^ 64;
+        bf16x4 a0l, a0h, a1l, a1h, b0l, b0h, b1l, b1h;
+#define LOB_KSTEP(S)                                                                                           \
+        LOB_TR2(a0, va0, 2 * 16 * BTM * S, 2 * 4 * BTM);                                                       \
+        LOB_TR2(a1, va1, 2 * 16 * BTM * S, 2 * 4 * BTM);                                                       \
+        LOB_TR2(b0, vb0, 2 * ASLOT + 2 * 16 * BTN * S, 2 * 4 * BTN);                                           \
+        LOB_TR2(b1, vb1, 2 * ASLOT + 2 * 16 * BTN * S, 2 * 4 * BTN);                                           \
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a0l), "+v"(a0h), "+v"(a1l), "+v"(a1h), "+v"(b0l), "+v"(b0h)); \
+        acc[0][0] = mfma_bf16(LOB_FRAG(a0), LOB_FRAG(b0), acc[0][0]);                                          \
+        acc[1][0] = mfma_bf16(LOB_FRAG(a1), LOB_FRAG(b0), acc[1][0]);                                          \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b1l), "+v"(b1h));                                           \
+        acc[0][1] = mfma_bf16(LOB_FRAG(a0), LOB_FRAG(b1), acc[0][1]);                                          \
+        acc[1][1] = mfma_bf16(LOB_FRAG(a1), LOB_FRAG(b1), acc[1][1]);
+        LOB_KSTEP(0)
+        LOB_KSTEP(1)
+#undef LOB_KSTEP
     }
+#undef LOB_TR2
+#undef LOB_FRAG
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -811,7 +830,8 @@ __global__ __launch_bounds__(512, 2) void lstm_dw_h128_kernel(DWArgs g) {
     // s_waitcnt vmcnt(0) in front of compiler-visible ones -- that waits for the DMA issued a moment ago, i.e. it
     // serialises the ring.  Asm reads are invisible to that pass; their own completion is counted here (LDS operations
     // return in order): the s_waitcnt lgkmcnt(n) that releases a fragment carries its registers as "+v" operands, so no
-    // MFMA can be scheduled above it.
+    // MFMA can be scheduled above it.  (hipcc sinks the MFMAs of a k-step below its last wait; pinning them between
+    // the waits with sched_barrier changed nothing: 0.952 vs 0.954 ms.)
 #define LOB_TR2(f, addr, OFF, HI)                                                                              \
     asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"                   \
                  : "=&v"(f##l), "=&v"(f##h) : "v"(addr), "n"(OFF), "n"((OFF) + (HI)) : "memory")

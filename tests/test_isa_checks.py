@@ -13,3 +13,9 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 def test_dma_bptt_kernel_isa_has_no_queue_drains_and_no_early_register_use():
     import isa_check
     assert isa_check.main() == []
+
+
+@pytest.mark.skipif(not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")), reason="needs hipcc")
+def test_dma_weight_gradient_gemms_keep_their_ring_in_flight():
+    import isa_check
+    assert isa_check.check_dma_gemms() == []

@@ -35,3 +35,21 @@ for (T, Bp, nx, D) in [(5, 32, 256, 2), (3, 64, 128, 2), (40, 96, 256, 2)]:
             # is the wrong value equal to the product WITHOUT the exclusion / with another shift?
             alt = a.T @ y
             print("   matches unshifted product:", (dwhh[d].double() - alt).abs()[32 * i:32 * i + 32, 32 * j:32 * j + 32].max().item())
+
+# ---- timing at the step's size
+T, Bp, D = 256, 4096, 2
+for nx in (256, 128):
+    bf = torch.bfloat16
+    dP = (torch.randn((T * Bp, D * 4 * H), device=dev) * 0.1).to(bf)
+    X = torch.randn((T * Bp, nx), device=dev).to(bf)
+    Y = torch.randn((T * Bp, D * H), device=dev).to(bf)
+    for _ in range(3):
+        ops.lstm_dw(dP, X, Y, T, Bp, H, D)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        ops.lstm_dw(dP, X, Y, T, Bp, H, D)
+    e1.record()
+    torch.cuda.synchronize()
+    print("lstm_dw nx=%d: %.3f ms" % (nx, e0.elapsed_time(e1) / 10))

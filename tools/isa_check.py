@@ -32,6 +32,36 @@ def compile_to_isa(path=None):
     return out
 
 
+def check_dma_gemms(path=None):
+    """The LDS-DMA TN GEMMs (gemm_tn_dma_kernel, lstm_dw_h128_kernel in gemm_bf16.hip) read their ring through inline
+    asm because hipcc puts `s_waitcnt vmcnt(0)` in front of every compiler-visible ds_read_b64_tr_b16 of a DMA target
+    (that wait covers the DMA issued a moment earlier: the ring degenerates to one tile in flight).  Check that no
+    compiler-generated vmcnt(0) and no scratch traffic is left in those kernels."""
+    src = os.path.join(ROOT, "lstm_ode_bci_amd", "csrc", "gemm_bf16.hip")
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    out = path or os.path.join(tempfile.mkdtemp(prefix="lob_isa_"), "gemm.s")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"),
+                    "-I", os.path.dirname(src), "-S", "--cuda-device-only", src, "-o", out],
+                   check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    lines = open(out).read().split("\n")
+    problems = []
+    for pat in ("gemm_tn_dma_kernelILi256ELi256E", "lstm_dw_h128_kernelILi256E", "lstm_dw_h128_kernelILi128E"):
+        body = _function(lines, pat)
+        in_asm = False
+        for i, l in enumerate(body):
+            if "#ASMSTART" in l:
+                in_asm = True
+            elif "#ASMEND" in l:
+                in_asm = False
+            elif not in_asm and "s_waitcnt" in l and "vmcnt(0)" in l:
+                problems.append(f"{pat}: compiler-generated vmcnt(0) at line {i}")
+            elif "scratch_" in l:
+                problems.append(f"{pat}: scratch access at line {i}")
+        if not any("global_load_lds" in l for l in body):
+            problems.append(f"{pat}: no LDS-DMA found (kernel changed?)")
+    return problems
+
+
 def _function(lines, pat):
     st = next(i for i, l in enumerate(lines) if re.match(r"^_ZN.*" + pat + r".*:", l))
     end = next(i for i in range(st + 1, len(lines)) if lines[i].startswith(".Lfunc_end"))
