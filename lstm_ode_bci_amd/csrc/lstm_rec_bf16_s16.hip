@@ -20,6 +20,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int H = 128;
+constexpr int YF_LD = 132;     // fp32 h staging row stride in floats (528 B = 33 x 16 B)
 constexpr int HB_LD = 136;     // h tile row stride in bf16 (272 B = 17 x 16 B, odd -> conflict-free b128)
 constexpr int DGB_LD = 520;    // dgates tile row stride in bf16 (1040 B = 65 x 16 B)
 
@@ -80,6 +81,9 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_fwd_h128_bf16_s16_kernel(
     float* __restrict__ Csave, __bf16* __restrict__ Y16p, __bf16* __restrict__ Yd, float drop_p, uint64_t seed,
     int T, int Bp) {
     __shared__ __attribute__((aligned(16))) __bf16 hs[2 * 16 * HB_LD];
+    // fp32 h of the step (last layer only), staged so that it leaves as 32-B-per-lane row segments instead of eight
+    // 4-byte stores per lane; double-buffered like hs (one barrier per step)
+    __shared__ __attribute__((aligned(16))) float yfs[YF32 ? 2 * 16 * YF_LD : 4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int d = blockIdx.y, D = gridDim.y, NBT = Bp >> 5;
@@ -112,7 +116,6 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_fwd_h128_bf16_s16_kernel(
     const unsigned lane_p = frag_lane<PE>(rq, c16);        // P / saved gates (storage type PE)
     const unsigned lane_c = frag_lane<float>(rq, c16);     // c (always fp32)
     const int DH = D * H;
-    const unsigned y_off = (unsigned)(4 * rq * DH + c16);
     const int t_first = d ? T - 1 : 0, dt = d ? -1 : 1;
     const int row0 = bt * 32 + s0 * 16;
 
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_fwd_h128_bf16_s16_kernel(
                 for (int cbu = 0; cbu < 2; ++cbu) acc[g][cbu] = mfma16_bf16(a, wr[g][cbu][ks], acc[g][cbu]);
         }
         __bf16* hnext = hs + (cur ^ 1) * 16 * HB_LD + 4 * rq * HB_LD + 32 * w + c16;
-        float* yrow = Y + ((size_t)t * Bp + row0) * DH + d * H + 32 * w;
+        float* ynext = yfs + (YF32 ? (cur ^ 1) * 16 * YF_LD + 4 * rq * YF_LD + 32 * w + c16 : 0);
 #pragma unroll
         for (int cbu = 0; cbu < 2; ++cbu)
 #pragma unroll
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_fwd_h128_bf16_s16_kernel(
                 c[cbu][j] = fg * c[cbu][j] + ig * gg;
                 const float h = og * fast_tanh(c[cbu][j]);
                 hnext[j * HB_LD + 16 * cbu] = (__bf16)h;
-                if (YF32) (yrow + (size_t)j * DH + 16 * cbu)[y_off] = h;
+                if (YF32) ynext[j * YF_LD + 16 * cbu] = h;
                 if (SAVE) { acc[0][cbu][j] = ig; acc[1][cbu][j] = fg; acc[2][cbu][j] = gg; acc[3][cbu][j] = og; }
             }
         if (SAVE) {
@@ -167,6 +170,13 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_fwd_h128_bf16_s16_kernel(
             }
         }
         __syncthreads();
+        if (YF32) {
+            const int row = tid >> 4, c8 = (tid & 15) * 8;
+            const float* ysrc = yfs + (cur ^ 1) * 16 * YF_LD + row * YF_LD + c8;
+            float* dst = Y + ((size_t)t * Bp + row0 + row) * DH + d * H + c8;
+            *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(ysrc);
+            *reinterpret_cast<f32x4*>(dst + 4) = *reinterpret_cast<const f32x4*>(ysrc + 4);
+        }
         if (Y16 || DROP) {       // h_t is complete in hs[cur ^ 1]: emit the bf16 row segments (16 rows x 256 B)
             const __bf16* hsrc = hs + (cur ^ 1) * 16 * HB_LD;
             const int row = tid >> 4, c8 = (tid & 15) * 8;
