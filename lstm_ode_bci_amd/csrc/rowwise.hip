@@ -1,5 +1,6 @@
 // HBM-bound row-wise pieces of the forward pass: LayerNorm(+GELU+dropout, + the
 // (b,t)->(t,b) relayout), additive-attention pooling over time, row softmax.
+#include <stdlib.h>
 #include "lob_common.h"
 
 namespace {
@@ -263,19 +264,34 @@ __device__ __forceinline__ bool tiled_row(int g, int T, int B, int Bp, int& row,
 }
 __device__ __forceinline__ int tiled_count(int T, int B) { return ((B + 7) >> 3) * ((T + 7) >> 3) * 64; }
 
-template <int VPL, bool OUT_BF16>
+// LPR = lanes per row: 64 (one row per wave pass) or 16 (four rows per pass, VPL = 8: width 128 then moves 32 B per
+// lane in and 16 B of bf16 out, instead of 8 B / 4 B with 64 lanes on the row).
+template <int LPR>
+__device__ __forceinline__ float row_sum(float v) {
+    if (LPR == 64) return wave_sum(v);
+#define LOB_DPP_ADD(CTRL)                                                                                   \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false))
+    LOB_DPP_ADD(0xB1);       // quad_perm [1,0,3,2]
+    LOB_DPP_ADD(0x4E);       // quad_perm [2,3,0,1]
+    LOB_DPP_ADD(0x141);      // row_half_mirror
+    LOB_DPP_ADD(0x140);      // row_mirror: every lane of the 16-lane row now holds the row's sum
+#undef LOB_DPP_ADD
+    return v;
+}
+
+template <int VPL, bool OUT_BF16, int LPR = 64>
 __global__ __launch_bounds__(256) void layernorm_act_vec_kernel(
     const float* __restrict__ in, const float* __restrict__ gamma, const float* __restrict__ beta,
     void* __restrict__ outv, int rows, float eps, int act,
     int remap_T, int remap_B, int remap_Bp, float drop_p, uint64_t seed) {
-    constexpr int width = 64 * VPL;
-    const int lane = threadIdx.x & 63;
+    constexpr int width = LPR * VPL, GPW = 64 / LPR;       // GPW rows per wave pass
+    const int lane = threadIdx.x & 63, sub = lane / LPR, sl = lane % LPR;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     float gm[VPL], bt[VPL];
     const bool norm = !(act & LOB_LN_IDENTITY);
     act &= 0xff;
-    if (norm) { ldv<VPL>(gamma + lane * VPL, gm); ldv<VPL>(beta + lane * VPL, bt); }
+    if (norm) { ldv<VPL>(gamma + sl * VPL, gm); ldv<VPL>(beta + sl * VPL, bt); }
     else {
 #pragma unroll
         for (int i = 0; i < VPL; ++i) { gm[i] = 1.f; bt[i] = 0.f; }
@@ -285,16 +301,16 @@ __global__ __launch_bounds__(256) void layernorm_act_vec_kernel(
     // RPW rows per wave in flight: with one 512-B / 1-KB row per wave the CU has too few bytes outstanding to cover the
     // HBM latency (measured 2.1 TB/s at width 128 against 4.6 at width 256 with the same code)
     constexpr int RPW = VPL <= 2 ? 4 : 2;
-    for (int g0 = wave * RPW; g0 < count; g0 += nwaves * RPW) {
+    for (int g0 = wave * RPW * GPW; g0 < count; g0 += nwaves * RPW * GPW) {
         float vv[RPW][VPL];
         int rowv[RPW], orowv[RPW];
         bool ok[RPW];
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
-            const int g = g0 + r;
+            const int g = g0 + r * GPW + sub;
             rowv[r] = g; orowv[r] = g;
             ok[r] = g < count && (remap_T <= 0 || tiled_row(g, remap_T, remap_B, remap_Bp, rowv[r], orowv[r]));
-            if (ok[r]) ldv<VPL>(in + (size_t)rowv[r] * width + lane * VPL, vv[r]);
+            if (ok[r]) ldv<VPL>(in + (size_t)rowv[r] * width + sl * VPL, vv[r]);
         }
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
@@ -304,15 +320,15 @@ __global__ __launch_bounds__(256) void layernorm_act_vec_kernel(
             float s = 0.f;
 #pragma unroll
             for (int i = 0; i < VPL; ++i) s += v[i];
-            const float mean = norm ? wave_sum(s) * invw : 0.f;
+            const float mean = norm ? row_sum<LPR>(s) * invw : 0.f;
             float q = 0.f;
 #pragma unroll
             for (int i = 0; i < VPL; ++i) { const float dl = v[i] - mean; q += dl * dl; }
-            const float rstd = norm ? rsqrtf(wave_sum(q) * invw + eps) : 1.f;
+            const float rstd = norm ? rsqrtf(row_sum<LPR>(q) * invw + eps) : 1.f;
             float ds[VPL];              // dropout scales: one hash per pair of neighbouring columns
 #pragma unroll
             for (int i = 0; i < VPL; i += 2) {
-                if (drop_p > 0.f) lob_dropout_scale2(seed, (uint64_t)orow * width + lane * VPL + i, drop_p, ds[i], ds[i + 1]);
+                if (drop_p > 0.f) lob_dropout_scale2(seed, (uint64_t)orow * width + sl * VPL + i, drop_p, ds[i], ds[i + 1]);
                 else { ds[i] = 1.f; ds[i + 1] = 1.f; }
             }
 #pragma unroll
@@ -320,45 +336,53 @@ __global__ __launch_bounds__(256) void layernorm_act_vec_kernel(
                 float o = (v[i] - mean) * rstd * gm[i] + bt[i];
                 v[i] = apply_act(o, act) * ds[i];
             }
-            if (OUT_BF16) stv_bf16<VPL>(reinterpret_cast<__bf16*>(outv) + (size_t)orow * width + lane * VPL, v);
-            else          stv<VPL>(reinterpret_cast<float*>(outv) + (size_t)orow * width + lane * VPL, v);
+            if (OUT_BF16) stv_bf16<VPL>(reinterpret_cast<__bf16*>(outv) + (size_t)orow * width + sl * VPL, v);
+            else          stv<VPL>(reinterpret_cast<float*>(outv) + (size_t)orow * width + sl * VPL, v);
         }
     }
 }
 
-template <int VPL>
+template <int N, int W>
+__device__ __forceinline__ float red_sum(const float (&r)[N][W], int c) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < N; ++i) t += r[i][c];
+    return t;
+}
+
+template <int VPL, int LPR = 64>
 __global__ __launch_bounds__(256) void layernorm_act_bwd_vec_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
     int rows, float eps, int act, int remap_T, int remap_B, int remap_Bp, float drop_p, uint64_t seed,
     const float* __restrict__ pool_attn, const float* __restrict__ pool_dctx, int pool_T, int pool_B, int pool_Bp,
     float* __restrict__ dx_colsum) {
-    constexpr int width = 64 * VPL;
-    __shared__ float red[2][4][width];
-    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    constexpr int width = LPR * VPL, GPW = 64 / LPR, NRED = 4 * GPW;
+    __shared__ float red[2][NRED][width];
+    const int lane = threadIdx.x & 63, sub = lane / LPR, sl = lane % LPR, wib = (threadIdx.x >> 6) * GPW + sub;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     float gm[VPL], bt[VPL], dga[VPL], dba[VPL], dxs[VPL];
     const bool norm = !(act & LOB_LN_IDENTITY);
     act &= 0xff;
-    if (norm) { ldv<VPL>(gamma + lane * VPL, gm); ldv<VPL>(beta + lane * VPL, bt); }
+    if (norm) { ldv<VPL>(gamma + sl * VPL, gm); ldv<VPL>(beta + sl * VPL, bt); }
 #pragma unroll
     for (int i = 0; i < VPL; ++i) { dga[i] = 0.f; dba[i] = 0.f; dxs[i] = 0.f; if (!norm) { gm[i] = 1.f; bt[i] = 0.f; } }
     const float invw = 1.0f / (float)width;
     const int count = remap_T > 0 ? tiled_count(remap_T, remap_B) : rows;
     constexpr int RPW = VPL <= 2 ? 4 : 2;       // rows per wave in flight (see the forward kernel)
-    for (int g0 = wave * RPW; g0 < count; g0 += nwaves * RPW) {
+    for (int g0 = wave * RPW * GPW; g0 < count; g0 += nwaves * RPW * GPW) {
         float vv[RPW][VPL], gov[RPW][VPL];
         int rowv[RPW], orowv[RPW];
         bool ok[RPW];
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
-            const int g = g0 + r;
+            const int g = g0 + r * GPW + sub;
             rowv[r] = g; orowv[r] = g;
             ok[r] = g < count && (remap_T <= 0 || tiled_row(g, remap_T, remap_B, remap_Bp, rowv[r], orowv[r]));
             if (ok[r]) {
-                ldv<VPL>(x + (size_t)rowv[r] * width + lane * VPL, vv[r]);
-                ldv<VPL>(dy + (size_t)orowv[r] * width + lane * VPL, gov[r]);
+                ldv<VPL>(x + (size_t)rowv[r] * width + sl * VPL, vv[r]);
+                ldv<VPL>(dy + (size_t)orowv[r] * width + sl * VPL, gov[r]);
             }
         }
 #pragma unroll
@@ -372,7 +396,7 @@ __global__ __launch_bounds__(256) void layernorm_act_bwd_vec_kernel(
                 if (b < pool_B) {
                     const float a = pool_attn[(size_t)b * pool_T + t];
                     float dcv[VPL];
-                    ldv<VPL>(pool_dctx + (size_t)b * width + lane * VPL, dcv);
+                    ldv<VPL>(pool_dctx + (size_t)b * width + sl * VPL, dcv);
 #pragma unroll
                     for (int i = 0; i < VPL; ++i) go[i] = fmaf(a, dcv[i], go[i]);
                 }
@@ -380,16 +404,16 @@ __global__ __launch_bounds__(256) void layernorm_act_bwd_vec_kernel(
             float s = 0.f;
 #pragma unroll
             for (int i = 0; i < VPL; ++i) s += v[i];
-            const float mean = norm ? wave_sum(s) * invw : 0.f;
+            const float mean = norm ? row_sum<LPR>(s) * invw : 0.f;
             float q = 0.f;
 #pragma unroll
             for (int i = 0; i < VPL; ++i) { const float dl = v[i] - mean; q += dl * dl; }
-            const float rstd = norm ? rsqrtf(wave_sum(q) * invw + eps) : 1.f;
+            const float rstd = norm ? rsqrtf(row_sum<LPR>(q) * invw + eps) : 1.f;
             float m1 = 0.f, m2 = 0.f;
             float ds[VPL];
 #pragma unroll
             for (int i = 0; i < VPL; i += 2) {
-                if (drop_p > 0.f) lob_dropout_scale2(seed, (uint64_t)orow * width + lane * VPL + i, drop_p, ds[i], ds[i + 1]);
+                if (drop_p > 0.f) lob_dropout_scale2(seed, (uint64_t)orow * width + sl * VPL + i, drop_p, ds[i], ds[i + 1]);
                 else { ds[i] = 1.f; ds[i + 1] = 1.f; }
             }
 #pragma unroll
@@ -403,30 +427,30 @@ __global__ __launch_bounds__(256) void layernorm_act_bwd_vec_kernel(
                 v[i] = xh; go[i] = dxh;
                 m1 += dxh; m2 += dxh * xh;
             }
-            m1 = norm ? wave_sum(m1) * invw : 0.f;
-            m2 = norm ? wave_sum(m2) * invw : 0.f;
+            m1 = norm ? row_sum<LPR>(m1) * invw : 0.f;
+            m2 = norm ? row_sum<LPR>(m2) * invw : 0.f;
 #pragma unroll
             for (int i = 0; i < VPL; ++i) { v[i] = rstd * (go[i] - m1 - v[i] * m2); dxs[i] += v[i]; }
-            stv<VPL>(dx + (size_t)row * width + lane * VPL, v);
+            stv<VPL>(dx + (size_t)row * width + sl * VPL, v);
         }
     }
     if (dx_colsum) {      // column sums of dx = the bias gradient of the Linear that feeds this LayerNorm (04:174-175)
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) red[0][wib][lane * VPL + i] = dxs[i];
+        for (int i = 0; i < VPL; ++i) red[0][wib][sl * VPL + i] = dxs[i];
         __syncthreads();
         for (int c = threadIdx.x; c < width; c += 256)
-            atomicAdd(dx_colsum + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+            atomicAdd(dx_colsum + c, red_sum<NRED, width>(red[0], c));
         __syncthreads();
     }
     // block-level reduction of the affine gradients, then ONE atomic per column per block
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) { red[0][wib][lane * VPL + i] = dga[i]; red[1][wib][lane * VPL + i] = dba[i]; }
+    for (int i = 0; i < VPL; ++i) { red[0][wib][sl * VPL + i] = dga[i]; red[1][wib][sl * VPL + i] = dba[i]; }
     __syncthreads();
     if (!norm) return;
     for (int c = threadIdx.x; c < width; c += 256) {
-        atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
-        atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+        atomicAdd(dgamma + c, red_sum<NRED, width>(red[0], c));
+        atomicAdd(dbeta + c, red_sum<NRED, width>(red[1], c));
     }
 }
 
@@ -622,6 +646,12 @@ extern "C" int lob_dropout_f32(const float* in, float* out, int64_t n, float p, 
     return 0;
 }
 
+// width 128: 16 lanes per row (LOB_LN_LPR=64 selects the one-row-per-wave form)
+static bool ln_lpr16() {
+    static const bool v = [] { const char* e = getenv("LOB_LN_LPR"); return !(e && atoi(e) == 64); }();
+    return v;
+}
+
 extern "C" int lob_layernorm_act_f32(const float* in, const float* gamma, const float* beta,
                                      void* out, int out_bf16, int rows, int width, float eps, int act,
                                      int remap_T, int remap_B, int remap_Bp,
@@ -640,7 +670,16 @@ extern "C" int lob_layernorm_act_f32(const float* in, const float* gamma, const 
         (hipStream_t)stream, in, gamma, beta, out, rows, eps, act, remap_T, remap_B, remap_Bp, drop_p, seed); \
     else hipLaunchKernelGGL((layernorm_act_vec_kernel<V, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, \
         in, gamma, beta, out, rows, eps, act, remap_T, remap_B, remap_Bp, drop_p, seed); } while (0)
-    if (al && width == 128) LOB_LN_VEC(2);
+    if (al && width == 128 && ln_lpr16()) {
+        // four rows per wave pass: a pass covers 4 rows, RPW = 2 passes in flight
+        blocks = (rows + 31) / 32;
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        if (out_bf16) hipLaunchKernelGGL((layernorm_act_vec_kernel<8, true, 16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                                         in, gamma, beta, out, rows, eps, act, remap_T, remap_B, remap_Bp, drop_p, seed);
+        else hipLaunchKernelGGL((layernorm_act_vec_kernel<8, false, 16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                                in, gamma, beta, out, rows, eps, act, remap_T, remap_B, remap_Bp, drop_p, seed);
+    }
+    else if (al && width == 128) LOB_LN_VEC(2);
     else if (al && width == 256) LOB_LN_VEC(4);
     else if (al && width == 512) LOB_LN_VEC(8);
     else {
@@ -723,7 +762,14 @@ extern "C" int lob_layernorm_act_bwd_f32(const float* x, const float* gamma, con
                        x, gamma, beta, dy, dx, dgamma, dbeta, rows, eps, act, remap_T, remap_B, remap_Bp, drop_p, seed, \
                        pool_attn, pool_dctx, pool_T, pool_B, pool_Bp, dx_colsum)
         if (pool_attn && (!pool_dctx || pool_T <= 0 || pool_Bp <= 0 || rows != pool_T * pool_Bp || remap_T)) return LOB_E_SHAPE;
-        if (width == 128) LOB_LNB_VEC(2); else if (width == 256) LOB_LNB_VEC(4); else LOB_LNB_VEC(8);
+        if (width == 128 && ln_lpr16()) {
+            blocks = (rows + 31) / 32;
+            if (blocks > 256 * 8) blocks = 256 * 8;
+            hipLaunchKernelGGL((layernorm_act_bwd_vec_kernel<8, 16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                               x, gamma, beta, dy, dx, dgamma, dbeta, rows, eps, act, remap_T, remap_B, remap_Bp, drop_p, seed,
+                               pool_attn, pool_dctx, pool_T, pool_B, pool_Bp, dx_colsum);
+        }
+        else if (width == 128) LOB_LNB_VEC(2); else if (width == 256) LOB_LNB_VEC(4); else LOB_LNB_VEC(8);
 #undef LOB_LNB_VEC
         LOB_CHECK_LAUNCH();
         return 0;
