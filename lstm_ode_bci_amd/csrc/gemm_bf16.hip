@@ -281,17 +281,23 @@ __device__ __forceinline__ void dma_rows8(const __bf16* G, int ld, int row0, int
 // algorithmic bytes and, not HBM, set the rate.
 // NDS = ring depth, BIASF = floats of the bias image.  <256,128,3,1024>: 76 KB of LDS -> TWO workgroups per CU, so
 // one workgroup's epilogue (stores at HBM rate) overlaps the other's main loop.
-template <int EPI, int BTM, int BTN, int NDS = DS, int BIASF = 2048, int KT = DTK>
+// ADEEP: the A operand (the one that comes from HBM: dP in the dX GEMMs) gets a ring one slot deeper than W's and
+// runs one k-tile further ahead -- with 64-wide slots only one (A, W) pair fits in flight otherwise, i.e. 32 KB of HBM
+// reads per CU.  3 x 32 KB of A + 2 x 32 KB of W is all 160 KB of LDS: no bias image (BIASF = 0), so no-bias GEMMs only.
+template <int EPI, int BTM, int BTN, int NDS = DS, int BIASF = 2048, int KT = DTK, bool ADEEP = false>
 __global__ __launch_bounds__((BTM / 64) * (BTN / 64) * 64, (BTM * BTN > 128 * 128) ? 4 : 2)
 void gemm_nt_dma_kernel(NTArgs g) {
     constexpr int WR = BTM / 64, WC = BTN / 64, NWV = WR * WC, NTHR = NWV * 64;
     constexpr int RPI = KT == 32 ? 16 : 8;                        // rows per 1-KB DMA instruction
     constexpr int NA = BTM / RPI / NWV, NB = BTN / RPI / NWV;     // 1-KB DMA instructions per wave per k-tile
-    constexpr int ASLOT = BTM * KT, WSLOT = BTN * KT, SLOT = ASLOT + WSLOT;
-    constexpr int VM_STEADY = (NDS - 2) * (NA + NB), VM_EPI = VM_STEADY + 16;   // (bf16 P: 8 stores; 16 covers fp32 P)
+    constexpr int ASLOT = BTM * KT, WSLOT = BTN * KT;
+    constexpr int NAS = ADEEP ? NDS + 1 : NDS;                    // A ring slots
+    constexpr int VM_STEADY = (NDS - 2) * (NA + NB) + (ADEEP ? NA : 0), VM_EPI = VM_STEADY + 16;   // (bf16 P: 8 stores; 16 covers fp32 P)
     static_assert(NA >= 1 && NB >= 1 && VM_EPI < 64, "tile / wave configuration");
-    __shared__ __attribute__((aligned(1024))) __bf16 ring[NDS * SLOT + 2 * BIASF];     // ring + bias image
-    float* bias_s = reinterpret_cast<float*>(ring + NDS * SLOT);
+    static_assert(!ADEEP || (NDS == 2 && BIASF == 0 && EPI == 0), "deep-A variant: two W slots, no bias image");
+    __shared__ __attribute__((aligned(1024))) __bf16 ring[NAS * ASLOT + NDS * WSLOT + 2 * BIASF];     // A ring, W ring, bias image
+    __bf16* wring = ring + NAS * ASLOT;
+    float* bias_s = reinterpret_cast<float*>(wring + NDS * WSLOT);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WC, wc = wave % WC;
@@ -304,7 +310,7 @@ void gemm_nt_dma_kernel(NTArgs g) {
     if (slot >= ntile) return;
     const int my_tiles = (ntile - slot + nslot - 1) / nslot;
     const int total = my_tiles * nk;
-    {       // bias via LDS: an ordinary global load inside the loop would make hipcc drain the DMA queue
+    if (BIASF > 0) {       // bias via LDS: an ordinary global load inside the loop would make hipcc drain the DMA queue
         for (int i = tid; i < g.N && i < BIASF; i += NTHR) bias_s[i] = g.bias ? g.bias[i] : 0.f;
         __syncthreads();
     }
@@ -312,29 +318,40 @@ void gemm_nt_dma_kernel(NTArgs g) {
     // workgroups' epilogues are not what synchronises them -- the epilogue cost is store issue, see there).
     for (int i = ((blockIdx.x >> 3) & 7) * g.stagger; i > 0; --i) __builtin_amdgcn_s_sleep(32);
 
-    // producer cursor (runs DS-1 k-tiles ahead of the consumer, across tile boundaries)
-    int p_q = 0, p_it = slot, p_kt = 0;
-    auto issue = [&]() {
-        const int m0 = ((p_it / ntn) * 8 + xcd) * BTM, n0 = (p_it % ntn) * BTN;
-        __bf16* as = ring + (p_q % NDS) * SLOT;
-        __bf16* ws = as + ASLOT;
+    // producer cursors (W runs NDS-1 k-tiles ahead of the consumer, A one more with ADEEP; across tile boundaries)
+    int pa_q = 0, pa_it = slot, pa_kt = 0, pw_q = 0, pw_it = slot, pw_kt = 0;
+    auto issueA = [&]() {
+        const int m0 = ((pa_it / ntn) * 8 + xcd) * BTM;
+        __bf16* as = ring + (pa_q % NAS) * ASLOT;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const int rb = (wave * NA + j) * RPI;
-            if constexpr (KT == 32) dma_rows16(A, g.lda, m0 + rb, g.M, p_kt * KT, as + rb * KT, lane);
-            else                    dma_rows8(A, g.lda, m0 + rb, g.M, p_kt * KT, as + rb * KT, lane);
+            if constexpr (KT == 32) dma_rows16(A, g.lda, m0 + rb, g.M, pa_kt * KT, as + rb * KT, lane);
+            else                    dma_rows8(A, g.lda, m0 + rb, g.M, pa_kt * KT, as + rb * KT, lane);
         }
+        ++pa_q;
+        if (++pa_kt == nk) { pa_kt = 0; pa_it += nslot; }
+    };
+    auto issueW = [&]() {
+        const int n0 = (pw_it % ntn) * BTN;
+        __bf16* ws = wring + (pw_q % NDS) * WSLOT;
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const int rb = (wave * NB + j) * RPI;
-            if constexpr (KT == 32) dma_rows16(W, g.ldw, n0 + rb, g.N, p_kt * KT, ws + rb * KT, lane);
-            else                    dma_rows8(W, g.ldw, n0 + rb, g.N, p_kt * KT, ws + rb * KT, lane);
+            if constexpr (KT == 32) dma_rows16(W, g.ldw, n0 + rb, g.N, pw_kt * KT, ws + rb * KT, lane);
+            else                    dma_rows8(W, g.ldw, n0 + rb, g.N, pw_kt * KT, ws + rb * KT, lane);
         }
-        ++p_q;
-        if (++p_kt == nk) { p_kt = 0; p_it += nslot; }
+        ++pw_q;
+        if (++pw_kt == nk) { pw_kt = 0; pw_it += nslot; }
     };
+    if (ADEEP) {            // issue order A(0) W(0) A(1): every wait below leaves exactly the youngest A tile in flight
+        issueA();
+        issueW();
+        if (total > 1) issueA();
+    } else {
 #pragma unroll 1
-    for (int i = 0; i < NDS - 1 && i < total; ++i) issue();
+        for (int i = 0; i < NDS - 1 && i < total; ++i) { issueA(); issueW(); }
+    }
 
     int it = slot, kt = 0, since_epi = 99;
     f32x16 acc[2][2];
@@ -348,7 +365,7 @@ void gemm_nt_dma_kernel(NTArgs g) {
     for (int q = 0; q < total; ++q) {
         // ---- wait for slot q: all but the younger operations of THIS wave may still be in flight:
         //      (DS-2) k-tiles x (NA+NB) DMAs, plus the 16 epilogue stores if they were issued after DMA(q)
-        if (q + NDS - 1 > total) {
+        if (q + NDS - 1 + (ADEEP ? 1 : 0) > total) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else if (EPI == 1 && since_epi < NDS - 1) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_EPI) : "memory");
@@ -358,11 +375,17 @@ void gemm_nt_dma_kernel(NTArgs g) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_STEADY) : "memory");
         }
         __builtin_amdgcn_s_barrier();
-        if (p_q < total) issue();                       // refills the slot read in iteration q-1
+        if (ADEEP) {                                    // W(q+1) first, then A(q+2): the next wait counts past the A tile
+            if (pw_q < total) issueW();
+            if (pa_q < total) issueA();
+        } else if (pa_q < total) {                      // refills the slots read in iteration q-1
+            issueA();
+            issueW();
+        }
         ++since_epi;
 
-        const __bf16* as = ring + (q % NDS) * SLOT;
-        const __bf16* ws = as + ASLOT;
+        const __bf16* as = ring + (q % NAS) * ASLOT;
+        const __bf16* ws = wring + (q % NDS) * WSLOT;
         const int r31 = lane & 31, hi = lane >> 5, sw = KT == 32 ? (r31 >> 2) & 3 : (r31 >> 1) & 7;
 #pragma unroll
         for (int s = 0; s < KT / 16; ++s) {
@@ -389,7 +412,7 @@ void gemm_nt_dma_kernel(NTArgs g) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int col = cn0 + 64 * wc + 32 * j + (lane & 31);
-                    const float bv = lds_read_f32_opaque(bias_s + (col < BIASF ? col : 0));
+                    const float bv = BIASF > 0 ? lds_read_f32_opaque(bias_s + (col < BIASF ? col : 0)) : 0.f;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = cm0 + 64 * wr + 32 * i + acc_row(r, lane);
@@ -987,7 +1010,13 @@ inline void launch_nt_dma(const NTArgs& g_, hipStream_t s) {
     // 64-wide k-slots (two of them) by default: every DMA instruction fetches whole cache lines.  Measured against
     // four 32-wide slots (half a line per row per k-tile): gate GEMM K=256 0.96 -> 0.92 ms, dX N=256 0.84 -> 0.77 ms.
     static const int kt64 = [] { const char* e = getenv("LOB_DMA_KT"); return e ? atoi(e) : 64; }();
-    if (kt64 == 64 && g.N % 256 == 0 && g.K % 64 == 0 && g.K / 64 >= 2)
+    static const bool adeep = [] { const char* e = getenv("LOB_NT_ADEEP"); return !(e && atoi(e) == 0); }();
+    if (EPI == 0 && adeep && kt64 == 64 && !g.bias && g.N % 256 == 0 && g.K % 64 == 0 && g.K / 64 >= 3) {
+        // no bias (dX = dP W_ih, dV = dU W1): deeper ring for the operand that comes from HBM
+        if constexpr (EPI == 0)
+            hipLaunchKernelGGL((gemm_nt_dma_kernel<0, 256, 256, 2, 0, 64, true>), dim3((unsigned)nt_dma_grid(g.M, g.N, 256)), dim3(1024), 0, s, g);
+    }
+    else if (kt64 == 64 && g.N % 256 == 0 && g.K % 64 == 0 && g.K / 64 >= 2)
         hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI, 256, 256, 2, 2048, 64>), dim3((unsigned)nt_dma_grid(g.M, g.N, 256)), dim3(1024), 0, s, g);
     else if (nt_dma_tile() == 2 && two_wg)
         launch_2wg();
