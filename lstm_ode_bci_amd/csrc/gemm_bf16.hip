@@ -292,7 +292,10 @@ void gemm_nt_dma_kernel(NTArgs g) {
     constexpr int NA = BTM / RPI / NWV, NB = BTN / RPI / NWV;     // 1-KB DMA instructions per wave per k-tile
     constexpr int ASLOT = BTM * KT, WSLOT = BTN * KT;
     constexpr int NAS = ADEEP ? NDS + 1 : NDS;                    // A ring slots
-    constexpr int VM_STEADY = (NDS - 2) * (NA + NB) + (ADEEP ? NA : 0), VM_EPI = VM_STEADY + 16;   // (bf16 P: 8 stores; 16 covers fp32 P)
+    constexpr int VM_STEADY = (NDS - 2) * (NA + NB) + (ADEEP ? NA : 0), VM_EPI = VM_STEADY + 8;
+    // VM_EPI: the wait right after an epilogue may leave only operations YOUNGER than the awaited DMA in flight, i.e. the
+    // epilogue's stores: 8 per wave with bf16 P (16-B fragment stores), 16 with fp32 P -- the smaller count is safe for both
+    // (a larger one would let the wait pass with the awaited DMA itself still outstanding)
     static_assert(NA >= 1 && NB >= 1 && VM_EPI < 64, "tile / wave configuration");
     static_assert(!ADEEP || (NDS == 2 && BIASF == 0 && EPI == 0), "deep-A variant: two W slots, no bias image");
     __shared__ __attribute__((aligned(1024))) __bf16 ring[NAS * ASLOT + NDS * WSLOT + 2 * BIASF];     // A ring, W ring, bias image
