@@ -390,7 +390,8 @@ def test_mixed_h256_train_mode_is_reproducible_and_finite(dev):
     assert (outs[0][2] - outs[1][2]).abs().max().item() <= 1e-5 * outs[0][2].abs().max().item()
 
 
-@pytest.mark.parametrize("T,Bp,nx,D", [(5, 32, 256, 2), (3, 64, 128, 2), (40, 96, 256, 2), (2, 32, 128, 1), (7, 4096, 256, 2)])
+@pytest.mark.parametrize("T,Bp,nx,D", [(5, 32, 256, 2), (3, 64, 128, 2), (40, 96, 256, 2), (2, 32, 128, 1), (7, 4096, 256, 2),
+                                         (2, 32, 256, 1), (3, 8192, 128, 2), (256, 32, 256, 2)])
 def test_fused_layer_weight_gradients(dev, T, Bp, nx, D):
     """dW_ih and dW_hh of a layer from one pass over dP == the exact products of the same bf16 operands (fp64 here),
     including the time shift of h_prev (t-1 forward, t+1 reverse) and the step without a predecessor."""
