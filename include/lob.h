@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LOB_VERSION 100
+#define LOB_VERSION 200
 
 #define LOB_E_ARG   (-1)   /* null pointer / non-positive size                      */
 #define LOB_E_SHAPE (-2)   /* shape not supported by this kernel (see each entry)   */
@@ -41,6 +41,40 @@ extern "C" {
                                * 09_sensitivity_analysis.py:190,209); gamma/beta/dgamma/dbeta may be NULL */
 
 int lob_version(void);
+
+/* Identity of the build: a hash of every csrc source, this header and the compile flags, injected by
+ * lstm_ode_bci_amd/build.py (-DLOB_BUILD_ID).  The Python loader compares it with the hash of the sources it
+ * sees and refuses a stale library.                                                                      */
+const char* lob_build_id(void);
+
+/* ------------------------------------------------------------------------------------
+ * TEST-ONLY: kernel variants.  Several hot kernels have a slower twin that computes the same values by a
+ * simpler route (register-staged instead of LDS-DMA with hand-counted waits, the tiled GEMM instead of the
+ * weight-stationary one, ...).  The parity tests run both at the bench's full shapes and compare them
+ * (bit-exact where the arithmetic order is the same).  The table is process-global and read at every launch;
+ * each entry starts from the environment variable of the same name, else its default.  Product code never
+ * calls the setter.  lob_debug_set_variant returns the previous value, LOB_E_ARG for an unknown index.
+ * ---------------------------------------------------------------------------------- */
+#define LOB_VAR_REC_BWD_DMA   0  /* 1: BPTT (H=128, mixed) streams G/c by LDS-DMA; 0: register-prefetch twin      */
+#define LOB_VAR_NT_DMA        1  /* 1: bf16 TN (weight-gradient) GEMM on the LDS-DMA kernel; 0: register-staged    */
+#define LOB_VAR_DMA_TILE      2  /* NT LDS-DMA GEMM output tile: 256 (256x256), 2 (256x128 x 2 WGs/CU), 128        */
+#define LOB_VAR_DMA_KT        3  /* NT LDS-DMA GEMM k-slot width: 64 or 32                                        */
+#define LOB_VAR_NT_ADEEP      4  /* 1: deeper A ring for the no-bias NT GEMMs (dX)                                */
+#define LOB_VAR_GATE_WS       5  /* 1: weight-stationary gate GEMM (H=128, mixed); 0: tiled LDS-DMA NT GEMM         */
+#define LOB_VAR_REC_BF16_ROWS 6  /* 16 (two workgroups per CU) or 32: row tile of the H=128 bf16 recurrent kernels */
+#define LOB_VAR_F32_DMA       7  /* 1: fp32 NT GEMM on its LDS-DMA kernel; 0: register-staged                      */
+#define LOB_VAR_REC_FWD_ROWS  8  /* 16 or 32: row tile of the fp32 recurrent forward (H=128)                      */
+#define LOB_VAR_LN_LPR        9  /* 16: several rows per wave in the vectorised LayerNorm kernels; 64: one         */
+#define LOB_VAR_NT_WGS       10  /* persistent workgroups per CU of the register-staged bf16 NT GEMM               */
+#define LOB_VAR_NT_TK        11  /* its k-tile: 32 or 64                                                          */
+#define LOB_VAR_NT_STAGGER   12  /* start stagger of the NT LDS-DMA GEMM (units of s_sleep(32)); 0 = off           */
+#define LOB_VAR_FUSED_DW     13  /* read by the Python host: 1 = dW_ih and dW_hh from one pass (lob_lstm_dw_bf16)  */
+#define LOB_VAR_F32_SPLIT    14  /* 1: fp32 gate GEMMs as three-way bf16 splits on bf16 MFMA; 0: exact-fp32 MFMA   */
+#define LOB_VAR_REC_F32_HALF 15  /* 1: fp32 recurrent forward may split the gate columns over two workgroups       */
+#define LOB_VAR_H256_BWD     16  /* H=256 BPTT kernel shape: 1 = 64-row pairs sharing one weight stream, 0 = 32-row */
+#define LOB_VAR_COUNT        17
+int lob_debug_set_variant(int which, int value);
+int lob_debug_get_variant(int which);
 
 /* ------------------------------------------------------------------------------------
  * Dense layers.  C[M,N] = act(A[M,K] * W[N,K]^T + bias[N]); fp32 in, exact-fp32 MFMA

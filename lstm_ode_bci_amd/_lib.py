@@ -13,6 +13,9 @@ _lib = None
 _f32p = C.c_void_p
 _SIGS = {
     "lob_version": ([], C.c_int),
+    "lob_build_id": ([], C.c_char_p),
+    "lob_debug_set_variant": ([C.c_int, C.c_int], C.c_int),
+    "lob_debug_get_variant": ([C.c_int], C.c_int),
     "lob_lstm_uses_fragment_layout": ([C.c_int], C.c_int),
     "lob_gemm_nt_f32": ([_f32p, C.c_int, _f32p, C.c_int, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int,
                          C.c_int, C.c_void_p], C.c_int),
@@ -78,14 +81,55 @@ def lib():
                 f"{LIB_PATH} not found: the HIP extension is not built. "
                 "Run `python -m lstm_ode_bci_amd.build` (needs hipcc). There is no CPU fallback.")
         l = C.CDLL(LIB_PATH)
+        missing = [name for name in _SIGS if not hasattr(l, name)]
+        if missing:
+            raise LobError(f"{LIB_PATH} is stale: it does not export {missing}. Rebuild: python -m lstm_ode_bci_amd.build")
         for name, (args, res) in _SIGS.items():
-            if not hasattr(l, name):
-                continue          # declared in lob.h but not built yet -> caught by tests/test_abi.py
             fn = getattr(l, name)
             fn.argtypes = args
             fn.restype = res
+        _check_build_id(l)
         _lib = l
     return _lib
+
+
+def _check_build_id(l):
+    """A prebuilt library must come from the sources next to it: compare lob_build_id() with the hash of csrc/*.hip,
+    *.h, include/*.h and the compile flags (build.source_id).  LOB_LIB_PATH (A/B of two builds) and
+    LOB_SKIP_BUILD_ID=1 opt out."""
+    if os.environ.get("LOB_LIB_PATH") or os.environ.get("LOB_SKIP_BUILD_ID") == "1":
+        return
+    from . import build as _b
+    have = l.lob_build_id().decode()
+    want = _b.source_id()
+    if have != want:
+        raise LobError(f"{LIB_PATH} was built from other sources (build id {have}, sources hash to {want}). "
+                       "Rebuild: python -m lstm_ode_bci_amd.build --force")
+
+
+# kernel-variant switches (include/lob.h LOB_VAR_*): test-only
+VAR = {"REC_BWD_DMA": 0, "NT_DMA": 1, "DMA_TILE": 2, "DMA_KT": 3, "NT_ADEEP": 4, "GATE_WS": 5, "REC_BF16_ROWS": 6,
+       "F32_DMA": 7, "REC_FWD_ROWS": 8, "LN_LPR": 9, "NT_WGS": 10, "NT_TK": 11, "NT_STAGGER": 12, "FUSED_DW": 13,
+       "F32_SPLIT": 14, "REC_F32_HALF": 15, "H256_BWD": 16}
+
+
+def get_variant(name):
+    return lib().lob_debug_get_variant(VAR[name])
+
+
+class variant:
+    """with variant(REC_BWD_DMA=0): ...  -- run a block on a kernel twin (tests only)."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.old = {k: lib().lob_debug_set_variant(VAR[k], int(v)) for k, v in self.kw.items()}
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            lib().lob_debug_set_variant(VAR[k], v)
 
 
 _ERR = {-1: "LOB_E_ARG (null pointer / bad size)", -2: "LOB_E_SHAPE (unsupported shape)",

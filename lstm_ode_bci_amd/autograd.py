@@ -84,7 +84,8 @@ def _forward_impl(x, ps, cfg, save):
         # bf16 x bf16 operands (bf16 activations from the layer below + a bf16 copy of the weights) take
         # the LDS-DMA GEMM; everything else the register-staged kernels
         w_in = wih.to(torch.bfloat16) if (inp.dtype == torch.bfloat16 and frag and
-                                          ops.dma_ok(inp.shape[1], wih.shape[0], inp.shape[0])) else wih
+                                          (ops.gate_ws_ok(inp.shape[1], H) or
+                                           ops.dma_ok(inp.shape[1], wih.shape[0], inp.shape[0]))) else wih
         P = ops.gate_gemm_x(inp, w_in, bias, T, Bp, H, D, frag, mixed=mixed)
         last = layer + 1 == L
         drop_here = not last and p_lstm > 0

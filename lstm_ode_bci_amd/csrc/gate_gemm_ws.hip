@@ -1,0 +1,199 @@
+// Weight-stationary input-side gate GEMM for the mixed path at H = 128 (nn.LSTM's W_ih x_t + b_ih + b_hh,
+// 04_lstm_model.py:181-188, 211, under autocast 04:487):
+//     P[T*Bp, D*512] = X[T*Bp, K] * W_ih[D*512, K]^T + bias,   K = 128 (layer 0) or 256 (layers 1..),
+// bf16 operands, fp32 accumulate (v_mfma_f32_32x32x16_bf16), P written as bf16 in the accumulator-fragment order the
+// recurrent kernel consumes (lob.h).
+//
+// Why a second kernel next to gemm_nt_dma_kernel<1,256,256>: with K = 256 an output tile has only four 64-deep k-tiles,
+// and the tiled kernel re-stages the 128-KB W tile through L2 -> LDS for every 256 rows -- 6.3 GB cross L2 -> LDS for
+// 2.7 GB of HBM traffic, and that path (about 7 TB/s with one k-tile in flight), not HBM, set its 0.85-0.96 ms.  Here
+// the weights never move: a workgroup (8 waves) owns the 512 gate columns of ONE direction, each wave keeps the B
+// fragments of its 64 columns for the whole contraction in registers (2 x K/16 x 4 = 128 VGPRs at K = 256), and only
+// the activations stream: 64-row tiles (32 KB at K = 256) HBM -> LDS by global_load_lds_dwordx4 through a 4-slot ring,
+// THREE tiles in flight, one workgroup barrier per 64 rows (64 MFMAs per wave) instead of one per 64-deep k-tile.
+// L2 -> LDS traffic is 2 x the bytes of X (once per direction), 1.1 GB.  The two workgroups that share a row tile (one
+// per direction) sit 8 apart in blockIdx -- same XCD under round-robin placement -- and walk the same tile sequence,
+// so the second read of a tile is an L2 hit (speed only, never correctness).
+//
+// vmcnt bookkeeping (VMEM operations of a wave retire in order).  Per iteration q a wave issues, after the barrier,
+// NDMA DMA instructions for tile q + LA and, after the MFMAs, NST = 8 fragment stores of tile q.  When iteration q
+// starts, the operations younger than DMA(q) (issued in iteration q - LA) are LA x NST stores and (LA - 1) x NDMA
+// DMAs: one counted s_waitcnt vmcnt(VM_STEADY) serves every steady-state iteration.  The first LA iterations wait
+// with the smaller VM_PRO (no stores older than the awaited DMA exist yet: waiting longer is safe, shorter is not);
+// past the end the DMA of the last tile is re-issued into a slot nobody reads again, so the count stays valid.
+//
+// LDS image of a slot: [64 rows][K] bf16, rows of 2K bytes, lane-linear as the DMA writes it (1 KB per wave
+// instruction = 2 rows at K = 256, 4 at K = 128).  16-B chunk c of row r is stored at chunk slot c ^ (r & 15): applied
+// on the per-lane GLOBAL source address of the DMA and again on the fragment read (cdna guide rule 21); the 16 lanes a
+// ds_read_b128 services together hold 16 different r & 15, i.e. the 16 different 16-B pieces of the 256-B bank row.
+#include "lob_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_cvoid;
+
+struct WSArgs {
+    const __bf16* A; const __bf16* W; const float* bias; __bf16* P;
+    int lda, M, T, Bp, D;
+};
+
+template <int K>
+__global__ __launch_bounds__(512, 2) void gate_gemm_ws_kernel(WSArgs g) {
+    constexpr int MT = 64;                          // rows per tile
+    constexpr int NSLOT = K == 256 ? 4 : 6, LA = NSLOT - 1;
+    constexpr int ROWB = 2 * K, SLOTB = MT * ROWB;  // bytes per LDS row / slot
+    constexpr int RPI = 1024 / ROWB;                // rows per DMA instruction
+    constexpr int NDMA = MT / RPI / 8;              // DMA instructions per wave per tile
+    constexpr int NST = 8;                          // fragment stores per wave per tile
+    constexpr int VM_STEADY = LA * NST + (LA - 1) * NDMA, VM_PRO = (LA - 1) * NDMA;
+    constexpr int KS = K / 16;                      // MFMA k-steps
+    static_assert(VM_STEADY < 64 && NDMA >= 1, "vmcnt is a 6-bit counter");
+    __shared__ __attribute__((aligned(1024))) unsigned char ring[NSLOT * SLOTB];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r31 = lane & 31, hi = lane >> 5;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int d = slot % g.D, pair = slot / g.D, npair = (gridDim.x >> 3) / g.D;
+    const int ntile = (g.M + MT - 1) / MT;
+    const int panels = (ntile - xcd + 7) / 8;       // row tiles owned by this XCD: mt = 8 p + xcd
+    if (pair >= panels) return;
+    const int total = (panels - pair + npair - 1) / npair;
+
+    // ---- stationary B fragments: wreg[cb][s] = W[d*512 + 64 wv + 32 cb + r31][16 s + 8 hi .. + 7]
+    bf16x8 wreg[2][KS];
+    float bv[2];
+    {
+        const __bf16* wb = g.W + (size_t)(d * 512 + 64 * wv + r31) * K + 8 * hi;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) wreg[cb][s] = *reinterpret_cast<const bf16x8*>(wb + (size_t)(32 * cb) * K + 16 * s);
+            bv[cb] = g.bias ? g.bias[d * 512 + 64 * wv + 32 * cb + r31] : 0.f;
+        }
+    }
+    // make the weights opaque: hipcc otherwise feels free to re-load them inside the loop (256 VGPRs are tight)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(wreg[cb][s]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- DMA source addressing: instruction j of this wave covers tile rows (8 wv... ) see RPI
+    const int drow = lane / (ROWB / 16), dsl = lane % (ROWB / 16);        // row inside the instruction, chunk slot
+    unsigned dsrc[NDMA];                                                  // element offsets inside a tile (rows clamped later)
+    int drw[NDMA];
+#pragma unroll
+    for (int j = 0; j < NDMA; ++j) {
+        const int r = (wv * NDMA + j) * RPI + drow;                        // row inside the tile (0..63)
+        drw[j] = r;
+        dsrc[j] = (unsigned)((dsl ^ (r & 15)) * 8);
+    }
+    auto issue = [&](int u) {
+        const int ut = u < total ? u : total - 1;
+        const int m0 = ((pair + npair * ut) * 8 + xcd) * MT;
+        unsigned char* dst = ring + (u % NSLOT) * SLOTB + wv * NDMA * 1024;
+#pragma unroll
+        for (int j = 0; j < NDMA; ++j) {
+            int r = m0 + drw[j];
+            r = r < g.M ? r : g.M - 1;                                      // rows past the end are never stored
+            const __bf16* src = g.A + (size_t)r * g.lda + dsrc[j];
+            __builtin_amdgcn_global_load_lds((gbl_cvoid*)src, (lds_void*)(dst + j * 1024), 16, 0, 0);
+        }
+    };
+#pragma unroll 1
+    for (int u = 0; u < LA; ++u) issue(u);
+
+    // ---- fragment read addressing: row 32 i + r31, chunk 2 s + hi at slot (2 s + hi) ^ (r31 & 15)
+    const unsigned ring_b = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)ring;
+    unsigned aoff[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) aoff[s] = (unsigned)(r31 * ROWB + (((2 * s + hi) ^ (r31 & 15)) * 16));
+
+    f32x16 acc[2][2];
+    const int NBT = g.Bp >> 5;
+    const int gate = wv >> 1, w4 = 2 * (wv & 1);
+
+    for (int q = 0; q < total; ++q) {
+        if (q < LA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_PRO) : "memory");
+        else        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_STEADY) : "memory");
+        __builtin_amdgcn_s_barrier();
+        issue(q + LA);                                  // refills the slot read in iteration q - 1
+
+        const unsigned sb = ring_b + (unsigned)((q % NSLOT) * SLOTB);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][cb][r] = 0.f;
+        // fragment reads as inline asm (compiler-visible LDS reads of a DMA target may get an s_waitcnt vmcnt(0) in
+        // front, which would drain the ring); LDS operations return in order: each wait names the registers it frees
+#define LOB_RD(dstv, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dstv) : "v"(ADDR), "n"(OFF) : "memory")
+        bf16x8 a0, a1, n0, n1;
+        LOB_RD(a0, sb + aoff[0], 0);
+        LOB_RD(a1, sb + aoff[0], 32 * ROWB);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if (s + 1 < KS) {
+                LOB_RD(n0, sb + aoff[(s + 1) & 7], ((s + 1) >> 3) * 256);
+                LOB_RD(n1, sb + aoff[(s + 1) & 7], ((s + 1) >> 3) * 256 + 32 * ROWB);
+                asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a0), "+v"(a1));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1));
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wreg[0][s], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wreg[1][s], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wreg[0][s], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wreg[1][s], acc[1][1], 0, 0, 0);
+            a0 = n0; a1 = n1;
+        }
+#undef LOB_RD
+
+        // ---- epilogue: + bias, bf16, fragment order [d][t][bt][w 4][gate 4][q pair 2][lane 64][8]
+        const int m0 = ((pair + npair * q) * 8 + xcd) * MT;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int mrow = m0 + 32 * i;
+            const bool ok = mrow < g.M;
+            const int mr = ok ? mrow : 0;
+            const int t = mr / g.Bp, bt = (mr - t * g.Bp) >> 5;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const size_t fo = ((((size_t)(d * g.T + t) * NBT + bt) * 4 + (w4 + cb)) * 4 + gate) * 1024;
+                __bf16* dst = g.P + fo + lane * 8;
+#pragma unroll
+                for (int pq = 0; pq < 2; ++pq) {
+                    bf16x8 v;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (__bf16)(acc[i][cb][8 * pq + e] + bv[cb]);
+                    // rows past the end (M % 64 == 32) exist only in the LAST iteration of the workgroup that owns the
+                    // last tile: skipping their stores changes no later vmcnt count
+                    if (ok) *reinterpret_cast<bf16x8*>(dst + pq * 512) = v;
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+}  // namespace
+
+// Internal entry point used by lob_gate_gemm_x_bf16 (gemm_bf16.hip).  Preconditions checked by the caller: X, W bf16,
+// P bf16 fragment order, H == 128, K in {128, 256}, ldx % 8 == 0, 16-B aligned bases, Bp % 32 == 0.
+int lob_gate_gemm_ws(const void* X, int ldx, const void* Wih, const float* bias, void* P, int T, int Bp, int D, int K,
+                     hipStream_t s) {
+    const int M = T * Bp;
+    const int ntile = (M + 63) / 64;
+    int npx = (ntile + 7) / 8;                       // pairs per XCD, one workgroup per CU at most
+    const int cap = 32 / D;
+    if (npx > cap) npx = cap;
+    WSArgs g{(const __bf16*)X, (const __bf16*)Wih, bias, (__bf16*)P, ldx, M, T, Bp, D};
+    const dim3 grid((unsigned)(8 * D * npx)), block(512);
+    if (K == 256) hipLaunchKernelGGL(gate_gemm_ws_kernel<256>, grid, block, 0, s, g);
+    else          hipLaunchKernelGGL(gate_gemm_ws_kernel<128>, grid, block, 0, s, g);
+    LOB_CHECK_LAUNCH();
+    return 0;
+}

@@ -956,7 +956,7 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 // persistent grid of the NT kernel: one resident wave of workgroups (multiple of 8 for the XCD map)
 inline int nt_grid(int M, int N) {
     const long tiles = (long)((M + TM - 1) / TM) * ((N + TN_ - 1) / TN_);
-    static const int per_cu = [] { const char* e = getenv("LOB_NT_WGS"); return e ? atoi(e) : 3; }();
+    const int per_cu = lob_variant(LOB_VAR_NT_WGS) > 0 ? lob_variant(LOB_VAR_NT_WGS) : 3;
     long gsz = 256L * per_cu;
     if (gsz > tiles) gsz = ((tiles + 7) / 8) * 8;
     return (int)gsz;
@@ -964,7 +964,7 @@ inline int nt_grid(int M, int N) {
 
 // contraction depth per LDS stage of the NT kernel (tuning knob; LOB_NT_TK=32|64)
 inline int nt_tk() {
-    static const int v = [] { const char* e = getenv("LOB_NT_TK"); return (e && atoi(e) == 64) ? 64 : 32; }();
+    const int v = lob_variant(LOB_VAR_NT_TK) == 64 ? 64 : 32;
     return v;
 }
 
@@ -972,16 +972,16 @@ inline int nt_tk() {
 
 // A: fp32 (a_bf16 = 0) or bf16 (a_bf16 = 1) row-major [M][lda]; W fp32 [N][ldw]; C fp32.
 inline int nt_stagger() {       // tuning knob LOB_NT_STAGGER (units of s_sleep(32) = 2048 clocks per group step)
-    static const int v = [] { const char* e = getenv("LOB_NT_STAGGER"); return e ? atoi(e) : 0; }();
+    const int v = lob_variant(LOB_VAR_NT_STAGGER);
     return v;
 }
 inline bool nt_dma_enabled() {
-    static const bool v = [] { const char* e = getenv("LOB_NT_DMA"); return !(e && atoi(e) == 0); }();
+    const bool v = lob_variant(LOB_VAR_NT_DMA) != 0;
     return v;
 }
 inline int nt_dma_tile() {      // output tile of the LDS-DMA kernel (tuning knob; LOB_DMA_TILE=128|256|2 (= 256x128, 2 WGs/CU))
-    static const int v = [] { const char* e = getenv("LOB_DMA_TILE"); const int x = e ? atoi(e) : 256;
-                              return (x == 128 || x == 2) ? x : 256; }();
+    const int x = lob_variant(LOB_VAR_DMA_TILE);
+    const int v = (x == 128 || x == 2) ? x : 256;
     return v;
 }
 inline int nt_dma_grid(int M, int N, int tile) {
@@ -1012,8 +1012,8 @@ inline void launch_nt_dma(const NTArgs& g_, hipStream_t s) {
     };
     // 64-wide k-slots (two of them) by default: every DMA instruction fetches whole cache lines.  Measured against
     // four 32-wide slots (half a line per row per k-tile): gate GEMM K=256 0.96 -> 0.92 ms, dX N=256 0.84 -> 0.77 ms.
-    static const int kt64 = [] { const char* e = getenv("LOB_DMA_KT"); return e ? atoi(e) : 64; }();
-    static const bool adeep = [] { const char* e = getenv("LOB_NT_ADEEP"); return !(e && atoi(e) == 0); }();
+    const int kt64 = lob_variant(LOB_VAR_DMA_KT);
+    const bool adeep = lob_variant(LOB_VAR_NT_ADEEP) != 0;
     if (EPI == 0 && adeep && kt64 == 64 && !g.bias && g.N % 256 == 0 && g.K % 64 == 0 && g.K / 64 >= 3) {
         // no bias (dX = dP W_ih, dV = dU W1): deeper ring for the operand that comes from HBM
         if constexpr (EPI == 0)
@@ -1062,6 +1062,9 @@ extern "C" int lob_gemm_nt_bf16(const void* A, int a_bf16, int lda, const void* 
     return 0;
 }
 
+int lob_gate_gemm_ws(const void* X, int ldx, const void* Wih, const float* bias, void* P, int T, int Bp, int D, int K,
+                     hipStream_t s);       // gate_gemm_ws.hip
+
 extern "C" int lob_gate_gemm_x_bf16(const void* X, int x_bf16, int ldx, const void* Wih, int w_bf16, const float* bias,
                                     void* P, int p_bf16, int T, int Bp, int H, int D, int K, void* stream) {
     if (!X || !Wih || !P || T <= 0 || Bp <= 0 || H <= 0 || K <= 0 || (D != 1 && D != 2)) return LOB_E_ARG;
@@ -1071,6 +1074,9 @@ extern "C" int lob_gate_gemm_x_bf16(const void* X, int x_bf16, int ldx, const vo
     NTArgs g{X, reinterpret_cast<const float*>(Wih), bias, reinterpret_cast<float*>(P), ldx, K, N, M, N, K, LOB_ACT_NONE, 0,
              T, Bp, H, D, p_bf16, 0.f, 0, 0};
     if (w_bf16) {
+        // H = 128, bf16 P: the weight-stationary kernel (gate_gemm_ws.hip) -- only the activations stream
+        if (x_bf16 && p_bf16 && H == 128 && (K == 128 || K == 256) && lob_variant(LOB_VAR_GATE_WS) != 0)
+            return lob_gate_gemm_ws(X, ldx, Wih, bias, P, T, Bp, D, K, (hipStream_t)stream);
         if (!x_bf16 || (K % DTK) || K / DTK < DS || N > 2048 || (N % 128) || (M % 256)) return LOB_E_SHAPE;
         launch_nt_dma<1>(g, (hipStream_t)stream);
         LOB_CHECK_LAUNCH();

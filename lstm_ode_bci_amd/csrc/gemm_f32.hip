@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 inline bool f32_dma_enabled() {
-    static const bool v = [] { const char* e = getenv("LOB_F32_DMA"); return !(e && atoi(e) == 0); }();
+    const bool v = lob_variant(LOB_VAR_F32_DMA) != 0;
     return v;
 }
 

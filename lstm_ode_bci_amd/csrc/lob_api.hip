@@ -1,4 +1,67 @@
-// Library-level entry points of liblob.so.
+// Library-level entry points of liblob.so: version, build identity, and the run-time kernel-variant table.
 #include "lob_common.h"
+#include <atomic>
+#include <stdlib.h>
+
+#ifndef LOB_BUILD_ID
+#define LOB_BUILD_ID "unknown"
+#endif
 
 extern "C" int lob_version(void) { return LOB_VERSION; }
+extern "C" const char* lob_build_id(void) { return LOB_BUILD_ID; }
+
+namespace {
+struct VarDef { const char* env; int dflt; };
+// index = LOB_VAR_* of lob.h
+const VarDef kVars[LOB_VAR_COUNT] = {
+    {"LOB_REC_BWD_DMA", 1},   // LOB_VAR_REC_BWD_DMA
+    {"LOB_NT_DMA", 1},        // LOB_VAR_NT_DMA
+    {"LOB_DMA_TILE", 256},    // LOB_VAR_DMA_TILE
+    {"LOB_DMA_KT", 64},       // LOB_VAR_DMA_KT
+    {"LOB_NT_ADEEP", 1},      // LOB_VAR_NT_ADEEP
+    {"LOB_GATE_WS", 1},       // LOB_VAR_GATE_WS
+    {"LOB_REC_BF16", 16},     // LOB_VAR_REC_BF16_ROWS
+    {"LOB_F32_DMA", 1},       // LOB_VAR_F32_DMA
+    {"LOB_REC_FWD", 16},      // LOB_VAR_REC_FWD_ROWS
+    {"LOB_LN_LPR", 16},       // LOB_VAR_LN_LPR
+    {"LOB_NT_WGS", 3},        // LOB_VAR_NT_WGS
+    {"LOB_NT_TK", 32},        // LOB_VAR_NT_TK
+    {"LOB_NT_STAGGER", 0},    // LOB_VAR_NT_STAGGER
+    {"LOB_FUSED_DW", 1},      // LOB_VAR_FUSED_DW (host-side choice, kept here so that one table lists them all)
+    {"LOB_F32_SPLIT", 1},     // LOB_VAR_F32_SPLIT
+    {"LOB_REC_F32_HALF", 1},  // LOB_VAR_REC_F32_HALF
+    {"LOB_H256_BWD", 1},      // LOB_VAR_H256_BWD
+};
+std::atomic<int> g_vals[LOB_VAR_COUNT];
+std::atomic<int> g_init{0};
+
+void init_once() {
+    if (g_init.load(std::memory_order_acquire) == 2) return;
+    int expect = 0;
+    if (g_init.compare_exchange_strong(expect, 1)) {
+        for (int i = 0; i < LOB_VAR_COUNT; ++i) {
+            const char* e = getenv(kVars[i].env);
+            g_vals[i].store(e ? atoi(e) : kVars[i].dflt, std::memory_order_relaxed);
+        }
+        g_init.store(2, std::memory_order_release);
+    } else {
+        while (g_init.load(std::memory_order_acquire) != 2) {}
+    }
+}
+}  // namespace
+
+int lob_variant(int which) {
+    init_once();
+    return (which >= 0 && which < LOB_VAR_COUNT) ? g_vals[which].load(std::memory_order_relaxed) : 0;
+}
+
+extern "C" int lob_debug_get_variant(int which) {
+    if (which < 0 || which >= LOB_VAR_COUNT) return LOB_E_ARG;
+    return lob_variant(which);
+}
+
+extern "C" int lob_debug_set_variant(int which, int value) {
+    if (which < 0 || which >= LOB_VAR_COUNT) return LOB_E_ARG;
+    init_once();
+    return g_vals[which].exchange(value, std::memory_order_relaxed);
+}

@@ -7,6 +7,9 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// current value of a LOB_VAR_* kernel-variant switch (lob_api.hip)
+int lob_variant(int which);
+
 #define LOB_CHECK_LAUNCH()                                   \
     do {                                                     \
         hipError_t e__ = hipGetLastError();                  \

@@ -348,7 +348,7 @@ int lob_rec_fwd_h256_bf16(void* P, const void* Whh16, float* Y, float* Csave, vo
 int lob_rec_bwd_h256_bf16(const void* G, const float* Csave, const void* WhhT16, const float* dY, void* dP,
                           float* dbias, int T, int Bp, int D, hipStream_t s);
 static bool use_s16() {
-    static const bool v = [] { const char* e = getenv("LOB_REC_BF16"); return !(e && atoi(e) == 32); }();
+    const bool v = lob_variant(LOB_VAR_REC_BF16_ROWS) != 32;
     return v;
 }
 

@@ -575,8 +575,8 @@ int lob_rec_fwd_bf16_s16(void* P, int pg_bf16, const float* Whh, float* Y, float
 int lob_rec_bwd_bf16_s16(const void* G, int pg_bf16, const float* Csave, const float* Whh, const float* dY, void* dP,
                          float* dbias, int T, int Bp, int D, hipStream_t s) {
     const dim3 grid(Bp / 16, D), block(256);
-    // LOB_REC_BWD_DMA=0 selects the register-prefetch kernel (also the only one for fp32 saved gates)
-    static const bool dma = [] { const char* e = getenv("LOB_REC_BWD_DMA"); return !(e && atoi(e) == 0); }();
+    // LOB_VAR_REC_BWD_DMA = 0 selects the register-prefetch kernel (also the only one for fp32 saved gates)
+    const bool dma = lob_variant(LOB_VAR_REC_BWD_DMA) != 0;
     if (pg_bf16 && dma) {
         if (D == 2)
             hipLaunchKernelGGL(lstm_rec_bwd_h128_bf16_s16_dma_kernel<2>, grid, block, 0, s,

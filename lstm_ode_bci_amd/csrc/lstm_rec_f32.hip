@@ -462,7 +462,7 @@ extern "C" int lob_lstm_rec_fwd_f32(float* P, const float* Whh, float* Y, float*
              reinterpret_cast<uintptr_t>(Csave)) & 15) return LOB_E_ALIGN;
         // 16-row tiles (v_mfma_f32_16x16x4_f32) by default: twice the workgroups for small batches and 2-8 % faster at
         // B = 4096; LOB_REC_FWD=32 selects the 32-row kernel below (kept for A/B measurements)
-        static const bool rows32 = [] { const char* e = getenv("LOB_REC_FWD"); return e && atoi(e) == 32; }();
+        const bool rows32 = lob_variant(LOB_VAR_REC_FWD_ROWS) == 32;
         if (!rows32) return lob_rec_fwd_s16(P, Whh, Y, Csave, T, Bp, D, save, s);
         const dim3 grid(Bp / 32, D), block(256);
         if (save) hipLaunchKernelGGL((lstm_rec_fwd_h128_kernel<true, SAVE_WLDS>), grid, block, 0, s, P, Whh, Y, Csave, T, Bp);

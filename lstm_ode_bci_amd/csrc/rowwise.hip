@@ -648,7 +648,7 @@ extern "C" int lob_dropout_f32(const float* in, float* out, int64_t n, float p, 
 
 // width 128: 16 lanes per row (LOB_LN_LPR=64 selects the one-row-per-wave form)
 static bool ln_lpr16() {
-    static const bool v = [] { const char* e = getenv("LOB_LN_LPR"); return !(e && atoi(e) == 64); }();
+    const bool v = lob_variant(LOB_VAR_LN_LPR) != 64;
     return v;
 }
 

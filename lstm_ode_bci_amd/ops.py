@@ -99,13 +99,14 @@ def gemm_tn(a, b, out, mixed=False):
     return out
 
 
-#: dW_ih and dW_hh of a layer from one pass over dP (LOB_FUSED_DW=0: two/three separate TN GEMMs)
-FUSED_DW = os.environ.get("LOB_FUSED_DW", "1") != "0"
+def fused_dw_enabled():
+    """dW_ih and dW_hh of a layer from one pass over dP (LOB_VAR_FUSED_DW = 0: two/three separate TN GEMMs)."""
+    return _lib.get_variant("FUSED_DW") != 0
 
 
 def can_fuse_dw(dP, inp, Y, T, Bp, H, D):
     bf = torch.bfloat16
-    return (FUSED_DW and H == 128 and T >= 2 and Bp % 32 == 0 and dP.dtype == bf and inp.dtype == bf and Y.dtype == bf
+    return (fused_dw_enabled() and H == 128 and T >= 2 and Bp % 32 == 0 and dP.dtype == bf and inp.dtype == bf and Y.dtype == bf
             and inp.shape[1] in (128, 256) and dP.shape[1] == D * 4 * H and Y.shape[1] == D * H
             and dP.stride(1) == 1 and inp.stride(1) == 1 and Y.stride(1) == 1
             and dP.stride(0) % 8 == 0 and inp.stride(0) % 8 == 0 and Y.stride(0) % 8 == 0
@@ -129,6 +130,12 @@ NT_DMA = True
 def dma_ok(K, N, M):
     """Shapes the LDS-DMA NT GEMM accepts (K = contraction, N = output columns, M = rows)."""
     return NT_DMA and K % 32 == 0 and K >= 128 and N % 128 == 0 and N <= 2048 and M % 256 == 0
+
+
+def gate_ws_ok(K, H):
+    """Shapes of the weight-stationary gate GEMM (csrc/gate_gemm_ws.hip): bf16 x bf16 -> bf16 fragment-order P at
+    H == 128, any number of rows."""
+    return PG_BF16 and H == 128 and K in (128, 256)
 
 
 #: mixed mode, H == 128: store the fragment-order pre-activations / saved gates as bf16 (half the HBM

@@ -433,10 +433,11 @@ def test_fused_weight_gradients_same_step_as_separate_gemms(dev, monkeypatch):
             loss = torch.nn.functional.cross_entropy(m(x).float(), y)
         loss.backward()
         return {k: p.grad.clone() for k, p in m.named_parameters()}
-    monkeypatch.setattr(ops, "FUSED_DW", True)
-    g1 = grads()
-    monkeypatch.setattr(ops, "FUSED_DW", False)
-    g0 = grads()
+    from lstm_ode_bci_amd import _lib
+    with _lib.variant(FUSED_DW=1):
+        g1 = grads()
+    with _lib.variant(FUSED_DW=0):
+        g0 = grads()
     for k in g0:
         sc = g0[k].abs().max().item() + 1e-12
         assert (g1[k] - g0[k]).abs().max().item() <= 1e-4 * sc + 1e-7, k

@@ -1,0 +1,229 @@
+"""Full-size parity of the kernels the bench times (run with ``-m gpu`` on an MI355X).
+
+The hand-synchronised kernels (LDS-DMA rings, hand-counted ``s_waitcnt vmcnt(N)``) are only correct if the counts are
+right, and a stale-ring read shows up under load, at the step's REAL shapes -- not at B = 40.  So each of them is run
+at rows = T * Bp = 1,048,576 (B = 4096, T = 256) against its slower twin, selected per call through the test-only
+variant table of the C-ABI (``lob_debug_set_variant``, include/lob.h):
+
+* same arithmetic in the same order -> the outputs must be BIT-IDENTICAL (BPTT dP, gate GEMM, NT GEMM);
+* split-k partial sums added with fp32 atomics (weight gradients) -> equal to fp32 rounding.
+
+Plus the mixed fwd+bwd of the whole model at B = 4096 (reference training step, 04_lstm_model.py:482-512 under
+autocast 04:487): gradient additivity over a ragged batch split, and mixed gradients against the fp32 path's on the
+same weights, per tensor, worst tensor printed.
+"""
+import numpy as np
+import pytest
+import torch
+
+from lstm_ode_bci_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+T, B = 256, 4096
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from lstm_ode_bci_amd import _lib
+    assert _lib.lib().lob_version() >= 200
+    return torch.device("cuda:0")
+
+
+def _rand(shape, dev, seed, scale=1.0, dtype=torch.float32):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    return (torch.randn(shape, generator=g, device=dev) * scale).to(dtype)
+
+
+@pytest.fixture(scope="module")
+def layer_state(dev):
+    """One H = 128 layer at the step's real shapes, through the product kernels: P -> (G, c, Y16) -> dP."""
+    from lstm_ode_bci_amd import ops
+    H, D, K = 128, 2, 256
+    Bp = ops.ceil32(B)
+    rows = T * Bp
+    x = _rand((rows, K), dev, 1, dtype=torch.bfloat16)
+    wih = (_rand((D * 4 * H, K), dev, 2, 0.06)).to(torch.bfloat16)
+    bias = _rand((D * 4 * H,), dev, 3, 0.1)
+    whh = _rand((D, 4 * H, H), dev, 4, 0.06)
+    P = ops.gate_gemm_x(x, wih, bias, T, Bp, H, D, True, mixed=True)
+    G = P.clone()
+    Y, Cs, Y16, _ = ops.lstm_rec_fwd(G, whh, T, Bp, H, D, True, mixed=True, want_f32=False, want_bf16=True)
+    dY = _rand((rows, D * H), dev, 5, 1e-3)
+    return dict(H=H, D=D, K=K, Bp=Bp, rows=rows, x=x, wih=wih, bias=bias, whh=whh, P=P, G=G, Cs=Cs, Y16=Y16, dY=dY)
+
+
+def test_gate_gemm_weight_stationary_bit_identical_to_tiled(dev, layer_state):
+    """gate_gemm_ws_kernel (weights in registers, activations through a 4-slot LDS-DMA ring, vmcnt(32)) against
+    gemm_nt_dma_kernel<1,256,256>: same MFMA, same k order, bias added last -> bit-identical P, K = 256 and 128."""
+    from lstm_ode_bci_amd import _lib, ops
+    s = layer_state
+    for K in (256, 128):
+        x = s["x"][:, :K].contiguous()
+        w = s["wih"][:, :K].contiguous()
+        with _lib.variant(GATE_WS=1):
+            p_ws = ops.gate_gemm_x(x, w, s["bias"], T, s["Bp"], s["H"], s["D"], True, mixed=True)
+            p_ws2 = ops.gate_gemm_x(x, w, s["bias"], T, s["Bp"], s["H"], s["D"], True, mixed=True)
+        with _lib.variant(GATE_WS=0):
+            p_tl = ops.gate_gemm_x(x, w, s["bias"], T, s["Bp"], s["H"], s["D"], True, mixed=True)
+        assert p_ws.dtype == torch.bfloat16 and torch.equal(p_ws, p_ws2)
+        nbad = int((p_ws.view(torch.int16) != p_tl.view(torch.int16)).sum())
+        assert nbad == 0, f"K={K}: {nbad} of {p_ws.numel()} elements differ"
+
+
+@pytest.mark.parametrize("Tn,Bn,K", [(3, 32, 256), (5, 96, 128), (7, 160, 256), (1, 32, 128), (12, 32, 256)])
+def test_gate_gemm_weight_stationary_ragged(dev, Tn, Bn, K):
+    """Tile counts below the ring depth, M % 64 == 32 tails, unidirectional: against a float64 product of the bf16
+    operands, un-permuted from the fragment order by the recurrent kernel's own layout rule (include/lob.h)."""
+    from lstm_ode_bci_amd import _lib, ops
+    H = 128
+    for D in (1, 2):
+        x = _rand((Tn * Bn, K), dev, 11 + Tn, dtype=torch.bfloat16)
+        w = _rand((D * 4 * H, K), dev, 12 + Bn, 0.06, dtype=torch.bfloat16)
+        bias = _rand((D * 4 * H,), dev, 13, 0.1)
+        with _lib.variant(GATE_WS=1):
+            p_ws = ops.gate_gemm_x(x, w, bias, Tn, Bn, H, D, True, mixed=True)
+        with _lib.variant(GATE_WS=0):
+            p_tl = (ops.gate_gemm_x(x, w, bias, Tn, Bn, H, D, True, mixed=True) if (Tn * Bn) % 256 == 0 else
+                    ops.gate_gemm_x(x, w.float(), bias, Tn, Bn, H, D, True, mixed=True))    # register-staged kernel
+        assert torch.equal(p_ws, p_tl), (Tn, Bn, K, D)
+
+
+def test_bptt_dma_ring_bit_identical_to_register_prefetch(dev, layer_state):
+    """lstm_rec_bwd_h128_bf16_s16_dma_kernel (wave-private LDS-DMA ring, vmcnt(14)/(18)) against the register-prefetch
+    kernel: same arithmetic in the same order -> dP bit-identical over all 1M rows; the bias gradient (fp32 atomics
+    over 512 workgroups) to rounding."""
+    from lstm_ode_bci_amd import _lib, ops
+    s = layer_state
+    with _lib.variant(REC_BWD_DMA=1):
+        dP1, db1 = ops.lstm_rec_bwd(s["G"], s["Cs"], s["whh"], s["dY"], T, s["Bp"], s["H"], s["D"], dp_bf16=True)
+    with _lib.variant(REC_BWD_DMA=0):
+        dP0, db0 = ops.lstm_rec_bwd(s["G"], s["Cs"], s["whh"], s["dY"], T, s["Bp"], s["H"], s["D"], dp_bf16=True)
+    nbad = int((dP1.view(torch.int16) != dP0.view(torch.int16)).sum())
+    assert nbad == 0, f"{nbad} of {dP1.numel()} dP elements differ"
+    assert torch.isfinite(dP1.float()).all() and dP1.float().abs().max().item() > 0
+    assert (db1 - db0).abs().max().item() <= 1e-4 * db0.abs().max().item() + 1e-9
+
+
+def test_nt_dma_gemm_matches_register_staged_twin(dev, layer_state):
+    """dX = dP W_ih through gemm_nt_dma_kernel<0,256,256,...,ADEEP> (LDS-DMA rings, VM_STEADY / VM_EPI) against the
+    register-staged gemm_nt_bf16_kernel on the same bf16 values (M = 1,048,576, K = 1024, N = 256): same MFMA and
+    k order -> identical to fp32 rounding (both accumulate 64 k-steps in the same sequence: in practice bit-equal)."""
+    from lstm_ode_bci_amd import ops
+    s = layer_state
+    dP = _rand((s["rows"], s["D"] * 4 * s["H"]), dev, 21, 1e-2, dtype=torch.bfloat16)
+    wt = s["wih"].t().contiguous()                        # (256, 1024) bf16
+    out_dma = ops.gemm_nt(dP, wt, mixed=True)
+    out_reg = ops.gemm_nt(dP, wt.float(), mixed=True)     # fp32 weights -> register-staged kernel (rounds to the same bf16)
+    diff = (out_dma - out_reg).abs().max().item()
+    assert diff <= 1e-6 * out_reg.abs().max().item(), diff
+    # and with the fused dropout-backward epilogue
+    o2 = ops.gemm_nt(dP, wt, mixed=True, drop_p=0.4, seed=77)
+    o3 = ops.gemm_nt(dP, wt.float(), mixed=True, drop_p=0.4, seed=77)
+    assert (o2 - o3).abs().max().item() <= 1e-6 * o3.abs().max().item()
+
+
+def test_fused_dw_matches_separate_tn_gemms(dev, layer_state):
+    """lstm_dw_h128_kernel<256> (4-slot LDS-DMA ring, inline-asm transposing reads, hand-counted lgkmcnt) against the
+    register-staged TN GEMM twins at rows = 1,048,576: split-k fp32 atomics -> equal to fp32 rounding of a
+    1M-term sum (2e-4 of the largest entry)."""
+    from lstm_ode_bci_amd import _lib, ops
+    s = layer_state
+    H, D, Bp = s["H"], s["D"], s["Bp"]
+    dP = _rand((s["rows"], D * 4 * H), dev, 31, 1e-2, dtype=torch.bfloat16)
+    X, Y = s["x"], s["Y16"]
+    assert ops.can_fuse_dw(dP, X, Y, T, Bp, H, D)
+    dwih, dwhh = ops.lstm_dw(dP, X, Y, T, Bp, H, D)
+    with _lib.variant(NT_DMA=0):                        # register-staged TN kernel
+        ref_ih = torch.zeros_like(dwih)
+        ops.gemm_tn(dP, X, ref_ih, mixed=True)
+        ref_hh = torch.zeros_like(dwhh)
+        ops.gemm_tn(dP[Bp:, :4 * H], Y[:(T - 1) * Bp, :H], ref_hh[0], mixed=True)
+        ops.gemm_tn(dP[:(T - 1) * Bp, 4 * H:], Y[Bp:, H:], ref_hh[1], mixed=True)
+    for got, ref, nm in ((dwih, ref_ih, "dW_ih"), (dwhh, ref_hh, "dW_hh")):
+        err = (got - ref).abs().max().item()
+        assert err <= 2e-4 * ref.abs().max().item(), (nm, err, ref.abs().max().item())
+    with _lib.variant(NT_DMA=1):                        # and the LDS-DMA TN kernel against the same reference
+        dma_ih = torch.zeros_like(dwih)
+        ops.gemm_tn(dP, X, dma_ih, mixed=True)
+    assert (dma_ih - ref_ih).abs().max().item() <= 2e-4 * ref_ih.abs().max().item()
+
+
+def test_h256_full_size_kernels_vs_twins(dev):
+    """H = 256 (the reference's real checkpoint size, 04_lstm_model.py:877) at B = 4096: the streamed-W_hh bf16
+    recurrent kernels on a full-size layer.  Forward: h of the first steps against a torch restatement on a sample of
+    windows; BPTT: the two kernel shapes (LOB_VAR_H256_BWD) must agree bit for bit on dP."""
+    from lstm_ode_bci_amd import _lib, ops
+    H, D, K = 256, 2, 512
+    Bp = ops.ceil32(B)
+    rows = T * Bp
+    x = _rand((rows, K), dev, 41, dtype=torch.bfloat16)
+    wih = _rand((D * 4 * H, K), dev, 42, 0.04, dtype=torch.bfloat16)
+    bias = _rand((D * 4 * H,), dev, 43, 0.1)
+    whh = _rand((D, 4 * H, H), dev, 44, 0.04)
+    P = ops.gate_gemm_x(x, wih, bias, T, Bp, H, D, True, mixed=True)
+    assert P.dtype == torch.bfloat16
+    G = P.clone()
+    Y, Cs, Y16, _ = ops.lstm_rec_fwd(G, whh, T, Bp, H, D, True, mixed=True, want_f32=True, want_bf16=True)
+    # forward direction, first 3 steps, windows 0..7 and the last 8: fp64 restatement on the same bf16 operands
+    idx = torch.cat([torch.arange(0, 8), torch.arange(B - 8, B)]).to(dev)
+    w_ih0 = wih[:4 * H].double()
+    w_hh0 = whh[0].to(torch.bfloat16).double()
+    h = torch.zeros((16, H), device=dev, dtype=torch.float64)
+    c = torch.zeros_like(h)
+    for t in range(3):
+        xt = x[t * Bp + idx].double()
+        z = (xt @ w_ih0.T + bias[:4 * H].double()).to(torch.bfloat16).double() + h.to(torch.bfloat16).double() @ w_hh0.T
+        i, f, g, o = z[:, :H].sigmoid(), z[:, H:2 * H].sigmoid(), z[:, 2 * H:3 * H].tanh(), z[:, 3 * H:].sigmoid()
+        c = f * c + i * g
+        h = o * c.tanh()
+        got = Y[t * Bp + idx, :H].double()
+        assert (got - h).abs().max().item() < 2e-3, t
+    dY = _rand((rows, D * H), dev, 45, 1e-3)
+    with _lib.variant(H256_BWD=1):
+        dP1, db1 = ops.lstm_rec_bwd(G, Cs, whh, dY, T, Bp, H, D, dp_bf16=True)
+    with _lib.variant(H256_BWD=0):
+        dP0, db0 = ops.lstm_rec_bwd(G, Cs, whh, dY, T, Bp, H, D, dp_bf16=True)
+    assert torch.isfinite(dP1.float()).all() and dP1.float().abs().max().item() > 0
+    nbad = int((dP1.view(torch.int16) != dP0.view(torch.int16)).sum())
+    assert nbad == 0, f"{nbad} of {dP1.numel()} dP elements differ"
+    assert (db1 - db0).abs().max().item() <= 1e-4 * db0.abs().max().item() + 1e-9
+
+
+def test_full_size_mixed_fwd_bwd_properties(dev):
+    """B = 4096, T = 256, H = 128 under autocast (the bench's default step): (i) gradient additivity over the ragged
+    1504 / 2592 batch split with a sum-reduced loss -- every hand-counted kernel runs at three different grid sizes and
+    must produce the same sums; (ii) mixed gradients against the fp32 path's on the same weights, <= 2e-2 of the
+    tensor's largest fp32 entry, worst tensor printed."""
+    from lstm_ode_bci_amd import EnhancedLSTMModel
+    sd = syn.make_state_dict(61, 128, 3, 2, True)
+    x, y = syn.make_windows(B)
+    m = EnhancedLSTMModel(input_size=61, hidden_size=128, num_layers=3, num_classes=2, dropout=0.4, bidirectional=True)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    m = m.to(dev).eval()
+    xt, yt = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+
+    def grads(xs, ys, mixed):
+        m.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=mixed):
+            loss = torch.nn.functional.cross_entropy(m(xs).float(), ys, reduction="sum")
+        loss.backward()
+        return {k: p.grad.clone() for k, p in m.named_parameters()}
+    g_all = grads(xt, yt, True)
+    g_a, g_b = grads(xt[:1504], yt[:1504], True), grads(xt[1504:], yt[1504:], True)
+    for k in g_all:
+        ref_ = g_a[k] + g_b[k]
+        # the three runs round the same bf16 values (windows are independent); only fp32 summation order differs
+        assert (g_all[k] - ref_).abs().max().item() <= 3e-4 * ref_.abs().max().item() + 1e-7, k
+    g32 = grads(xt, yt, False)
+    worst, wk = 0.0, None
+    for k in g32:
+        sc = g32[k].abs().max().item()
+        if sc < 1e-7:
+            continue
+        e = (g_all[k] - g32[k]).abs().max().item() / sc
+        if e > worst:
+            worst, wk = e, k
+    print(f"mixed vs fp32 gradients at B={B}: worst tensor {wk} rel err {worst:.3e}")
+    assert worst <= 2e-2, (wk, worst)

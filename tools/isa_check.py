@@ -62,6 +62,50 @@ def check_dma_gemms(path=None):
     return problems
 
 
+def check_gate_ws(path=None):
+    """The weight-stationary gate GEMM (gate_gemm_ws.hip): its ring wait is one hand-counted `s_waitcnt vmcnt(N)` per
+    64-row tile; a compiler-generated VMEM wait or spill traffic inside the tile loop would drain the three tiles in
+    flight, and the count assumes exactly NDMA LDS-DMA instructions and 8 fragment stores per iteration."""
+    src = os.path.join(ROOT, "lstm_ode_bci_amd", "csrc", "gate_gemm_ws.hip")
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    out = path or os.path.join(tempfile.mkdtemp(prefix="lob_isa_"), "ws.s")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"),
+                    "-I", os.path.dirname(src), "-S", "--cuda-device-only", src, "-o", out],
+                   check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    lines = open(out).read().split("\n")
+    problems = []
+    for K, ndma in ((256, 4), (128, 2)):
+        pat = "gate_gemm_ws_kernelILi%dE" % K
+        body = _function(lines, pat)
+        ins = _instrs(body)
+        labels = {m.group(1): i for i, l in enumerate(body) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+        # the tile loop: the innermost backward branch that encloses the MFMAs
+        mf = [k for k, (_, t, _) in enumerate(ins) if t.startswith("v_mfma")]
+        back = [(k, labels[m.group(1)]) for k, (i, t, _) in enumerate(ins)
+                for m in [re.search(r"s_c?branch\S*\s+(\.LBB\d+_\d+)", t)] if m and labels.get(m.group(1), 1 << 30) < i]
+        encl = [(k, tgt) for k, tgt in back if k > mf[-1] and tgt < ins[mf[0]][0]]
+        if not encl:
+            problems.append(f"{pat}: tile loop not found")
+            continue
+        tgt = max(t for _, t in encl)                          # innermost loop header in front of the MFMAs
+        kend = max(k for k, t in encl if t == tgt)             # ... and its last backward branch
+        loop = [x for x in ins[:kend + 1] if x[0] >= tgt]
+        n_dma = sum(1 for _, t, _ in loop if t.startswith("global_load_lds"))
+        n_st = sum(1 for _, t, _ in loop if t.startswith("global_store"))
+        n_mfma = sum(1 for _, t, _ in loop if t.startswith("v_mfma"))
+        if n_dma != ndma or n_st != 8 or n_mfma != 4 * (K // 16):
+            problems.append(f"{pat}: tile loop has {n_dma} DMA / {n_st} stores / {n_mfma} MFMAs, the wait counts assume "
+                            f"{ndma} / 8 / {4 * (K // 16)}")
+        for _, t, a in loop:
+            if not a and re.search(r"s_waitcnt.*vmcnt\(", t):
+                problems.append(f"{pat}: compiler-generated VMEM wait in the tile loop: {t}")
+            if t.startswith("scratch_"):
+                problems.append(f"{pat}: spill traffic in the tile loop: {t}")
+            if not a and t.startswith("global_load") and not t.startswith("global_load_lds"):
+                problems.append(f"{pat}: register load in the tile loop (weights re-loaded?): {t}")
+    return problems
+
+
 def _function(lines, pat):
     st = next(i for i, l in enumerate(lines) if re.match(r"^_ZN.*" + pat + r".*:", l))
     end = next(i for i in range(st + 1, len(lines)) if lines[i].startswith(".Lfunc_end"))
@@ -147,6 +191,6 @@ def main(path=None):
 
 
 if __name__ == "__main__":
-    probs = main(sys.argv[1] if len(sys.argv) > 1 else None)
+    probs = main(sys.argv[1] if len(sys.argv) > 1 else None) + check_dma_gemms() + check_gate_ws()
     print("\n".join(probs) if probs else "isa_check: ok")
     sys.exit(1 if probs else 0)

@@ -98,6 +98,17 @@ if on("dma"):
             report(f"dX N={Kout} {nm}", timeit(lambda: ops.gemm_nt(dPb, wt.to(wdt), mixed=True)), 2.0 * rows * N * Kout,
                    rows * (2.0 * N + 4.0 * Kout))
 
+if on("ws"):
+    from lstm_ode_bci_amd import _lib
+    for K in (128, 256):
+        xb = torch.randn((rows, K), generator=g).to(dev).to(torch.bfloat16)
+        wb = (torch.rand((N, K), generator=g) * 0.17 - 0.085).to(dev).to(torch.bfloat16)
+        bias = torch.zeros(N, device=dev)
+        for v, nm in ((0, "tiled"), (1, "weight-stationary")):
+            with _lib.variant(GATE_WS=v):
+                report(f"gate_gemm K={K} {nm}", timeit(lambda: ops.gate_gemm_x(xb, wb, bias, T, Bp, H, D, True, mixed=True), 8),
+                       2.0 * rows * N * K, rows * (2.0 * K + 2.0 * N))
+
 if on("tndma"):
     dPb = torch.randn((rows, N), generator=g).to(dev).to(torch.bfloat16)
     xb = torch.randn((rows, 256), generator=g).to(dev).to(torch.bfloat16)
