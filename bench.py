@@ -11,9 +11,13 @@ data-path collective; the step ends with the one collective the path needs (all-
 logits for inference, gradient all-reduce for training).
 
 Prints ONE JSON line on rank 0 (contract in the task statement), carrying `roofline` (live HIP
-event timing of the dominant kernel vs the fp32 MFMA peak) and `cpu_baseline` (the oracle's
+event timing of the dominant kernel against the roof that bounds it) and `cpu_baseline` (the oracle's
 torch-CPU layer stack -- the reference's CPU path semantically -- timed on this host's cores on a
-bounded sample; rank 0, N = 1 only).
+bounded sample; rank 0, N = 1 only).  At N = 1 with the default mode the same run also times the other
+BASELINE.json configurations in short legs and embeds them under `extra_configs` (--no-extra skips them):
+configs[1] fp32 forward at B = 1024, configs[3] the coupled LSTM -> ODE path at B = 4096 / 300 points
+(device-resident AND numpy-in / numpy-out through `predict_batch`), the H = 256 mixed training step (the
+reference's real checkpoint size, 04_lstm_model.py:877) and the B = 8192 forward (configs[4]'s per-rank shard).
 """
 import argparse
 import json
@@ -27,10 +31,15 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-T, C, H, L, D = 256, 61, 128, 3, 2
-FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-GATE_FLOP_FWD = 2 ** 29            # per window, SURVEY.md §8d
-HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
+T, C, L, D = 256, 61, 3, 2
+# MI355X_MICROARCH.md: dense MFMA peaks per arithmetic dtype, HBM3E spec peak
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}
+HBM_PEAK_GBPS = 8000.0
+
+
+def gate_flop_fwd(H):
+    """Gate-GEMM FLOPs per window, forward (2^29 at H = 128, 2^31 at H = 256)."""
+    return 2.0 * T * D * 4 * H * (2 * H + (L - 1) * 3 * H)
 
 
 def parse():
@@ -41,6 +50,7 @@ def parse():
     ap.add_argument("--mode", default=None, choices=["train", "fwd", "coupled"])
     ap.add_argument("--batch", type=int, default=4096, help="windows per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra BASELINE-config legs")
     ap.add_argument("--hidden", type=int, default=128, help="hidden size (128 = BASELINE configs; 256 = real checkpoints)")
     ap.add_argument("--forecast-steps", type=int, default=300)
     ap.add_argument("--precision", default=None, choices=["fp32", "mixed"],
@@ -49,15 +59,7 @@ def parse():
     return ap.parse_args()
 
 
-def have_backward():
-    try:
-        from lstm_ode_bci_amd import backward  # noqa: F401
-        return True
-    except Exception:
-        return False
-
-
-def build_model(dev):
+def build_model(dev, H):
     from lstm_ode_bci_amd import EnhancedLSTMModel
     from lstm_ode_bci_amd import synthetic as syn
     sd = syn.make_state_dict(C, H, L, 2, True)
@@ -67,10 +69,10 @@ def build_model(dev):
     return m.to(dev), sd
 
 
-def kernel_roofline(dev, B, mode, precision):
+def kernel_roofline(dev, B, mode, precision, H):
     """Per-launch durations of the hot kernels of THIS workload, HIP events on the launch stream
     (torch's current stream is the stream every lob_* call is launched on).  Returns
-    {name: {sec, flop, bytes, per_step}}; `bytes` = algorithmic HBM bytes of one launch."""
+    {name: {sec, flop, bytes, per_step, mfma}}; `bytes` = algorithmic HBM bytes of one launch."""
     from lstm_ode_bci_amd import ops
     Bp = ops.ceil32(B)
     g = torch.Generator(device="cpu").manual_seed(1)
@@ -94,9 +96,9 @@ def kernel_roofline(dev, B, mode, precision):
     bf16_rec = mixed and ops.bf16_rec(H, ops.PG_BF16)   # bf16-MFMA recurrent kernels: H = 128 and 256
     pe = 2.0 if (bf16_rec and ops.PG_BF16) else 4.0     # bytes per stored pre-activation / saved gate
     de = 2.0 if mixed else 4.0                          # bytes per dP element
-    # operand storage types as the step itself uses them: in mixed mode at H = 128 the layer below hands
-    # over bf16 activations and the weights are cast once per step -> the LDS-DMA GEMM kernels
-    act16 = bf16_rec and ops.dma_ok(K, N, rows)
+    # operand storage types as the step itself uses them: in mixed mode the layer below hands over bf16
+    # activations and the weights are cast once per step -> the bf16 x bf16 GEMM kernels
+    act16 = bf16_rec and (ops.gate_ws_ok(K, H) or ops.dma_ok(K, N, rows))
     xe = 2.0 if act16 else 4.0                          # bytes per inter-layer activation element
     x = torch.randn((rows, K), generator=g).to(dev)
     wih = (torch.rand((N, K), generator=g) * 0.17 - 0.085).to(dev)
@@ -107,8 +109,8 @@ def kernel_roofline(dev, B, mode, precision):
     bias = torch.zeros(N, device=dev)
     whh = (torch.rand((D, 4 * H, H), generator=g) * 0.17 - 0.085).to(dev)
     sec = timeit(lambda: ops.gate_gemm_x(x, w_in, bias, T, Bp, H, D, True, mixed=mixed))
-    out["gate_gemm_x(K=256)"] = {"sec": sec, "flop": 2.0 * rows * N * K, "bytes": rows * (xe * K + pe * N) + xe * N * K,
-                                 "per_step": L - 1, "mfma": "bf16" if mixed else "f32"}
+    out[f"gate_gemm_x(K={K})"] = {"sec": sec, "flop": 2.0 * rows * N * K, "bytes": rows * (xe * K + pe * N) + xe * N * K,
+                                  "per_step": L - 1, "mfma": "bf16" if mixed else "f32"}
     P = ops.gate_gemm_x(x, w_in, bias, T, Bp, H, D, True, mixed=mixed)
     if train:
         Pk = P.clone()
@@ -157,18 +159,22 @@ def kernel_roofline(dev, B, mode, precision):
 
 
 def roofline_of(kr):
-    """The dominant kernel (largest time per step) priced against the roofline that bounds it."""
+    """The dominant kernel (largest time per step) priced against the roofline that bounds it: the fp32 kernels sit
+    under the fp32 MFMA roof; every bf16-MFMA kernel of this path (K <= 1024) sits under the HBM roof.  `all` lists
+    every hot kernel with BOTH fractions against its own arithmetic dtype's peaks."""
     dom = max(kr, key=lambda k: kr[k]["sec"] * kr[k]["per_step"])
     v = kr[dom]
     allk = {k: {"ms": round(x["sec"] * 1e3, 3), "tflops": round(x["flop"] / x["sec"] / 1e12, 1),
-                "GBps": round(x["bytes"] / x["sec"] / 1e9, 0), "launches_per_step": x["per_step"], "mfma": x["mfma"]}
+                "GBps": round(x["bytes"] / x["sec"] / 1e9, 0), "launches_per_step": x["per_step"], "mfma": x["mfma"],
+                "frac_of_mfma_peak": round(x["flop"] / x["sec"] / 1e12 / MFMA_PEAK_TFLOPS[x["mfma"]], 4),
+                "frac_of_hbm_peak": round(x["bytes"] / x["sec"] / 1e9 / HBM_PEAK_GBPS, 4)}
             for k, x in kr.items()}
     if v["mfma"] == "f32":
         a = v["flop"] / v["sec"] / 1e12
-        return {"bound": "mfma", "kernel": dom, "achieved": a, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": a / FP32_MFMA_PEAK_TFLOPS, "traffic": None, "flop_per_launch": v["flop"],
+        return {"bound": "mfma", "kernel": dom, "achieved": a, "peak": MFMA_PEAK_TFLOPS["f32"], "unit": "TFLOP/s",
+                "frac": a / MFMA_PEAK_TFLOPS["f32"], "traffic": None, "flop_per_launch": v["flop"],
                 "sec_per_launch": v["sec"], "all": allk}
-    a = v["bytes"] / v["sec"] / 1e9              # bf16 GEMMs at K <= 1024 sit under the HBM roof
+    a = v["bytes"] / v["sec"] / 1e9
     return {"bound": "hbm", "kernel": dom, "achieved": a, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": a / HBM_PEAK_GBPS, "traffic": None, "bytes_per_launch": v["bytes"],
             "sec_per_launch": v["sec"], "all": allk}
@@ -184,32 +190,77 @@ def _cpu_model_name():
     return "unknown"
 
 
-def cpu_baseline(mode, sd, forecast_steps=300):
-    """The reference's CPU path (same torch layer stack -> aten::lstm -> oneDNN), bounded sample.  Coupled mode adds
-    the reference's step 2 as it runs it: one scipy odeint (LSODA) solve per window in a Python loop, single-threaded
-    by construction (06_lstm_ode_integration.py:372-401)."""
+def _time_cpu(fn, budget_s, min_iters=5, warmup=2):
+    """SURVEY.md §8d / BASELINE.md §3 protocol: `warmup` untimed calls, then >= `min_iters` timed calls (fewer only
+    when the budget is exhausted, never fewer than 2); returns the list of durations."""
+    t_start = time.perf_counter()
+    for _ in range(warmup):
+        fn()
+    ts = []
+    while len(ts) < min_iters:
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+        if len(ts) >= 2 and time.perf_counter() - t_start + ts[-1] > budget_s:
+            break
+    return ts
+
+
+def cpu_baseline(mode, sd, forecast_steps=300, H=128, budget_s=60.0):
+    """The reference's CPU path (same torch layer stack -> aten::lstm -> oneDNN), bounded sample, SURVEY.md §8d
+    protocol: 2 warm-ups, then min / median of >= 5 timed iterations (fewer only if the time budget runs out; the
+    count is recorded), at n = 1 thread and at the best of 8/16/32/64 threads (oneDNN's RNN primitive does not scale
+    to all host threads), for B = 32 and B = 256.  `value` = the best rate found (the number the GPU must beat).
+    Coupled mode adds the reference's step 2 as it runs it: one scipy odeint (LSODA) solve per window in a Python
+    loop, single-threaded by construction (06_lstm_ode_integration.py:372-401)."""
     from oracle import torch_cpu_path as TP
     from lstm_ode_bci_amd import synthetic as syn
+    import torch.nn as nn
     ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     m = TP.build(sd, C, H)
-    Bc = 128
-    x, y = syn.make_windows(Bc)
-    xt, yt = torch.from_numpy(x), torch.from_numpy(y)
-    t0 = time.perf_counter()
-    best, med, nthreads = 0.0, 0.0, 1
-    # oneDNN's RNN primitive does not scale to all host threads; keep the best thread count
+    t_all = time.perf_counter()
+    data = {Bc: syn.make_windows(Bc) for Bc in (32, 256)}
+    w = torch.tensor([1.0, 1.0])
+
+    def one(Bc):
+        xt, yt = torch.from_numpy(data[Bc][0]), torch.from_numpy(data[Bc][1])
+        if mode == "train":
+            def fn():
+                m.train()
+                m.zero_grad(set_to_none=True)
+                nn.functional.cross_entropy(m(xt), yt, weight=w).backward()
+        else:
+            def fn():
+                m.eval()
+                with torch.no_grad():
+                    m(xt, return_attention=True)
+        return fn
+
+    # thread count: quick probe at B = 32
+    probe = {}
     for nt in sorted({min(ncores, n) for n in (8, 16, 32, 64)}):
         torch.set_num_threads(nt)
-        if mode == "train":
-            b, md = TP.time_train_step(m, xt, yt, iters=2, warmup=1)
-        else:
-            b, md = TP.time_forward(m, xt, iters=3, warmup=1)
-        if b > best:
-            best, med, nthreads = b, md, nt
-    what = (f"fwd+bwd train-mode (dropout on, weighted CE), B={Bc}" if mode == "train"
-            else f"fwd eval-mode no_grad, B={Bc}") + ", best over 8/16/32/64 threads"
-    out = {"value": best, "median": med, "unit": "windows/s", "cores": nthreads, "kind": "port", "host_cpus": os.cpu_count(),
-           "cpu_model": _cpu_model_name()}
+        ts = _time_cpu(one(32), budget_s=budget_s / 12, min_iters=2, warmup=1)
+        probe[nt] = 32 / min(ts)
+    best_n = max(probe, key=probe.get)
+    table = {}
+    share = budget_s * 0.8 / 4
+    for nt, tag in ((best_n, "best_n"), (1, "n1")):
+        torch.set_num_threads(nt)
+        for Bc in (32, 256):
+            ts = _time_cpu(one(Bc), budget_s=share)
+            table[f"{tag}_B{Bc}"] = {"threads": nt, "batch": Bc, "iters": len(ts), "windows_per_s_min_time": Bc / min(ts),
+                                     "windows_per_s_median": Bc / float(np.median(ts))}
+    torch.set_num_threads(best_n)
+    bestk = max((k for k in table if k.startswith("best_n")), key=lambda k: table[k]["windows_per_s_min_time"])
+    best = table[bestk]["windows_per_s_min_time"]
+    what = (("fwd+bwd train-mode (dropout on, weighted CE)" if mode == "train" else "fwd eval-mode no_grad") +
+            f", H={H}, B=32 and 256, n=1 and n={best_n} threads (best of 8/16/32/64 probed at B=32), 2 warm-ups + "
+            f"{'/'.join(str(table[k]['iters']) for k in table)} timed iterations; value = best (min-time) rate, {bestk}")
+    out = {"value": best, "median": table[bestk]["windows_per_s_median"], "unit": "windows/s", "cores": best_n,
+           "kind": "port", "host_cpus": os.cpu_count(), "cpu_model": _cpu_model_name(),
+           "n1_value": max(table["n1_B32"]["windows_per_s_min_time"], table["n1_B256"]["windows_per_s_min_time"]),
+           "table": table, "thread_probe_B32": probe}
     if mode == "coupled":
         from oracle import restatement as R
         n = 256
@@ -221,16 +272,155 @@ def cpu_baseline(mode, sd, forecast_steps=300):
         out["ode_solves_per_s_1thread"] = ode_rate
         out["value"] = 1.0 / (1.0 / best + 1.0 / ode_rate)          # LSTM chunk loop, then the per-window ODE loop
         what += f" + {n} odeint solves of {forecast_steps} points on 1 thread"
-    out["sample"] = what + f"; torch {torch.__version__} CPU (oneDNN), {time.perf_counter() - t0:.1f}s wall"
+    out["sample"] = what + f"; torch {torch.__version__} CPU (oneDNN), {time.perf_counter() - t_all:.1f}s wall"
+    return out
+
+
+class Leg:
+    """One workload: model + inputs resident in HBM, a step() closure, and its JSON description."""
+
+    def __init__(self, dev, mode, precision, B, H, forecast_steps, world=1, rank=0, dist=None, api_level=False):
+        from lstm_ode_bci_amd import CognitiveStateODE, LSTMODEIntegration
+        from lstm_ode_bci_amd import synthetic as syn
+        self.mode, self.precision, self.B, self.H, self.world, self.dist = mode, precision, B, H, world, dist
+        self.forecast_steps, self.api_level, self.dev = forecast_steps, api_level, dev
+        self.model, self.sd = build_model(dev, H)
+        # rank r owns global windows [r*B, (r+1)*B): independent shards, no data-path collective
+        self.x_np, y_np = syn.make_windows(B, T, C, seed=syn.INPUT_SEED + rank)
+        self.x = torch.from_numpy(self.x_np).to(dev)
+        self.y = torch.from_numpy(y_np).to(dev)
+        self.integ = LSTMODEIntegration(self.model, CognitiveStateODE(), 0.5)
+        self.gather_buf = torch.empty((world * B, 2), device=dev) if world > 1 else None
+        if mode == "train":
+            # the reference's training-step body (04_lstm_model.py:482-512): fwd -> weighted CE -> bwd ->
+            # [data-parallel: all-reduce of the flat gradient] -> clip 1.0 + AdamW, all inside the timed step
+            from lstm_ode_bci_amd.training import FusedAdamW, WeightedCrossEntropy
+            self.criterion = WeightedCrossEntropy(torch.tensor([1.0, 1.0], device=dev)).to(dev)
+            self.opt = FusedAdamW(self.model.parameters(), lr=3e-4, weight_decay=1e-4)
+
+    def step(self):
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(self.precision == "mixed")):
+            self._step()
+
+    def _step(self):
+        from lstm_ode_bci_amd.sharding import all_reduce_flat_grad_
+        m = self.model
+        if self.mode == "train":
+            m.train()
+            self.opt.zero_grad()
+            loss = self.criterion(m(self.x), self.y)
+            loss.backward()
+            gscale = 1.0
+            if self.world > 1:
+                _, gscale = all_reduce_flat_grad_(self.opt.flat_grad)        # one 4.55 MB message
+            self.opt.step(clip_grad_norm=1.0, grad_scale=gscale)
+        elif self.mode == "fwd":
+            m.eval()
+            with torch.no_grad():
+                logits = m(self.x)
+                if self.world > 1:
+                    self.dist.all_gather_into_tensor(self.gather_buf, logits.contiguous())
+        elif self.api_level:
+            # the reference's contract: numpy in -> numpy out (06:346, 406), PCIe both ways inside the timed step
+            self.integ.predict_batch(self.x_np, forecast_steps=self.forecast_steps, batch_size=self.B, show_progress=False)
+        else:
+            traj, probs, pred = self.integ.predict_batch_device(self.x, forecast_steps=self.forecast_steps, batch_size=self.B)
+            if self.world > 1:
+                self.dist.all_gather_into_tensor(self.gather_buf, probs.contiguous())
+
+    def run(self, steps, warmup):
+        """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
+        for _ in range(warmup):
+            self.step()
+        if self.world > 1:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+        dt = time.perf_counter() - t0
+        if self.world > 1:
+            tt = torch.tensor([dt], device=self.dev, dtype=torch.float64)
+            self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    def describe(self, steps, warmup, dt, with_roofline=True):
+        mode, precision, B, H, world = self.mode, self.precision, self.B, self.H, self.world
+        value = world * B * steps / dt
+        mf = "f32" if precision == "fp32" else "bf16"
+        flop_per_window = gate_flop_fwd(H) * (3 if mode == "train" else 1)
+        res = {
+            "metric": {"train": "eeg_windows_per_sec_fwd_bwd", "fwd": "eeg_windows_per_sec_fwd",
+                       "coupled": "eeg_windows_per_sec_fwd_ode"}[mode],
+            "value": value, "unit": "windows/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": mf, "data": "synthetic",
+            "config": {"workload": f"BiLSTM({L}x{H})+attn {mode}, (T={T},C={C}) windows, B={B}/GPU, " +
+                                   ("fp32 exact-MFMA" if precision == "fp32" else
+                                    "bf16 gate GEMMs + fp32 recurrence/accumulate (autocast)")
+                                   + (f", RK4 ODE {self.forecast_steps} points" if mode == "coupled" else "")
+                                   + (", numpy in -> numpy out through predict_batch (PCIe inside the step)" if self.api_level else ""),
+                       "batch_per_gpu": B, "global_batch": world * B, "seq_len": T, "channels": C,
+                       "hidden": H, "layers": L, "mode": mode, "precision": precision,
+                       **({"step": "fwd + weighted CE + bwd + clip 1.0 + AdamW (04_lstm_model.py:482-512)"}
+                          if mode == "train" else {}),
+                       "collective": ("none" if world == 1 else
+                                      ("all_reduce(grads 4.55MB)" if mode == "train" else "all_gather(logits)"))},
+            # whole-step gate-GEMM rate against the dense MFMA peak of the arithmetic dtype the GEMMs run in
+            "gate_gemm_tflops_effective": value * flop_per_window / 1e12 / world,
+            "gate_gemm_mfma_dtype": mf,
+            "gate_gemm_frac_of_mfma_peak": value * flop_per_window / 1e12 / MFMA_PEAK_TFLOPS[mf] / world,
+        }
+        if with_roofline:
+            kr = kernel_roofline(self.dev, B, mode, precision, H)
+            roof = roofline_of(kr)
+            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # HBM bytes per launch from rocprofv3 --pmc
+            if os.path.exists(tpath):
+                try:
+                    roof["traffic"] = json.load(open(tpath)).get(f"{roof['kernel']}|{precision}|B{B}" + ("" if H == 128 else f"|H{H}"))
+                except Exception:
+                    pass
+            res["roofline"] = roof
+        return res
+
+    def free(self):
+        for a in ("model", "x", "y", "integ", "opt", "criterion", "gather_buf"):
+            if hasattr(self, a):
+                delattr(self, a)
+        torch.cuda.empty_cache()
+
+
+def extra_legs(dev, forecast_steps):
+    """Short legs over the BASELINE.json configurations the headline does not cover (N = 1 only)."""
+    specs = [
+        ("configs[1] fp32 forward, B=1024", dict(mode="fwd", precision="fp32", B=1024, H=128), 8, 3),
+        ("configs[3] coupled LSTM->ODE, B=4096, device-resident", dict(mode="coupled", precision="fp32", B=4096, H=128), 5, 2),
+        ("configs[3] coupled LSTM->ODE, B=4096, numpy in -> numpy out (predict_batch)",
+         dict(mode="coupled", precision="fp32", B=4096, H=128, api_level=True), 3, 1),
+        ("H=256 mixed training step, B=4096 (the reference's checkpoint size, 04:877)",
+         dict(mode="train", precision="mixed", B=4096, H=256), 5, 2),
+        ("configs[4] per-rank shard: forward, B=8192, fp32", dict(mode="fwd", precision="fp32", B=8192, H=128), 4, 2),
+        ("configs[4] per-rank shard: forward, B=8192, mixed", dict(mode="fwd", precision="mixed", B=8192, H=128), 5, 2),
+    ]
+    out = {}
+    for name, kw, steps, warmup in specs:
+        t0 = time.perf_counter()
+        leg = Leg(dev, forecast_steps=forecast_steps, **kw)
+        dt = leg.run(steps, warmup)
+        r = leg.describe(steps, warmup, dt, with_roofline=not kw.get("api_level", False))
+        r["leg_wall_s"] = round(time.perf_counter() - t0, 1)
+        leg.free()
+        out[name] = r
     return out
 
 
 def main():
-    global H, GATE_FLOP_FWD
     a = parse()
-    if a.hidden != H:
-        GATE_FLOP_FWD = GATE_FLOP_FWD * (a.hidden // 128) ** 2 if a.hidden % 128 == 0 else int(GATE_FLOP_FWD * (a.hidden / 128) ** 2)
-        H = a.hidden
+    H = a.hidden
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -253,102 +443,21 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from lstm_ode_bci_amd import CognitiveStateODE, LSTMODEIntegration
-    from lstm_ode_bci_amd import synthetic as syn
-
-    mode = a.mode or ("train" if have_backward() else "fwd")
+    default_run = a.mode is None and a.precision is None and a.batch == 4096 and H == 128
+    mode = a.mode or "train"
     precision = a.precision or ("mixed" if mode == "train" else "fp32")
-    B = a.batch
-    model, sd = build_model(dev)
-    # rank r owns global windows [r*B, (r+1)*B): independent shards, no data-path collective
-    x_np, y_np = syn.make_windows(B, T, C, seed=syn.INPUT_SEED + rank)
-    x = torch.from_numpy(x_np).to(dev)
-    y = torch.from_numpy(y_np).to(dev)
-    class_w = torch.tensor([1.0, 1.0], device=dev)
-    integ = LSTMODEIntegration(model, CognitiveStateODE(), 0.5)
-    gather_buf = torch.empty((world * B, 2), device=dev) if world > 1 else None
-    criterion = opt = None
-    if mode == "train":
-        # the reference's training-step body (04_lstm_model.py:482-512): fwd -> weighted CE -> bwd ->
-        # [data-parallel: all-reduce of the flat gradient] -> clip 1.0 + AdamW, all inside the timed step
-        from lstm_ode_bci_amd.sharding import all_reduce_flat_grad_
-        from lstm_ode_bci_amd.training import FusedAdamW, WeightedCrossEntropy
-        criterion = WeightedCrossEntropy(class_w).to(dev)
-        opt = FusedAdamW(model.parameters(), lr=3e-4, weight_decay=1e-4)
-
-    def step():
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(precision == "mixed")):
-            _step()
-
-    def _step():
-        if mode == "train":
-            model.train()
-            opt.zero_grad()
-            loss = criterion(model(x), y)
-            loss.backward()
-            _, gscale = all_reduce_flat_grad_(opt.flat_grad)        # one 4.55 MB message; no-op at N = 1
-            opt.step(clip_grad_norm=1.0, grad_scale=gscale)
-        elif mode == "fwd":
-            model.eval()
-            with torch.no_grad():
-                logits = model(x)
-                if world > 1:
-                    dist.all_gather_into_tensor(gather_buf, logits.contiguous())
-        else:
-            traj, probs, pred = integ.predict_batch_device(x, forecast_steps=a.forecast_steps, batch_size=B)
-            if world > 1:
-                dist.all_gather_into_tensor(gather_buf, probs.contiguous())
-
-    for _ in range(a.warmup):
-        step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    leg = Leg(dev, mode, precision, a.batch, H, a.forecast_steps, world, rank, dist)
+    dt = leg.run(a.steps, a.warmup)
 
     if rank == 0:
-        value = world * B * a.steps / dt
-        kr = kernel_roofline(dev, B, mode, precision)
-        roof = roofline_of(kr)
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # HBM bytes per launch from rocprofv3 --pmc
-        if os.path.exists(tpath) and H == 128:           # the committed PMC table is for the H = 128 kernels
-            try:
-                roof["traffic"] = json.load(open(tpath)).get(f"{roof['kernel']}|{precision}|B{B}")
-            except Exception:
-                pass
-        flop_per_window = GATE_FLOP_FWD * (3 if mode == "train" else 1)
-        res = {
-            "metric": {"train": "eeg_windows_per_sec_fwd_bwd", "fwd": "eeg_windows_per_sec_fwd",
-                       "coupled": "eeg_windows_per_sec_fwd_ode"}[mode],
-            "value": value, "unit": "windows/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if precision == "fp32" else "bf16", "data": "synthetic",
-            "config": {"workload": f"BiLSTM(3x128)+attn {mode}, (T=256,C=61) windows, B={B}/GPU, " + ("fp32 exact-MFMA" if precision == "fp32" else
-                                                       "bf16 gate GEMMs + fp32 recurrence/accumulate (autocast)")
-                                   + (f", RK4 ODE {a.forecast_steps} points" if mode == "coupled" else ""),
-                       "batch_per_gpu": B, "global_batch": world * B, "seq_len": T, "channels": C,
-                       "hidden": H, "layers": L, "mode": mode, "precision": precision,
-                       **({"step": "fwd + weighted CE + bwd + clip 1.0 + AdamW (04_lstm_model.py:482-512)"}
-                          if mode == "train" else {}),
-                       "collective": ("none" if world == 1 else
-                                      ("all_reduce(grads 4.55MB)" if mode == "train" else "all_gather(logits)"))},
-            "gate_gemm_tflops_effective": value * flop_per_window / 1e12,
-            "gate_gemm_frac_of_fp32_mfma_peak": value * flop_per_window / 1e12 / FP32_MFMA_PEAK_TFLOPS / world,
-            "roofline": roof,
-        }
+        res = leg.describe(a.steps, a.warmup, dt)
+        sd = leg.sd
+        leg.free()
+        if world == 1 and default_run and not a.no_extra:
+            res["extra_configs"] = extra_legs(dev, a.forecast_steps)
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(mode, sd, a.forecast_steps)
-            res["speedup_vs_cpu_baseline"] = value / res["cpu_baseline"]["value"]
+            res["cpu_baseline"] = cpu_baseline(mode, sd, a.forecast_steps, H)
+            res["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

@@ -156,8 +156,9 @@ class _LobModelFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits, _dattn):
         from .backward import backward_impl
-        gx, gps = backward_impl(ctx.sv, ctx.ps, ctx.cfg, ctx.x_shape, dlogits.contiguous().float(),
-                                ctx.needs_input_grad)
+        with ops.on_device(dlogits.device):
+            gx, gps = backward_impl(ctx.sv, ctx.ps, ctx.cfg, ctx.x_shape, dlogits.contiguous().float(),
+                                    ctx.needs_input_grad)
         need = ctx.needs_input_grad
         return (gx, None) + tuple(g if need[2 + i] else None for i, g in enumerate(gps))
 
@@ -190,9 +191,10 @@ def lob_forward(model, x, drops, seed):
     cfg = (model.num_layers, model.num_directions, model.hidden_size, tuple(float(d) for d in drops), int(seed),
            mixed)
     params = _collect(model)
+    ops.same_device([x] + params, "EnhancedLSTMModel.forward (input and parameters)")
     if not _PARAM_GRADS:
         params = [None if p is None else p.detach() for p in params]
-    with torch.autocast(device_type="cuda", enabled=False):
+    with ops.on_device(x.device), torch.autocast(device_type="cuda", enabled=False):
         return _LobModelFn.apply(x, cfg, *params)
 
 
@@ -201,6 +203,8 @@ def attention_forward(lstm_output, w1, b1, w2, b2):
     if not lstm_output.is_cuda:
         raise ops._lib.LobError("Attention.forward: input must be on the GPU")
     B, T, W = lstm_output.shape
-    v = _f32c(lstm_output).transpose(0, 1).contiguous().reshape(T * B, W)
-    u = ops.gemm_nt(v, _f32c(w1), _f32c(b1), act=ACT_TANH)
-    return ops.attn_pool_fwd(v, u, _f32c(w2).reshape(-1), _f32c(b2), T, B, B)
+    ops.same_device([lstm_output, w1, b1, w2, b2], "Attention.forward")
+    with ops.on_device(lstm_output.device):
+        v = _f32c(lstm_output).transpose(0, 1).contiguous().reshape(T * B, W)
+        u = ops.gemm_nt(v, _f32c(w1), _f32c(b1), act=ACT_TANH)
+        return ops.attn_pool_fwd(v, u, _f32c(w2).reshape(-1), _f32c(b2), T, B, B)

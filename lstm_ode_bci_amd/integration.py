@@ -15,10 +15,29 @@ from . import ops
 from .synthetic import RATE_KEYS
 
 
+_COPY_THREADS = 8
+_pool = None
+
+
+def _copy_pool():
+    global _pool
+    if _pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _pool = ThreadPoolExecutor(max_workers=_COPY_THREADS, thread_name_prefix="lob-h2d")
+    return _pool
+
+
 class LSTMODEIntegration:
-    #: windows per device pass.  ``predict_batch``'s ``batch_size`` argument is honoured as a
-    #: lower bound; results do not depend on the chunking (every window is independent).
+    #: windows per device pass.  By default ``predict_batch``'s ``batch_size`` (the reference's 512 "fits 24 GB"
+    #: value, 06:308) is only a LOWER bound: an MI355X pass of fewer than 4096 windows leaves CUs idle, and results
+    #: do not depend on the chunking (every window is independent).  ``respect_batch_size=True`` (per call) or
+    #: ``max_device_chunk = n`` (per object) make the caller's number a true upper bound -- a memory cap.
     min_device_chunk = 4096
+    max_device_chunk = None
+    #: the reference enters ``autocast()`` whenever CUDA is available (06:340, 349).  Here the default is the fp32
+    #: parity path (<= 1e-5 on probabilities); ``use_amp=True`` (per call) or this attribute select the mixed path
+    #: (bf16 MFMA inputs, fp32 accumulate / state), as the reference's GPU runs do.
+    use_amp = False
 
     def __init__(self, lstm_model, ode_model, coupling_strength=0.5):
         self.lstm_model = lstm_model
@@ -34,14 +53,28 @@ class LSTMODEIntegration:
         """(probs, attention) device tensors for a batch-first (B,T,C) array/tensor."""
         if isinstance(X, np.ndarray):
             X = torch.from_numpy(np.ascontiguousarray(X, dtype=np.float32))
-        X = X.to(self._device(), dtype=torch.float32)
-        logits, attention = self.lstm_model(X, return_attention=True)
-        return ops.softmax_rows(logits.contiguous()), attention
+        dev = self._device()
+        X = X.to(dev, dtype=torch.float32)
+        with ops.on_device(dev), torch.autocast("cuda", dtype=torch.bfloat16, enabled=bool(self._amp_now)):
+            logits, attention = self.lstm_model(X, return_attention=True)
+            return ops.softmax_rows(logits.float().contiguous()), attention
+
+    _amp_now = False
+
+    def _chunk(self, batch_size, respect_batch_size):
+        chunk = int(batch_size)
+        if chunk <= 0:
+            raise ValueError(f"batch_size must be positive, got {batch_size}")
+        if not respect_batch_size:
+            chunk = max(chunk, self.min_device_chunk)
+        if self.max_device_chunk is not None:
+            chunk = min(chunk, int(self.max_device_chunk))
+        return chunk
 
     def get_lstm_probabilities(self, X):
         """(probs (B,2) [P(open), P(closed)], attention (B,T)) as numpy (06:216-234)."""
         self.lstm_model.eval()
-        with torch.no_grad():
+        with torch.no_grad(), ops.on_device(self._device()):
             probs, attention = self._probs_device(X)
         return probs.cpu().numpy(), attention.cpu().numpy()
 
@@ -67,7 +100,7 @@ class LSTMODEIntegration:
     def predict_trajectory(self, X, initial_state=None, forecast_steps=10):
         """(trajectory (steps,3), probs (1,2), attention (1,T)) for one window (06:266-306)."""
         self.lstm_model.eval()
-        with torch.no_grad():
+        with torch.no_grad(), ops.on_device(self._device()):
             probs, attention = self._probs_device(X)
             if initial_state is None:
                 traj, _, _ = ops.ode_rk4(self._base_rates(), forecast_steps, 0.0, float(forecast_steps),
@@ -82,25 +115,89 @@ class LSTMODEIntegration:
         self.ode_model.params = self.base_params.copy()
         return traj[0].cpu().numpy(), probs.cpu().numpy(), attention.cpu().numpy()
 
-    def predict_batch_device(self, X_batch, forecast_steps=20, batch_size=512, want_traj=True):
-        """Device-resident result tensors: (traj (N,steps,3) f64 | None, probs (N,2) f32, pred (N,) i64)."""
+    def predict_batch_device(self, X_batch, forecast_steps=20, batch_size=512, want_traj=True, use_amp=None,
+                             respect_batch_size=False):
+        """Device-resident result tensors: (traj (N,steps,3) f64 | None, probs (N,2) f32, pred (N,) i64).
+        ``X_batch``: numpy array (host; uploaded chunk by chunk through pinned staging buffers, the copy of chunk
+        i+1 overlapping the LSTM pass of chunk i on a side stream) or a device tensor."""
         n = len(X_batch)
-        chunk = max(int(batch_size), self.min_device_chunk)
+        chunk = self._chunk(batch_size, respect_batch_size)
         self.lstm_model.eval()
-        probs_all = []
-        with torch.no_grad():
-            for i in range(0, n, chunk):
-                probs, _ = self._probs_device(X_batch[i:i + chunk])
-                probs_all.append(probs)
-            probs = torch.cat(probs_all, 0) if len(probs_all) > 1 else probs_all[0]
-            traj, _, pred = ops.ode_rk4(self._base_rates(), forecast_steps, 0.0, float(forecast_steps),
-                                        self._substeps(), probs=probs, alpha=self.coupling_strength,
-                                        want_traj=want_traj, want_pred=True)
+        dev = self._device()
+        self._amp_now = self.use_amp if use_amp is None else bool(use_amp)
+        try:
+            with torch.no_grad(), ops.on_device(dev):
+                probs_all = []
+                for Xc in self._device_chunks(X_batch, n, chunk, dev):
+                    probs, _ = self._probs_device(Xc)
+                    probs_all.append(probs)
+                probs = torch.cat(probs_all, 0) if len(probs_all) > 1 else probs_all[0]
+                traj, _, pred = ops.ode_rk4(self._base_rates(), forecast_steps, 0.0, float(forecast_steps),
+                                            self._substeps(), probs=probs, alpha=self.coupling_strength,
+                                            want_traj=want_traj, want_pred=True)
+        finally:
+            self._amp_now = False
         return traj, probs, pred
 
-    def predict_batch(self, X_batch, forecast_steps=20, batch_size=512, show_progress=True):
+    def _device_chunks(self, X_batch, n, chunk, dev):
+        """Chunks of X_batch as fp32 device tensors.  Host arrays go through two pinned staging buffers and a copy
+        stream: the H2D copy of chunk i+1 runs while chunk i is in the LSTM kernels (06:346 does a synchronous
+        ``torch.FloatTensor(X_batch[i:batch_end]).to(DEVICE)`` per chunk)."""
+        if torch.is_tensor(X_batch) and X_batch.is_cuda:
+            for i in range(0, n, chunk):
+                yield X_batch[i:i + chunk]
+            return
+        if torch.is_tensor(X_batch):
+            X_batch = X_batch.numpy()
+        shape = tuple(X_batch.shape[1:])
+        nb = min(chunk, n)
+        copy_stream = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        stage = [torch.empty((nb,) + shape, dtype=torch.float32).pin_memory() for _ in range(2)]
+        dbuf = [torch.empty((nb,) + shape, dtype=torch.float32, device=dev) for _ in range(2)]
+        done = [None, None]          # events: device buffer b may be overwritten (its consumer kernels finished)
+        starts = list(range(0, n, chunk))
+
+        pool = _copy_pool()
+
+        def upload(k):
+            b, i = k & 1, starts[k]
+            m = min(chunk, n - i)
+            # host-side cast + copy into pinned memory (float64 .npz arrays: half the PCIe bytes, 04:346), sliced
+            # over a few threads (numpy releases the GIL in copyto; one thread moves only ~5 GB/s)
+            dst = stage[b].numpy()
+            step = max(1, (m + _COPY_THREADS - 1) // _COPY_THREADS)
+            list(pool.map(lambda s: np.copyto(dst[s:min(m, s + step)], X_batch[i + s:i + min(m, s + step)],
+                                              casting="same_kind"), range(0, m, step)))
+            with torch.cuda.stream(copy_stream):
+                if done[b] is not None:
+                    copy_stream.wait_event(done[b])
+                dbuf[b][:m].copy_(stage[b][:m], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(copy_stream)
+            return ev, m
+        nxt = upload(0)
+        for k in range(len(starts)):
+            ev, m = nxt
+            main.wait_event(ev)
+            b = k & 1
+            if k + 1 < len(starts):
+                if k >= 1:
+                    # staging buffer (k+1)&1 was last read by the copy of chunk k-1: make sure that copy has finished
+                    prev_ev.synchronize()
+                prev_ev = ev
+                nxt = upload(k + 1)
+            yield dbuf[b][:m]
+            done[b] = torch.cuda.Event()
+            done[b].record(main)
+
+    def predict_batch(self, X_batch, forecast_steps=20, batch_size=512, show_progress=True, use_amp=None,
+                      respect_batch_size=False):
         """(trajectories (N,steps,3) f64, probs (N,2) f32, predictions (N,) int64) as numpy
-        (06:308-406).  ``show_progress`` is accepted and ignored (no per-sample loop to show)."""
-        traj, probs, pred = self.predict_batch_device(X_batch, forecast_steps, batch_size)
+        (06:308-406).  ``show_progress`` is accepted and ignored (no per-sample loop to show).  ``use_amp`` mirrors
+        the reference's flag of 06:340 (see the class attribute); ``respect_batch_size`` makes ``batch_size`` an
+        upper bound on the windows per device pass."""
+        traj, probs, pred = self.predict_batch_device(X_batch, forecast_steps, batch_size, use_amp=use_amp,
+                                                      respect_batch_size=respect_batch_size)
         self.ode_model.params = self.base_params.copy()
         return traj.cpu().numpy(), probs.cpu().numpy(), pred.cpu().numpy()

@@ -2,10 +2,10 @@
 HIP stream).  torch is plumbing here (allocator, streams); all arithmetic is in liblob.so."""
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 
 import numpy as np
-import os
 
 import torch
 
@@ -19,6 +19,31 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def on_device(device):
+    """Context manager for the high-level entry points: every lob_* launch goes to the CURRENT device on its current
+    stream, so a model that lives on cuda:1 while cuda:0 is current must be run under a device guard.  A no-op when
+    `device` is already current."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx == torch.cuda.current_device():
+        return contextlib.nullcontext()
+    return torch.cuda.device(idx)
+
+
+def same_device(tensors, what):
+    """All of `tensors` (None entries skipped) on one CUDA device, else LobError; returns that device."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.LobError(f"{what}: expected device tensors (the product path has no CPU fallback)")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise _lib.LobError(f"{what}: operands on different devices ({dev} and {t.device})")
+    return dev
+
+
 def _ptr(t):
     return C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())
 
@@ -28,6 +53,10 @@ def _chk(t, name, dtype=torch.float32):
         return
     if not t.is_cuda:
         raise _lib.LobError(f"{name}: expected a device tensor (the product path has no CPU fallback)")
+    if t.device.index != torch.cuda.current_device():
+        # the launch would go to the current device with another device's pointers: a memory fault or silent peer access
+        raise _lib.LobError(f"{name}: tensor lives on {t.device} but the current device is cuda:{torch.cuda.current_device()}"
+                            " (run the call under torch.cuda.device(...): the model / integration entry points do)")
     if t.dtype != dtype:
         raise _lib.LobError(f"{name}: expected {dtype}, got {t.dtype}")
     if not t.is_contiguous():

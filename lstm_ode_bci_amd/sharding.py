@@ -62,6 +62,35 @@ def predict_batch_sharded(integ, X_batch, forecast_steps=20, batch_size=512, gat
     return sharded_apply(X_batch, fn, group)
 
 
+def dp_assert_equal(values, group=None, what="value"):
+    """Every rank must hold the same tuple of integers (batches per epoch, ...): a data-parallel loop whose ranks run
+    different numbers of collectives hangs.  Gathers the tuples and raises the SAME ValueError on every rank if they
+    differ, so that no rank is left waiting in a collective."""
+    world = dist.get_world_size(group)
+    mine = [int(v) for v in values]
+    # device of the collective: the backend's (nccl needs device tensors)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    t = torch.tensor(mine, dtype=torch.int64, device=dev)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t, group=group)
+    allv = [tuple(int(x) for x in o.tolist()) for o in out]
+    if any(v != allv[0] for v in allv):
+        raise ValueError(f"data-parallel ranks disagree on {what}: {allv} (shard the loader evenly, "
+                         "e.g. with sharding.shard_bounds and drop the remainder)")
+    return allv[0]
+
+
+def dp_sum_(t, group=None):
+    """In-place sum of a small metrics tensor over the ranks (host tensors are routed through the backend's device)."""
+    if dist.get_backend(group) == "nccl" and not t.is_cuda:
+        d = t.to(torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(d, group=group)
+        t.copy_(d)
+    else:
+        dist.all_reduce(t, group=group)
+    return t
+
+
 def all_reduce_flat_grad_(flat_grad, group=None):
     """Sum the flat gradient buffer over the ranks in place and return ``(flat_grad, 1 / world)``: the factor is
     handed to ``FusedAdamW.step(grad_scale=...)`` so that the mean is taken inside the optimizer launch instead of

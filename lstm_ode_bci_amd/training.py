@@ -25,7 +25,7 @@ import torch.nn as nn
 
 from . import ops
 from .model import AblationLSTMModel
-from .sharding import all_reduce_flat_grad_
+from .sharding import all_reduce_flat_grad_, dp_assert_equal, dp_sum_
 
 
 # ---------------------------------------------------------------------------------------------
@@ -57,7 +57,8 @@ class WeightedCrossEntropy(nn.Module):
     def forward(self, logits, target):
         if not logits.is_cuda:
             raise ops._lib.LobError("WeightedCrossEntropy: logits must be on the GPU (no CPU fallback)")
-        with torch.autocast(device_type="cuda", enabled=False):
+        ops.same_device([logits, target, self.weight], "WeightedCrossEntropy (logits, target, class weights)")
+        with ops.on_device(logits.device), torch.autocast(device_type="cuda", enabled=False):
             loss, self.last_correct = _WeightedCEFn.apply(logits, target, self.weight)
         return loss
 
@@ -93,7 +94,7 @@ class FusedAdamW(torch.optim.Optimizer):
         ps = self.param_groups[0]["params"]
         if not ps or not all(p.is_cuda and p.dtype == torch.float32 for p in ps):
             raise ops._lib.LobError("FusedAdamW: fp32 parameters on the GPU (no CPU fallback)")
-        dev = ps[0].device
+        dev = ops.same_device(ps, "FusedAdamW (parameters)")
         self._offsets, total = [], 0
         for p in ps:
             self._offsets.append(total)
@@ -142,9 +143,10 @@ class FusedAdamW(torch.optim.Optimizer):
     def clip_grad_norm_(self, max_norm=1.0):
         """torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm) in place (04:501); returns the total norm
         as a device tensor."""
-        nsq = self.grad_norm_sq()
-        total = nsq.sqrt()
-        ops.clip_scale_(self.flat_grad, nsq, max_norm)
+        with ops.on_device(self.flat_grad.device):
+            nsq = self.grad_norm_sq()
+            total = nsq.sqrt()
+            ops.clip_scale_(self.flat_grad, nsq, max_norm)
         return total.reshape(())
 
     @torch.no_grad()
@@ -154,13 +156,14 @@ class FusedAdamW(torch.optim.Optimizer):
         if closure is not None:
             raise ValueError("FusedAdamW.step: closures are not supported")
         g = self.param_groups[0]
-        nsq = self.grad_norm_sq() if clip_grad_norm is not None else None
-        if nsq is None:
-            self._attach_grads()
-        self.step_count += 1
-        ops.adamw_(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.step_count, g["lr"],
-                   g["betas"], g["eps"], g["weight_decay"], normsq=nsq,
-                   max_norm=clip_grad_norm if clip_grad_norm is not None else 1.0, grad_scale=grad_scale)
+        with ops.on_device(self.flat_param.device):
+            nsq = self.grad_norm_sq() if clip_grad_norm is not None else None
+            if nsq is None:
+                self._attach_grads()
+            self.step_count += 1
+            ops.adamw_(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.step_count, g["lr"],
+                       g["betas"], g["eps"], g["weight_decay"], normsq=nsq,
+                       max_norm=clip_grad_norm if clip_grad_norm is not None else 1.0, grad_scale=grad_scale)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -221,6 +224,10 @@ def binary_f1(true, pred):
     tp = int(((pred == 1) & (true == 1)).sum())
     fp = int(((pred == 1) & (true == 0)).sum())
     fn = int(((pred == 0) & (true == 1)).sum())
+    return f1_from_counts(tp, fp, fn)
+
+
+def f1_from_counts(tp, fp, fn):
     return 0.0 if 2 * tp + fp + fn == 0 else 2 * tp / (2 * tp + fp + fn)
 
 
@@ -229,15 +236,31 @@ def _to_dev(t, dev):
 
 
 def train_model(model, train_loader, val_loader, y_train, epochs=100, learning_rate=3e-4, patience=15,
-                weight_decay=1e-4, warmup_epochs=5, gradient_accumulation_steps=4, use_amp=True, verbose=True):
+                weight_decay=1e-4, warmup_epochs=5, gradient_accumulation_steps=4, use_amp=True, verbose=True,
+                data_parallel=False, process_group=None):
     """``train_model`` of 04_lstm_model.py:406-596: same arguments, same ``(model, history)`` result, same
     arithmetic -- weighted CE / accumulation steps, clip at 1.0, AdamW, warm-up + cosine stepped per epoch,
     early stopping on validation F1.  ``use_amp`` selects the mixed path (bf16 autocast, no GradScaler).
 
     As in the reference the "best model" snapshot is a shallow ``state_dict().copy()`` (04:576), i.e. the model
-    that is returned carries the weights of the last epoch that ran."""
+    that is returned carries the weights of the last epoch that ran.
+
+    ``data_parallel=True`` (opt-in; the reference is single-process): one process per GPU, every rank passes ITS shard
+    of the data in ``train_loader`` / ``val_loader``.  All ranks then run the same number of optimizer steps (checked
+    up front: unequal batch counts raise on every rank), the flat gradient is all-reduced once per optimizer step, and
+    the epoch metrics -- including the validation F1 that drives early stopping -- are summed over the ranks, so every
+    rank takes the same stop decision and holds the same weights and history.  Without the flag no collective is
+    issued, whether or not a process group exists."""
     dev = next(model.parameters()).device
     start_time = time.time()
+    dp = bool(data_parallel)
+    if dp:
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("train_model(data_parallel=True) needs an initialised torch.distributed process group")
+        dp_assert_equal((len(train_loader), len(val_loader), int(gradient_accumulation_steps), int(epochs)),
+                        process_group, "batches per epoch (train, val), accumulation steps, epochs")
+
     criterion = WeightedCrossEntropy(class_weights_from_labels(y_train)).to(dev)
     optimizer = FusedAdamW(model.parameters(), lr=learning_rate, weight_decay=weight_decay)
     scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lambda e: warmup_cosine(e, warmup_epochs, epochs))
@@ -262,16 +285,22 @@ def train_model(model, train_loader, val_loader, y_train, epochs=100, learning_r
                 loss = criterion(outputs, yb) / acc_steps
             loss.backward()
             if (batch_idx + 1) % acc_steps == 0:
-                # data-parallel runs (one process per GPU, each with its own shard of the loader): one all-reduce of
-                # the flat gradient; single process: no-op
-                _, gscale = all_reduce_flat_grad_(optimizer.flat_grad)
+                # data-parallel: one all-reduce of the flat gradient; the mean over ranks is taken inside the
+                # optimizer launch (every rank's loss is the mean over ITS batch, as DistributedDataParallel does)
+                gscale = 1.0
+                if dp:
+                    _, gscale = all_reduce_flat_grad_(optimizer.flat_grad, process_group)
                 optimizer.step(clip_grad_norm=1.0, grad_scale=gscale)     # clip_grad_norm_(…, 1.0) + optimizer.step(), 04:501-502
                 optimizer.zero_grad()
             loss_sum += loss.detach() * (acc_steps * xb.size(0))
             correct += criterion.last_correct[0]
             total += yb.size(0)
-        train_loss = float(loss_sum) / total
-        train_acc = int(correct) / total
+        tm = torch.stack([loss_sum.double(), correct.double(), torch.tensor(float(total), device=dev, dtype=torch.float64)])
+        if dp:
+            dp_sum_(tm, process_group)
+        tm = tm.tolist()
+        train_loss = tm[0] / tm[2]
+        train_acc = int(tm[1]) / int(tm[2])
 
         model.eval()
         vloss = torch.zeros((), device=dev)
@@ -288,9 +317,16 @@ def train_model(model, train_loader, val_loader, y_train, epochs=100, learning_r
                 vtotal += yb.size(0)
                 vpreds.append(outputs.argmax(1))
                 vtrue.append(yb)
-        val_loss = float(vloss) / vtotal
-        val_acc = int(vcorrect) / vtotal
-        val_f1 = binary_f1(torch.cat(vtrue).cpu().numpy(), torch.cat(vpreds).cpu().numpy())
+        vt, vp = torch.cat(vtrue), torch.cat(vpreds)
+        vm = torch.stack([vloss.double(), vcorrect.double(), torch.tensor(float(vtotal), device=dev, dtype=torch.float64),
+                          ((vp == 1) & (vt == 1)).sum().double(), ((vp == 1) & (vt == 0)).sum().double(),
+                          ((vp == 0) & (vt == 1)).sum().double()])
+        if dp:                      # the stop decision below must be the same on every rank
+            dp_sum_(vm, process_group)
+        vm = vm.tolist()
+        val_loss = vm[0] / vm[2]
+        val_acc = int(vm[1]) / int(vm[2])
+        val_f1 = f1_from_counts(int(vm[3]), int(vm[4]), int(vm[5]))
 
         scheduler.step()
         current_lr = optimizer.param_groups[0]["lr"]

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
     text = open(os.path.join(ROOT, "include", "lob.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\bint\s+(lob_\w+)\s*\(", text)))
+    return sorted(set(re.findall(r"(?:\bint|const\s+char\s*\*)\s+(lob_\w+)\s*\(", text)))
 
 
 def test_library_builds_and_exports_every_declared_symbol():
@@ -25,7 +25,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
     lib.lob_version.restype = ctypes.c_int
-    assert lib.lob_version() >= 100
+    assert lib.lob_version() >= 200
 
 
 def test_python_binding_covers_the_header():

@@ -38,9 +38,13 @@ def test_cpu_baseline_leg_runs_and_describes_its_sample():
     import bench
     from lstm_ode_bci_amd import synthetic as syn
     sd = syn.make_state_dict(61, 128, 3, 2, True)
-    r = bench.cpu_baseline("coupled", sd, forecast_steps=20)
+    r = bench.cpu_baseline("coupled", sd, forecast_steps=20, budget_s=25.0)
     for k in CPU:
         assert k in r
     assert r["kind"] == "port" and r["unit"] == "windows/s" and r["cores"] >= 1
     assert r["value"] < r["lstm_windows_per_s"] and r["ode_solves_per_s_1thread"] > 0
     assert "odeint" in r["sample"] and "threads" in r["sample"]
+    # SURVEY.md §8d protocol: n = 1 and best-n, B = 32 and 256, iteration counts recorded
+    assert set(r["table"]) == {"best_n_B32", "best_n_B256", "n1_B32", "n1_B256"}
+    assert all(v["iters"] >= 2 for v in r["table"].values()) and r["table"]["n1_B32"]["threads"] == 1
+    assert r["n1_value"] > 0

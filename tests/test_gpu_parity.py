@@ -23,7 +23,7 @@ TOL = 1e-5
 def dev():
     assert torch.cuda.is_available(), "GPU tests need a GPU"
     from lstm_ode_bci_amd import _lib
-    assert _lib.lib().lob_version() >= 100
+    assert _lib.lib().lob_version() >= 200
     return torch.device("cuda:0")
 
 

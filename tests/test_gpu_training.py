@@ -18,7 +18,7 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 def dev():
     assert torch.cuda.is_available(), "GPU tests need a GPU"
     from lstm_ode_bci_amd import _lib
-    assert _lib.lib().lob_version() >= 100
+    assert _lib.lib().lob_version() >= 200
     return torch.device("cuda:0")
 
 

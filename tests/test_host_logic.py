@@ -44,8 +44,10 @@ def test_signatures_mirror_the_reference():
     assert list(inspect.signature(LSTMODEIntegration.__init__).parameters) == ["self", "lstm_model", "ode_model",
                                                                                "coupling_strength"]
     pb = inspect.signature(LSTMODEIntegration.predict_batch)
-    assert list(pb.parameters) == ["self", "X_batch", "forecast_steps", "batch_size", "show_progress"]
-    assert [p.default for p in list(pb.parameters.values())[2:]] == [20, 512, True]
+    # the reference's four arguments first, in order, with its defaults (06:308); the extra keywords have defaults
+    assert list(pb.parameters)[:5] == ["self", "X_batch", "forecast_steps", "batch_size", "show_progress"]
+    assert [p.default for p in list(pb.parameters.values())[2:5]] == [20, 512, True]
+    assert [p.default for p in list(pb.parameters.values())[5:]] == [None, False]       # use_amp, respect_batch_size
     pt = inspect.signature(LSTMODEIntegration.predict_trajectory)
     assert list(pt.parameters) == ["self", "X", "initial_state", "forecast_steps"]
     assert list(inspect.signature(CognitiveStateODE.solve).parameters)[:4] == ["self", "initial_state", "t_span",
@@ -211,3 +213,70 @@ def test_load_processed_sequences_formats(tmp_path):
     Xt, yt, Xv, yv, _, _ = load_processed_sequences(tmp_path / "b.npz")
     assert len(Xv) == 6 and len(Xt) == 34 and len(yv) == 6
     assert sorted(np.concatenate([Xt, Xv])[:, 0, 0].tolist()) == sorted(X[:, 0, 0].tolist())
+
+
+def test_batch_size_is_a_lower_bound_by_default_and_an_upper_bound_on_request():
+    """06:308 `batch_size`: the device pass is at least `min_device_chunk` windows unless the caller caps it."""
+    integ = LSTMODEIntegration.__new__(LSTMODEIntegration)
+    assert integ._chunk(512, False) == 4096 and integ._chunk(8192, False) == 8192
+    assert integ._chunk(512, True) == 512
+    integ.max_device_chunk = 1000
+    assert integ._chunk(512, False) == 1000 and integ._chunk(512, True) == 512 and integ._chunk(2048, True) == 1000
+    with pytest.raises(ValueError):
+        integ._chunk(0, False)
+
+
+def test_solve_rejects_the_rk45_branch_instead_of_ignoring_it():
+    """05:137-163 `method='solve_ivp'` is not provided: raising beats silently returning another accuracy."""
+    with pytest.raises(ValueError, match="solve_ivp"):
+        CognitiveStateODE().solve([0.6, 0.2, 0.2], (0, 20), 20, method="solve_ivp")
+
+
+class _FakeDev:
+    def __init__(self, index):
+        self.index, self.type = index, "cuda"
+
+    def __eq__(self, o):
+        return self.index == o.index
+
+    def __repr__(self):
+        return f"cuda:{self.index}"
+
+
+class _FakeTensor:
+    """Enough of a device tensor for the operand checks (no GPU in the CPU suite)."""
+    is_cuda, dtype = True, torch.float32
+
+    def __init__(self, index):
+        self.device = _FakeDev(index)
+
+    def is_contiguous(self):
+        return True
+
+
+def test_device_mismatch_raises_instead_of_launching(monkeypatch):
+    """Every lob_* launch goes to the current device: operands of another device, or of two devices, must raise
+    LobError before any pointer reaches a kernel (a model moved to cuda:1 while cuda:0 is current)."""
+    from lstm_ode_bci_amd import ops
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    ops._chk(_FakeTensor(0), "a")                                  # same device: fine
+    with pytest.raises(_lib.LobError, match="current device"):
+        ops._chk(_FakeTensor(1), "a")
+    with pytest.raises(_lib.LobError, match="different devices"):
+        ops.same_device([_FakeTensor(0), None, _FakeTensor(1)], "forward")
+    assert ops.same_device([_FakeTensor(1), None, _FakeTensor(1)], "forward").index == 1
+    with pytest.raises(_lib.LobError, match="no CPU fallback"):
+        ops.same_device([torch.zeros(2)], "forward")
+
+
+def test_library_identity_and_variant_table():
+    """lob_build_id() of the loaded library equals the hash of the sources next to it (a stale prebuilt .so is refused
+    at load time); the test-only variant table round-trips and rejects unknown indices."""
+    from lstm_ode_bci_amd import build as B
+    lib = _lib.lib()
+    assert lib.lob_build_id().decode() == B.source_id() == B.built_id()
+    assert lib.lob_debug_set_variant(999, 1) == -1 and lib.lob_debug_get_variant(-1) == -1
+    before = _lib.get_variant("GATE_WS")
+    with _lib.variant(GATE_WS=0, REC_BWD_DMA=0):
+        assert _lib.get_variant("GATE_WS") == 0 and _lib.get_variant("REC_BWD_DMA") == 0
+    assert _lib.get_variant("GATE_WS") == before and _lib.get_variant("REC_BWD_DMA") == 1
