@@ -1,0 +1,111 @@
+"""Multi-process readiness on a one-GPU box (``-m gpu``): the N > 1 product code with the REAL model.
+
+Two fresh child processes (tests/mp_gpu_worker.py), both on cuda:0, gloo backend: `predict_batch_sharded` (window
+shards + chunked, side-stream trajectory all-gather) must be bit-identical to one process, and one data-parallel
+training step -- per-rank shard, `all_reduce_flat_grad_`, `FusedAdamW(grad_scale=1/world)` -- must equal the
+single-process step on the concatenated batch.  A world-size-1 `nccl` run loads RCCL once and pushes the bench's two
+collectives through it (the 8-GPU curve itself is the driver's to measure).
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from lstm_ode_bci_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_ranks(world, backend, tmp_path):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), LOB_MP_BACKEND=backend, LOB_MP_OUT=str(tmp_path),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mp_gpu_worker.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=420)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o)
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    return [np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(world)]
+
+
+def _single_process_reference():
+    from lstm_ode_bci_amd import CognitiveStateODE, EnhancedLSTMModel, LSTMODEIntegration
+    from lstm_ode_bci_amd.training import FusedAdamW, WeightedCrossEntropy
+    dev = torch.device("cuda:0")
+    C, H, T, N, B = 61, 128, 32, 44, 40
+    sd = syn.make_state_dict(C, H, 3, 2, True)
+    m = EnhancedLSTMModel(C, H, 3, 2, 0.0, True)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m = m.to(dev).eval()
+    x, y = syn.make_windows(N, T, C, seed=21)
+    X = torch.from_numpy(x).to(dev)
+    integ = LSTMODEIntegration(m, CognitiveStateODE(), 0.5)
+    traj, probs, pred = integ.predict_batch_device(X, forecast_steps=12, batch_size=N)
+    ref = dict(traj=traj.cpu().numpy(), probs=probs.cpu().numpy(), pred=pred.cpu().numpy())
+    m.train()
+    opt = FusedAdamW(m.parameters(), lr=3e-4, weight_decay=1e-4)
+    crit = WeightedCrossEntropy(torch.tensor([0.7, 1.3])).to(dev)
+    yb = torch.from_numpy(y[:B]).to(dev)
+    # data-parallel semantics (as DistributedDataParallel): the MEAN over ranks of each rank's weighted-mean loss
+    from lstm_ode_bci_amd import sharding
+    opt.zero_grad()
+    for r in range(2):
+        lo, hi = sharding.shard_bounds(B, 2, r)
+        (crit(m(X[lo:hi]), yb[lo:hi]) / 2).backward()
+    ref["flat_grad_mean"] = opt.flat_grad.cpu().numpy().copy()
+    opt.step(clip_grad_norm=1.0)
+    ref["flat_param"] = opt.flat_param.cpu().numpy()
+    return ref
+
+
+def test_two_ranks_real_model_sharded_inference_and_dp_step(tmp_path):
+    ref = _single_process_reference()
+    ranks = _run_ranks(2, "gloo", tmp_path)
+    for r, d in enumerate(ranks):
+        # inference: pure data movement around independent windows -> bit-identical on every rank
+        assert np.array_equal(d["traj"], ref["traj"]), r
+        assert np.array_equal(d["probs"], ref["probs"]) and np.array_equal(d["pred"], ref["pred"]), r
+        assert np.array_equal(d["probs_no_traj"], ref["probs"]), r
+        assert d["gscale"] == 0.5
+    # the all-reduced gradient is the same buffer on both ranks, bit for bit
+    assert np.array_equal(ranks[0]["flat_grad_mean"], ranks[1]["flat_grad_mean"])
+    assert np.array_equal(ranks[0]["flat_param"], ranks[1]["flat_param"])
+    g, gr = ranks[0]["flat_grad_mean"], ref["flat_grad_mean"]
+    assert np.abs(g - gr).max() <= 2e-6 * np.abs(gr).max() + 1e-10          # fp32 summation order only
+    w, wr = ranks[0]["flat_param"], ref["flat_param"]
+    solid = np.abs(gr) > 1e-6 * np.abs(gr).max()        # Adam normalises: elements with a ~zero gradient amplify rounding noise
+    assert np.abs(w - wr)[solid].max() <= 2e-6, np.abs(w - wr)[solid].max()
+    assert np.abs(w - wr).max() <= 6.1e-4               # nothing moves by more than two steps of lr = 3e-4 even there
+
+
+def test_rccl_world_size_one_smoke(tmp_path):
+    """backend "nccl" IS RCCL on ROCm: initialise it, run the sharded predict, the gradient all-reduce and the bench's
+    all_gather_into_tensor through it on one rank."""
+    ref = _single_process_reference()
+    (d,) = _run_ranks(1, "nccl", tmp_path)
+    assert np.array_equal(d["traj"], ref["traj"]) and np.array_equal(d["probs"], ref["probs"])
+    assert d["gscale"] == 1.0 and np.array_equal(d["nccl_gather"], np.ones((4, 2), np.float32))

@@ -87,3 +87,66 @@ def test_flat_gradient_all_reduce_two_ranks():
         p.join(60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res)
+
+
+class _FakeInteg:
+    """Stand-in for LSTMODEIntegration on CPU tensors: same predict_batch_device contract, deterministic arithmetic."""
+    min_device_chunk = 3
+
+    def _chunk(self, batch_size, respect):
+        return max(int(batch_size), self.min_device_chunk)
+
+    def predict_batch_device(self, X, forecast_steps=20, batch_size=512, want_traj=True):
+        s = X.reshape(len(X), -1).double().sum(1)
+        traj = s[:, None, None] * torch.arange(1, forecast_steps * 3 + 1, dtype=torch.float64).reshape(1, forecast_steps, 3)
+        probs = torch.stack([torch.sigmoid(s), 1 - torch.sigmoid(s)], 1).float()
+        return (traj if want_traj else None), probs, (s > 0).long()
+
+
+def _pbs_worker(rank, world, port, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lstm_ode_bci_amd import sharding
+    X = torch.from_numpy(np.random.default_rng(1).standard_normal((n, 4, 3)).astype(np.float32))
+    integ = _FakeInteg()
+    ref = integ.predict_batch_device(X, 5, n)
+    ok = True
+    for want_traj in (True, False):
+        out = sharding.predict_batch_sharded(integ, X, forecast_steps=5, batch_size=2, gather_trajectories=want_traj)
+        ok &= (out[0] is None) == (not want_traj)
+        ok &= all(a is None or torch.equal(a, b) for a, b in zip(out, ref))
+    # control-flow helpers of the data-parallel train loop
+    try:
+        sharding.dp_assert_equal((4 + rank, 2), None, "batches")
+        raised = False
+    except ValueError:
+        raised = True
+    same = sharding.dp_assert_equal((4, 2), None, "batches") == (4, 2)
+    t = torch.tensor([1.0 + rank, 10.0], dtype=torch.float64)
+    sharding.dp_sum_(t)
+    ok &= raised and same and torch.equal(t, torch.tensor([3.0, 20.0], dtype=torch.float64))
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [11, 4, 1])
+def test_predict_batch_sharded_chunked_gather_and_dp_helpers(n):
+    """predict_batch_sharded (chunked trajectory gather, ragged shards, a rank with an exhausted / empty shard) is
+    bit-identical to one process; dp_assert_equal raises on EVERY rank when batch counts differ (so no rank is left
+    in a collective), dp_sum_ sums the epoch metrics that drive early stopping."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pbs_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)
