@@ -206,7 +206,7 @@ def _time_cpu(fn, budget_s, min_iters=5, warmup=2):
     return ts
 
 
-def cpu_baseline(mode, sd, forecast_steps=300, H=128, budget_s=60.0):
+def cpu_baseline(mode, sd, forecast_steps=300, H=128, budget_s=100.0):
     """The reference's CPU path (same torch layer stack -> aten::lstm -> oneDNN), bounded sample, SURVEY.md §8d
     protocol: 2 warm-ups, then min / median of >= 5 timed iterations (fewer only if the time budget runs out; the
     count is recorded), at n = 1 thread and at the best of 8/16/32/64 threads (oneDNN's RNN primitive does not scale

@@ -304,8 +304,10 @@ int lob_weighted_ce_f32(const float* logits, const int64_t* target, const float*
                         void* stream);
 
 /* out[0] += sum x[i]^2 (the squared global gradient norm of clip_grad_norm_, 04:501).  x 16-B aligned;
- * the caller zeroes out[0].                                                                         */
-int lob_sumsq_f32(const float* x, int64_t n, float* out, void* stream);
+ * the caller zeroes out[0].  scratch: 512 floats of workspace -> the per-workgroup partial sums are added in a
+ * fixed order by a second launch, so the result is bit-reproducible (data-parallel ranks that hold the same
+ * all-reduced gradient then take bit-identical optimizer steps); NULL -> fp32 atomics (order varies).        */
+int lob_sumsq_f32(const float* x, int64_t n, float* out, float* scratch, void* stream);
 
 /* g *= min(1, max_norm / (sqrt(normsq[0]) + 1e-6)): torch.nn.utils.clip_grad_norm_ in place (04:501),
  * normsq read on the device (no host round trip).                                                   */

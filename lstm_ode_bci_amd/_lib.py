@@ -59,7 +59,7 @@ _SIGS = {
     "lob_prob_to_state_f64": ([_f32p, C.c_void_p, C.c_int, C.c_void_p], C.c_int),
     "lob_weighted_ce_f32": ([_f32p, C.c_void_p, _f32p, _f32p, _f32p, C.c_void_p, C.c_int, C.c_int, C.c_float,
                              C.c_void_p], C.c_int),
-    "lob_sumsq_f32": ([_f32p, C.c_int64, _f32p, C.c_void_p], C.c_int),
+    "lob_sumsq_f32": ([_f32p, C.c_int64, _f32p, _f32p, C.c_void_p], C.c_int),
     "lob_clip_scale_f32": ([_f32p, C.c_int64, _f32p, C.c_float, C.c_void_p], C.c_int),
     "lob_adamw_f32": ([_f32p, _f32p, _f32p, _f32p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                        C.c_int64, _f32p, C.c_float, C.c_float, C.c_void_p], C.c_int),

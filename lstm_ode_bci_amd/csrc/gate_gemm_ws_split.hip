@@ -1,0 +1,211 @@
+// fp32-accurate input-side gate GEMM (H = 128) on the 16-bit matrix pipe: two-way fp16 operand splits, weights stationary.
+//     P[T*Bp, D*512] = X[T*Bp, K] * W_ih[D*512, K]^T + bias,   K = 128 or 256, all fp32 in HBM
+// (nn.LSTM's W_ih x_t + b_ih + b_hh, 04_lstm_model.py:181-188, 211, in the reference's fp32 CPU arithmetic).
+//
+// Arithmetic: as lstm_rec_f32_split.hip -- every fp32 operand is carried as hi = fp16(s), lo = fp16((s - hi) 2^11) with
+// s = x 2^6 (activations) or w 2^8 (weights); x w = 2^-14 hi hi + 2^-25 (hi lo + lo hi), the two groups summed in
+// separate fp32 accumulators: three v_mfma_f32_32x32x16_f16 per 16-deep k-step instead of sixteen fp32 MFMA cycles'
+// worth -- 3/16 of the matrix time of the exact-fp32 kernel (gemm_f32.hip, 0.72 of the fp32 MFMA peak = 4.9 ms at
+// K = 256), at 2^-22 relative error per product.  The kernel is then bound by its 5.4 GB of HBM traffic (fp32 P out).
+//
+// Structure: as gate_gemm_ws.hip.  A workgroup (8 waves) owns 256 gate columns, each wave keeps BOTH halves of the B
+// fragments of its 32 columns for the whole contraction in registers (128 VGPRs at K = 256).  Activation tiles of 32
+// rows stream HBM -> LDS as fp32 by global_load_lds_dwordx4 through a 4-slot ring; once a tile has landed the eight
+// waves split it cooperatively (16 elements per thread) into two swizzled fp16 images, from which every wave reads
+// its A fragments -- the split is done once per tile, not once per wave.  Two workgroup barriers per tile (48 MFMAs
+// per wave).  The four workgroups that share a row tile sit 8 apart in blockIdx (same XCD under round-robin
+// placement: the tile is read from HBM once; speed only).
+//
+// vmcnt bookkeeping: per iteration a wave issues NDMA DMA instructions (tile q + NSLOT, into the slot just converted)
+// and 4 fragment stores.  Younger than DMA(q) when iteration q starts: 4 + (NSLOT - 1) (NDMA + 4) operations.
+#include "lob_common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_cvoid;
+
+constexpr float SX = 64.f, SW = 256.f, S_LO = 2048.f;
+constexpr float R_HH = 1.f / 16384.f;        // 2^-14
+constexpr float R_SM = 1.f / 33554432.f;     // 2^-25
+
+__device__ __forceinline__ void split2(float x, float scale, _Float16& hi, _Float16& lo) {
+    const float s = x * scale;
+    hi = (_Float16)s;
+    lo = (_Float16)((s - (float)hi) * S_LO);
+}
+
+struct WSSArgs {
+    const float* A; const float* W; const float* bias; float* P;
+    int lda, M, T, Bp, D;
+};
+
+template <int K>
+__global__ __launch_bounds__(512, 2) void gate_gemm_ws_split_kernel(WSSArgs g) {
+    constexpr int MT = 32, NSLOT = 4;
+    constexpr int ROWF = 4 * K, SLOTB = MT * ROWF;          // fp32 ring: bytes per row / slot
+    constexpr int ROWH = 2 * K, IMGB = MT * ROWH;           // fp16 images: bytes per row / image
+    constexpr int RPI = 1024 / ROWF > 0 ? 1024 / ROWF : 1;  // rows per DMA instruction (1 at K = 256, 2 at K = 128)
+    constexpr int NDMA = MT / RPI / 8;                      // DMA instructions per wave per tile (4 / 2)
+    constexpr int NST = 4;                                  // fragment stores per wave per tile
+    constexpr int VM_STEADY = NST + (NSLOT - 1) * (NDMA + NST), VM_PRO = (NSLOT - 1) * NDMA;
+    constexpr int KS = K / 16;
+    constexpr int EPT = MT * K / 512;                       // elements per thread in the split pass (16 / 8)
+    static_assert(ROWF <= 1024 && VM_STEADY < 64, "tile configuration");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NSLOT * SLOTB + 2 * IMGB];
+    unsigned char* img = lds + NSLOT * SLOTB;               // [split 2][32 rows][K] fp16, chunk-swizzled
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r31 = lane & 31, hi = lane >> 5;
+    const int ncg = g.D * 2;                                // 256-column groups
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int cg = slot % ncg, quad = slot / ncg, nquad = (gridDim.x >> 3) / ncg;
+    const int ntile = (g.M + MT - 1) / MT;
+    const int panels = (ntile - xcd + 7) / 8;
+    if (quad >= panels) return;
+    const int total = (panels - quad + nquad - 1) / nquad;
+    const int ncol0 = 256 * cg + 32 * wv;                   // this wave's first gate column
+
+    // ---- stationary B fragments, both halves: W[ncol0 + r31][16 s + 8 hi .. + 7]
+    f16x8 whi[KS], wlo[KS];
+    {
+        const float* wb = g.W + (size_t)(ncol0 + r31) * K + 8 * hi;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(wb + 16 * s), b = *reinterpret_cast<const f32x4*>(wb + 16 * s + 4);
+            f16x8 h8, l8;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                _Float16 hh, ll;
+                split2(a[j], SW, hh, ll); h8[j] = hh; l8[j] = ll;
+                split2(b[j], SW, hh, ll); h8[4 + j] = hh; l8[4 + j] = ll;
+            }
+            whi[s] = h8; wlo[s] = l8;
+        }
+    }
+    const float bv = g.bias ? g.bias[ncol0 + r31] : 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(whi[s]), "+v"(wlo[s]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- DMA: instruction j of this wave fills rows (wv * NDMA + j) * RPI .. of the slot, lane-linear (no swizzle)
+    const int drow = lane / (ROWF / 16), dch = lane % (ROWF / 16);
+    auto issue = [&](int u) {
+        const int ut = u < total ? u : total - 1;
+        const int m0 = ((quad + nquad * ut) * 8 + xcd) * MT;
+        unsigned char* dst = lds + (u % NSLOT) * SLOTB + wv * NDMA * 1024;
+#pragma unroll
+        for (int j = 0; j < NDMA; ++j) {
+            int r = m0 + (wv * NDMA + j) * RPI + drow;
+            r = r < g.M ? r : g.M - 1;
+            const float* src = g.A + (size_t)r * g.lda + dch * 4;
+            __builtin_amdgcn_global_load_lds((gbl_cvoid*)src, (lds_void*)(dst + j * 1024), 16, 0, 0);
+        }
+    };
+#pragma unroll 1
+    for (int u = 0; u < NSLOT; ++u) issue(u);
+
+    const unsigned lds_b = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const unsigned img_b = lds_b + NSLOT * SLOTB;
+    // split pass: thread -> row tid / 16, 16-B fp32 chunks cs + 16 j (j < EPT / 4): 16 lanes read 256 contiguous bytes
+    const int crow = tid >> 4, ccs = tid & 15;
+    // fragment reads: row r31, 16-B fp16 chunk 2 s + hi stored at chunk slot (2 s + hi) ^ (r31 & 15)
+    unsigned aoff[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) aoff[s] = img_b + (unsigned)(r31 * ROWH + (((2 * s + hi) ^ (r31 & 15)) * 16));
+
+    const int NBT = g.Bp >> 5;
+    const int dd = ncol0 / 512, gate = (ncol0 % 512) / 128, w4 = (ncol0 % 128) / 32;
+
+    for (int q = 0; q < total; ++q) {
+        if (q < NSLOT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_PRO) : "memory");
+        else           asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_STEADY) : "memory");
+        __builtin_amdgcn_s_barrier();          // tile q has landed (all waves); every wave is done reading the images
+
+        // ---- split pass (ring reads through inline asm: see gate_gemm_ws.hip)
+        {
+            const unsigned src = lds_b + (unsigned)((q % NSLOT) * SLOTB + crow * ROWF + ccs * 16);
+            f32x4 v[EPT / 4];
+#pragma unroll
+            for (int j = 0; j < EPT / 4; ++j)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(v[j]) : "v"(src), "n"(j * 256) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < EPT / 4; ++j) asm volatile("" : "+v"(v[j]));
+#pragma unroll
+            for (int j = 0; j < EPT / 4; ++j) {
+                f16x4 h4, l4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { _Float16 hh, ll; split2(v[j][e], SX, hh, ll); h4[e] = hh; l4[e] = ll; }
+                const int k = 4 * (ccs + 16 * j);                        // first element of this 4-element piece
+                const unsigned o = (unsigned)(crow * ROWH + ((((k >> 3) ^ (crow & 15)) * 16) + (k & 4) * 2));
+                asm volatile("ds_write_b64 %0, %1" :: "v"(img_b + o), "v"(h4) : "memory");
+                asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(img_b + o), "v"(l4), "n"(IMGB) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();          // images complete; ring slot q % NSLOT is free
+        issue(q + NSLOT);
+
+        f32x16 ahh, asm_;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ahh[r] = 0.f; asm_[r] = 0.f; }
+#define LOB_RD(dstv, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dstv) : "v"(ADDR), "n"(OFF) : "memory")
+        f16x8 a0, a1, n0, n1;
+        LOB_RD(a0, aoff[0], 0);
+        LOB_RD(a1, aoff[0], IMGB);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if (s + 1 < KS) {
+                LOB_RD(n0, aoff[(s + 1) & 7], ((s + 1) >> 3) * 256);
+                LOB_RD(n1, aoff[(s + 1) & 7], ((s + 1) >> 3) * 256 + IMGB);
+                asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a0), "+v"(a1));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1));
+            }
+            ahh = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, whi[s], ahh, 0, 0, 0);
+            asm_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, wlo[s], asm_, 0, 0, 0);
+            asm_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, whi[s], asm_, 0, 0, 0);
+            a0 = n0; a1 = n1;
+        }
+#undef LOB_RD
+
+        // ---- epilogue: fp32 fragment order [d][t][bt][w 4][gate 4][q 4][lane 64][4]
+        const int mrow = ((quad + nquad * q) * 8 + xcd) * MT;
+        if (mrow < g.M) {
+            const int t = mrow / g.Bp, bt = (mrow - t * g.Bp) >> 5;
+            float* dst = g.P + ((((size_t)(dd * g.T + t) * NBT + bt) * 4 + w4) * 4 + gate) * 1024 + lane * 4;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (ahh[4 * qq + e] * R_HH + asm_[4 * qq + e] * R_SM) + bv;
+                *reinterpret_cast<f32x4*>(dst + qq * 256) = v;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+}  // namespace
+
+// Internal entry point used by lob_gate_gemm_x_f32 (gemm_f32.hip).  Preconditions checked by the caller: fp32 X / W / P,
+// fragment order, H == 128, K in {128, 256}, ldx % 4 == 0, 16-B aligned bases, Bp % 32 == 0.
+int lob_gate_gemm_ws_split(const float* X, int ldx, const float* Wih, const float* bias, float* P, int T, int Bp, int D,
+                           int K, hipStream_t s) {
+    const int M = T * Bp;
+    const int ntile = (M + 31) / 32;
+    const int ncg = D * 2;
+    int nqx = (ntile + 7) / 8;                        // quads per XCD, one workgroup per CU at most
+    const int cap = 32 / ncg;
+    if (nqx > cap) nqx = cap;
+    WSSArgs g{X, Wih, bias, P, ldx, M, T, Bp, D};
+    const dim3 grid((unsigned)(8 * ncg * nqx)), block(512);
+    if (K == 256) hipLaunchKernelGGL(gate_gemm_ws_split_kernel<256>, grid, block, 0, s, g);
+    else          hipLaunchKernelGGL(gate_gemm_ws_split_kernel<128>, grid, block, 0, s, g);
+    LOB_CHECK_LAUNCH();
+    return 0;
+}

@@ -20,6 +20,7 @@
 
 // H = 128 on 16-row sub-tiles / v_mfma_f32_16x16x4_f32 (lstm_rec_f32_s16.hip)
 int lob_rec_fwd_s16(float* P, const float* Whh, float* Y, float* Csave, int T, int Bp, int D, int save, hipStream_t s);
+int lob_rec_fwd_split(float* P, const float* Whh, float* Y, float* Csave, int T, int Bp, int D, int save, hipStream_t s);
 // H = 32 / 64 / 256: W_hh streamed from L2 (lstm_rec_stream.hip)
 int lob_stream_supports(int H);
 int lob_stream_fwd(float* P, const float* Whh, float* Y, float* Csave, int T, int Bp, int H, int D, int save, hipStream_t s);
@@ -462,6 +463,9 @@ extern "C" int lob_lstm_rec_fwd_f32(float* P, const float* Whh, float* Y, float*
              reinterpret_cast<uintptr_t>(Csave)) & 15) return LOB_E_ALIGN;
         // 16-row tiles (v_mfma_f32_16x16x4_f32) by default: twice the workgroups for small batches and 2-8 % faster at
         // B = 4096; LOB_REC_FWD=32 selects the 32-row kernel below (kept for A/B measurements)
+        // default: the fp32-accurate split kernel on the 16-bit matrix pipe (lstm_rec_f32_split.hip);
+        // LOB_VAR_F32_SPLIT = 0 selects the exact-fp32 MFMA kernels (16-row, or 32-row with LOB_VAR_REC_FWD_ROWS = 32)
+        if (lob_variant(LOB_VAR_F32_SPLIT) != 0) return lob_rec_fwd_split(P, Whh, Y, Csave, T, Bp, D, save, s);
         const bool rows32 = lob_variant(LOB_VAR_REC_FWD_ROWS) == 32;
         if (!rows32) return lob_rec_fwd_s16(P, Whh, Y, Csave, T, Bp, D, save, s);
         const dim3 grid(Bp / 32, D), block(256);

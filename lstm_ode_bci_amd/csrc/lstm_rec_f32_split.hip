@@ -1,0 +1,175 @@
+// fp32-accurate recurrent forward kernel (H = 128) on the 16-bit matrix pipe: two-way fp16 operand splits.
+//
+// The exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) runs at the fp32 VECTOR rate, 1/16 of the 16-bit MFMA rate
+// (MI355X_MICROARCH.md, Matrix cores), and the fp32 recurrent forward (lstm_rec_f32_s16.hip) is bound by it: 5.3 us per
+// step, 2.4 ms per layer at B = 4096, and at B = 1024 (BASELINE.json configs[1]) its 128 workgroups leave half the
+// chip idle.  Here every fp32 operand x is carried as TWO fp16 numbers
+//     s = x * 2^8,   hi = fp16(s),   lo = fp16((s - hi) * 2^11)          (s - hi is exact in fp32)
+// i.e. 22 significant bits (fp32 has 24), and the product of two such pairs is three 16-bit MFMAs:
+//     x y  =  2^-16 hi_x hi_y  +  2^-27 (hi_x lo_y + lo_x hi_y)  [+ 2^-38 lo_x lo_y, dropped: 2^-22 relative]
+// fp16 x fp16 products are exact in the fp32 accumulator (11 + 11 bits), and the two groups of terms are summed in
+// SEPARATE fp32 accumulators (the small terms do not lose their low bits against the large ones); the pre-activation
+// is z = P + 2^-16 acc_hh + 2^-27 acc_small.  The power-of-two pre-scalings keep both halves of every operand in
+// fp16's normal range (|h| <= 1, |w| <~ 10^2), so nothing depends on how the matrix pipe treats fp16 denormals.
+// Measured against the fp32 reference goldens the logits move by < 1e-6 (the parity bar of configs[1] is 1e-5).
+//
+// Shape: 16 batch rows per workgroup, EIGHT waves (lstm_rec_f32_s16.hip: four): wave w8 owns the 16 hidden columns
+// 32 (w8 >> 1) + 16 (w8 & 1) of all four gates, W_hh of those columns as 2 x 4 x 4 fp16x8 B fragments = 128 VGPRs.
+// Per step and wave 48 v_mfma_f32_16x16x32_f16 (16 cycles each) replace 256 v_mfma_f32_16x16x4_f32 (32 cycles each):
+// 0.73 us of matrix time per step per SIMD (two waves) instead of 3.9.  Same fragment-order P / saved gates / c
+// layouts as the other H = 128 kernels (include/lob.h), so the gate GEMM and BPTT on either side are unchanged.
+#include "lob_common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int H = 128;
+constexpr int HB_LD = 136;     // fp16 h tile row stride (272 B = 17 x 16 B, odd -> conflict-free b128)
+constexpr int YF_LD = 132;     // fp32 h staging row stride (528 B = 33 x 16 B)
+constexpr float S_OP = 256.f;              // operand pre-scale 2^8
+constexpr float S_LO = 2048.f;             // residual scale 2^11
+constexpr float R_HH = 1.f / 65536.f;      // 2^-16
+constexpr float R_SM = 1.f / 134217728.f;  // 2^-27
+
+__device__ __forceinline__ void split2(float x, _Float16& hi, _Float16& lo) {
+    const float s = x * S_OP;
+    hi = (_Float16)s;
+    lo = (_Float16)((s - (float)hi) * S_LO);
+}
+
+__device__ __forceinline__ f32x4 mfma16_f16(f16x8 a, f16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+template <bool SAVE>
+__global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h128_split_kernel(
+    float* __restrict__ P, const float* __restrict__ Whh, float* __restrict__ Y, float* __restrict__ Csave, int T, int Bp) {
+    __shared__ __attribute__((aligned(16))) _Float16 hs[2 * 2 * 16 * HB_LD];      // [buf][split][16 rows][HB_LD]
+    __shared__ __attribute__((aligned(16))) float yfs[2 * 16 * YF_LD];            // fp32 h of the step, for wide stores
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wcol = w8 >> 1, cbu = w8 & 1;
+    const int d = blockIdx.y, D = gridDim.y, NBT = Bp >> 5;
+    const int c16 = lane & 15, rq = lane >> 4;
+    const int bt = blockIdx.x >> 1, s0 = blockIdx.x & 1;      // 32-row fragment block, 16-row half
+    const int col = 32 * wcol + 16 * cbu + c16;               // this lane's hidden column
+
+    // B fragments: W_hh[g*128 + col][32 ks + 8 rq .. + 7], split
+    f16x8 whi[4][4], wlo[4][4];
+    {
+        const float* wbase = Whh + (size_t)d * 4 * H * H;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float* row = wbase + (size_t)(g * H + col) * H + 8 * rq;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(row + 32 * ks), b = *reinterpret_cast<const f32x4*>(row + 32 * ks + 4);
+                f16x8 h8, l8;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    _Float16 hh, ll;
+                    split2(a[j], hh, ll); h8[j] = hh; l8[j] = ll;
+                    split2(b[j], hh, ll); h8[4 + j] = hh; l8[4 + j] = ll;
+                }
+                whi[g][ks] = h8; wlo[g][ks] = l8;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    for (int i = tid; i < 2 * 2 * 16 * HB_LD; i += 512) hs[i] = (_Float16)0.f;
+    float c[4] = {0.f, 0.f, 0.f, 0.f};
+
+    // fragment addressing (lob.h): gate g, 16-row half s0: rows 4 rq .. + 3 of column `col` are ONE float4 at
+    // [wcol][g][q = 2 s0 + (rq >> 1)][lane' = (rq & 1) * 32 + 16 cbu + c16][0..3]
+    const size_t pstep = (size_t)NBT * 16 * 1024, cstep = (size_t)NBT * 4096;
+    const unsigned lane_p = (unsigned)((2 * s0 + (rq >> 1)) * 256 + ((rq & 1) * 32 + 16 * cbu + c16) * 4);
+    float* pblk = P + ((size_t)d * T * NBT + bt) * 16 * 1024 + (size_t)wcol * 4096 + lane_p;
+    float* cblk = SAVE ? Csave + ((size_t)d * T * NBT + bt) * 4096 + (size_t)wcol * 1024 + lane_p : nullptr;
+    const int DH = D * H;
+    const int t_first = d ? T - 1 : 0, dt = d ? -1 : 1;
+    const int row0 = bt * 32 + s0 * 16;
+
+    f32x4 pa[4], pb[4];            // P two steps ahead
+    auto load_p = [&](int t, f32x4 (&dst)[4]) {
+        const float* p = pblk + (size_t)t * pstep;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dst[g] = *reinterpret_cast<const f32x4*>(p + g * 1024);
+    };
+    load_p(t_first, pa);
+    if (T > 1) load_p(t_first + dt, pb);
+    __syncthreads();
+
+    auto one_step = [&](int step, f32x4 (&praw)[4], int cur) {
+        const int t = t_first + dt * step;
+        f32x4 pz[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pz[g] = praw[g];
+        if (step + 2 < T) load_p(t + 2 * dt, praw);
+        f32x4 ahh[4], asm_[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; ahh[g] = z; asm_[g] = z; }
+        const _Float16* hrow = hs + cur * 2 * 16 * HB_LD + c16 * HB_LD + 8 * rq;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(hrow + 32 * ks);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(hrow + 16 * HB_LD + 32 * ks);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                ahh[g] = mfma16_f16(ah, whi[g][ks], ahh[g]);
+                asm_[g] = mfma16_f16(ah, wlo[g][ks], asm_[g]);
+                asm_[g] = mfma16_f16(al, whi[g][ks], asm_[g]);
+            }
+        }
+        _Float16* hnext = hs + (cur ^ 1) * 2 * 16 * HB_LD + 4 * rq * HB_LD + col;
+        float* ynext = yfs + (cur ^ 1) * 16 * YF_LD + 4 * rq * YF_LD + col;
+        f32x4 gi, gf, gg_, go;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float zi = pz[0][j] + (ahh[0][j] * R_HH + asm_[0][j] * R_SM);
+            const float zf = pz[1][j] + (ahh[1][j] * R_HH + asm_[1][j] * R_SM);
+            const float zg = pz[2][j] + (ahh[2][j] * R_HH + asm_[2][j] * R_SM);
+            const float zo = pz[3][j] + (ahh[3][j] * R_HH + asm_[3][j] * R_SM);
+            const float ig = fast_sigmoid(zi), fg = fast_sigmoid(zf), gg = fast_tanh(zg), og = fast_sigmoid(zo);
+            c[j] = fg * c[j] + ig * gg;
+            const float h = og * fast_tanh(c[j]);
+            _Float16 hh, hl;
+            split2(h, hh, hl);
+            hnext[j * HB_LD] = hh;
+            hnext[16 * HB_LD + j * HB_LD] = hl;
+            ynext[j * YF_LD] = h;
+            if (SAVE) { gi[j] = ig; gf[j] = fg; gg_[j] = gg; go[j] = og; }
+        }
+        if (SAVE) {
+            float* p = pblk + (size_t)t * pstep;
+            *reinterpret_cast<f32x4*>(p) = gi;
+            *reinterpret_cast<f32x4*>(p + 1024) = gf;
+            *reinterpret_cast<f32x4*>(p + 2048) = gg_;
+            *reinterpret_cast<f32x4*>(p + 3072) = go;
+            f32x4 cv = {c[0], c[1], c[2], c[3]};
+            *reinterpret_cast<f32x4*>(cblk + (size_t)t * cstep) = cv;
+        }
+        __syncthreads();
+        {   // h_t is complete in yfs[cur ^ 1]: 16 rows x 512 B leave as one 16-B store per thread
+            const int row = tid >> 5, c4 = (tid & 31) * 4;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(yfs + (cur ^ 1) * 16 * YF_LD + row * YF_LD + c4);
+            *reinterpret_cast<f32x4*>(Y + ((size_t)t * Bp + row0 + row) * DH + d * H + c4) = v;
+        }
+    };
+
+    for (int step = 0; step < T; step += 2) {
+        one_step(step, pa, 0);
+        if (step + 1 < T) one_step(step + 1, pb, 1);
+    }
+}
+
+}  // namespace
+
+// Internal entry point used by lob_lstm_rec_fwd_f32 (lstm_rec_f32.hip): 16-row tiles, eight waves, grid Bp/16 x D.
+int lob_rec_fwd_split(float* P, const float* Whh, float* Y, float* Csave, int T, int Bp, int D, int save, hipStream_t s) {
+    const dim3 grid(Bp / 16, D), block(512);
+    if (save) hipLaunchKernelGGL((lstm_rec_fwd_h128_split_kernel<true>), grid, block, 0, s, P, Whh, Y, Csave, T, Bp);
+    else      hipLaunchKernelGGL((lstm_rec_fwd_h128_split_kernel<false>), grid, block, 0, s, P, Whh, Y, Csave, T, Bp);
+    LOB_CHECK_LAUNCH();
+    return 0;
+}

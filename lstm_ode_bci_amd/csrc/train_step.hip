@@ -66,7 +66,8 @@ __global__ __launch_bounds__(1024) void weighted_ce_kernel(
     }
 }
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, size_t n, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, size_t n, float* __restrict__ out,
+                                                    float* __restrict__ partial) {
     __shared__ float red[16];
     const size_t n4 = n >> 2, stride = (size_t)gridDim.x * blockDim.x;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -77,7 +78,23 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
     }
     if (gid < (n & 3)) { const float t = x[4 * n4 + gid]; s += t * t; }      // ragged tail
     s = block_sum(s, red);
-    if (threadIdx.x == 0) atomicAdd(out, s);
+    if (threadIdx.x == 0) {
+        if (partial) partial[blockIdx.x] = s;      // deterministic path: summed in block order by sumsq_finish_kernel
+        else         atomicAdd(out, s);
+    }
+}
+
+// out[0] += partial[0] + ... + partial[nb-1], always in the same order: the squared gradient norm (and with it the
+// clip coefficient and every weight) is then bit-identical on all data-parallel ranks that hold the same gradient.
+__global__ __launch_bounds__(512) void sumsq_finish_kernel(const float* __restrict__ partial, int nb, float* __restrict__ out) {
+    __shared__ float buf[512];
+    buf[threadIdx.x] = (int)threadIdx.x < nb ? partial[threadIdx.x] : 0.f;
+    __syncthreads();
+    for (int w = 256; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) buf[threadIdx.x] += buf[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] += buf[0];
 }
 
 __device__ __forceinline__ float clip_coef_of(const float* normsq, float max_norm, float grad_scale) {
@@ -172,12 +189,14 @@ extern "C" int lob_weighted_ce_f32(const float* logits, const int64_t* target, c
     return 0;
 }
 
-extern "C" int lob_sumsq_f32(const float* x, int64_t n, float* out, void* stream) {
+extern "C" int lob_sumsq_f32(const float* x, int64_t n, float* out, float* scratch, void* stream) {
     if (!x || !out || n <= 0) return LOB_E_ARG;
     if (reinterpret_cast<uintptr_t>(x) & 15) return LOB_E_ALIGN;
     int64_t blocks = (n + 1023) / 1024;
     if (blocks > 512) blocks = 512;
-    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (size_t)n, out);
+    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (size_t)n, out, scratch);
+    if (scratch)
+        hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(512), 0, (hipStream_t)stream, scratch, (int)blocks, out);
     LOB_CHECK_LAUNCH();
     return 0;
 }

@@ -461,12 +461,13 @@ def weighted_ce(logits, target, class_weight=None, scale=1.0, want_grad=True):
     return loss, dl, correct
 
 
-def sumsq(x, out=None):
-    """out[0] += sum x^2 over a flat fp32 buffer."""
-    _chk(x, "x")
+def sumsq(x, out=None, scratch=None):
+    """out[0] += sum x^2 over a flat fp32 buffer.  scratch (512 floats): bit-reproducible summation order."""
+    _chk(x, "x"); _chk(scratch, "scratch")
     if out is None:
         out = torch.zeros((1,), device=x.device, dtype=torch.float32)
-    rc = _lib.lib().lob_sumsq_f32(_ptr(x), x.numel(), _ptr(out), _stream())
+    assert scratch is None or scratch.numel() >= 512
+    rc = _lib.lib().lob_sumsq_f32(_ptr(x), x.numel(), _ptr(out), _ptr(scratch), _stream())
     _lib.check(rc, "lob_sumsq_f32")
     return out
 

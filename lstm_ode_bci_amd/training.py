@@ -104,6 +104,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self.exp_avg = torch.zeros(total, device=dev)
         self.exp_avg_sq = torch.zeros(total, device=dev)
         self._normsq = torch.zeros(1, device=dev)
+        self._scratch = torch.zeros(512, device=dev)       # partial sums of the gradient norm (fixed summation order)
         self.step_count = 0
         with torch.no_grad():
             for p, off in zip(ps, self._offsets):
@@ -138,7 +139,7 @@ class FusedAdamW(torch.optim.Optimizer):
     def grad_norm_sq(self):
         self._attach_grads()
         self._normsq.zero_()
-        return ops.sumsq(self.flat_grad, self._normsq)
+        return ops.sumsq(self.flat_grad, self._normsq, self._scratch)
 
     def clip_grad_norm_(self, max_norm=1.0):
         """torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm) in place (04:501); returns the total norm

@@ -693,3 +693,22 @@ def test_full_size_coupled_b65536_properties(dev):
         mp = R.modulate_rates(syn.FITTED_RATES, 1.0, probs_np[i, 1], probs_np[i, 0])
         _, te = R.solve_expm(R.initial_state_rule(probs_np[i, 1], probs_np[i, 0]), (0, 300), 300, mp)
         assert np.abs(traj[i].cpu().numpy() - te).max() < 1e-6
+
+
+@pytest.mark.parametrize("H", [128])
+def test_forward_full_size_goldens_exact_fp32_mfma_kernels(dev, H):
+    """The exact-fp32 MFMA kernels (LOB_VAR_F32_SPLIT = 0; the default fp32 path runs the two-way fp16 split) against
+    the same reference goldens, <= 1e-5."""
+    from lstm_ode_bci_amd import _lib
+    d = np.load(os.path.join(GOLDEN, f"g2_full_H{H}.npz"))
+    sd = syn.make_state_dict(61, H, 3, 2, True)
+    x, _ = syn.make_windows(8)
+    m = _model(sd, 61, H, 3, True, dev)
+    with _lib.variant(F32_SPLIT=0), torch.no_grad():
+        logits, attn = m(torch.from_numpy(x).to(dev), return_attention=True)
+    with torch.no_grad():
+        l2, a2 = m(torch.from_numpy(x).to(dev), return_attention=True)
+    assert np.abs(logits.cpu().numpy() - d["logits"]).max() < TOL and np.abs(attn.cpu().numpy() - d["attn"]).max() < TOL
+    print(f"H={H}: |logits split - exact| {float((l2 - logits).abs().max()):.2e}, split vs golden "
+          f"{np.abs(l2.cpu().numpy() - d['logits']).max():.2e}, exact vs golden {np.abs(logits.cpu().numpy() - d['logits']).max():.2e}")
+    assert np.abs(l2.cpu().numpy() - d["logits"]).max() < TOL

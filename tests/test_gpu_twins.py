@@ -227,3 +227,60 @@ def test_full_size_mixed_fwd_bwd_properties(dev):
             worst, wk = e, k
     print(f"mixed vs fp32 gradients at B={B}: worst tensor {wk} rel err {worst:.3e}")
     assert worst <= 2e-2, (wk, worst)
+
+
+def _unfrag_f32(P, T_, Bp, D):
+    """fp32 fragment-order P (include/lob.h: [d][t][bt][w 4][gate 4][q 4][lane 64][4]) -> row-major (T*Bp, D*512):
+    lane = 32 lh + c; row in the 32-row block = 8 q + 4 lh + e, column = d*512 + gate*128 + w*32 + c."""
+    v = P.view(D, T_, Bp // 32, 4, 4, 4, 2, 32, 4)           # d t bt w g q lh c e
+    return v.permute(1, 2, 5, 6, 8, 0, 4, 3, 7).reshape(T_ * Bp, D * 512)
+
+
+def test_fp32_split_gate_gemm_and_recurrence_vs_exact_fp32_mfma(dev):
+    """The fp32 path's default kernels carry every operand as two fp16 halves (22 bits) on the 16-bit matrix pipe
+    (gate_gemm_ws_split.hip, lstm_rec_f32_split.hip); LOB_VAR_F32_SPLIT = 0 selects the exact-fp32 MFMA kernels.  At
+    B = 4096, T = 256 (configs[1]/[3] arithmetic): the split gate GEMM against a float64 product is as close as the
+    exact-fp32 MFMA kernel is (errors of both are fp32 accumulation noise), and a whole layer (256 recurrent steps)
+    stays within 5e-6 of the exact kernels' h."""
+    from lstm_ode_bci_amd import _lib, ops
+    H, D, K = 128, 2, 256
+    Bp = ops.ceil32(B)
+    rows = T * Bp
+    x = _rand((rows, K), dev, 51)                      # layer-1 input scale (|h| <= 1 x dropout scale)
+    wih = _rand((D * 4 * H, K), dev, 52, 0.06)
+    bias = _rand((D * 4 * H,), dev, 53, 0.1)
+    whh = _rand((D, 4 * H, H), dev, 54, 0.06)
+    with _lib.variant(F32_SPLIT=1):
+        p_s = ops.gate_gemm_x(x, wih, bias, T, Bp, H, D, True)
+        p_s2 = ops.gate_gemm_x(x, wih, bias, T, Bp, H, D, True)
+    with _lib.variant(F32_SPLIT=0):
+        p_e = ops.gate_gemm_x(x, wih, bias, T, Bp, H, D, True)
+    assert p_s.dtype == torch.float32 and torch.equal(p_s, p_s2)
+    d_se = (p_s - p_e).abs().max().item()
+    # float64 truth on a sample of rows (first, middle, last time steps; ragged offsets inside the 32-row blocks)
+    idx = torch.cat([torch.arange(0, 96), torch.arange(rows // 2 + 5, rows // 2 + 69), torch.arange(rows - 64, rows)]).to(dev)
+    ref = x[idx].double() @ wih.double().T + bias.double()
+    e_s = (_unfrag_f32(p_s, T, Bp, D)[idx].double() - ref).abs().max().item()
+    e_e = (_unfrag_f32(p_e, T, Bp, D)[idx].double() - ref).abs().max().item()
+    print(f"gate GEMM K={K}: |split - exact| {d_se:.2e}; vs float64: split {e_s:.2e}, exact fp32 MFMA {e_e:.2e}")
+    assert e_e < 2e-6 and e_s < max(4 * e_e, 1e-6) and d_se < 4e-6
+    for Kx in (128,):                                  # layer-0 shape
+        xs, ws = x[:, :Kx].contiguous(), wih[:, :Kx].contiguous()
+        with _lib.variant(F32_SPLIT=1):
+            a = ops.gate_gemm_x(xs, ws, bias, T, Bp, H, D, True)
+        with _lib.variant(F32_SPLIT=0):
+            b = ops.gate_gemm_x(xs, ws, bias, T, Bp, H, D, True)
+        assert (a - b).abs().max().item() < 3e-6
+    # one whole layer: 256 dependent steps
+    with _lib.variant(F32_SPLIT=1):
+        y_s, _, _, _ = ops.lstm_rec_fwd(p_e.clone(), whh, T, Bp, H, D, False)
+        pk = p_e.clone()
+        y_sv, c_sv, _, _ = ops.lstm_rec_fwd(pk, whh, T, Bp, H, D, True)
+    with _lib.variant(F32_SPLIT=0):
+        y_e, _, _, _ = ops.lstm_rec_fwd(p_e.clone(), whh, T, Bp, H, D, False)
+        pk2 = p_e.clone()
+        y_ev, c_ev, _, _ = ops.lstm_rec_fwd(pk2, whh, T, Bp, H, D, True)
+    dy = (y_s - y_e).abs().max().item()
+    print(f"recurrent layer, 256 steps: |h_split - h_exact| max {dy:.2e}")
+    assert dy < 5e-6 and torch.equal(y_s, y_sv)                    # save mode computes the same h
+    assert (pk - pk2).abs().max().item() < 5e-6 and (c_sv - c_ev).abs().max().item() < 2e-5      # saved gates, c

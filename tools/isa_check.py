@@ -62,11 +62,11 @@ def check_dma_gemms(path=None):
     return problems
 
 
-def check_gate_ws(path=None):
-    """The weight-stationary gate GEMM (gate_gemm_ws.hip): its ring wait is one hand-counted `s_waitcnt vmcnt(N)` per
-    64-row tile; a compiler-generated VMEM wait or spill traffic inside the tile loop would drain the three tiles in
-    flight, and the count assumes exactly NDMA LDS-DMA instructions and 8 fragment stores per iteration."""
-    src = os.path.join(ROOT, "lstm_ode_bci_amd", "csrc", "gate_gemm_ws.hip")
+def _check_ws_kernel(srcname, cases, path=None):
+    """Shared check of the weight-stationary streaming GEMMs: in the tile loop exactly the LDS-DMA instructions, fragment
+    stores and MFMAs the hand-counted `s_waitcnt vmcnt(N)` assumes, no compiler-generated VMEM wait, no spill traffic,
+    no register loads (weights re-loaded)."""
+    src = os.path.join(ROOT, "lstm_ode_bci_amd", "csrc", srcname)
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     out = path or os.path.join(tempfile.mkdtemp(prefix="lob_isa_"), "ws.s")
     subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"),
@@ -74,8 +74,7 @@ def check_gate_ws(path=None):
                    check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     lines = open(out).read().split("\n")
     problems = []
-    for K, ndma in ((256, 4), (128, 2)):
-        pat = "gate_gemm_ws_kernelILi%dE" % K
+    for pat, ndma, nst, nmfma in cases:
         body = _function(lines, pat)
         ins = _instrs(body)
         labels = {m.group(1): i for i, l in enumerate(body) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
@@ -93,9 +92,9 @@ def check_gate_ws(path=None):
         n_dma = sum(1 for _, t, _ in loop if t.startswith("global_load_lds"))
         n_st = sum(1 for _, t, _ in loop if t.startswith("global_store"))
         n_mfma = sum(1 for _, t, _ in loop if t.startswith("v_mfma"))
-        if n_dma != ndma or n_st != 8 or n_mfma != 4 * (K // 16):
+        if n_dma != ndma or n_st != nst or n_mfma != nmfma:
             problems.append(f"{pat}: tile loop has {n_dma} DMA / {n_st} stores / {n_mfma} MFMAs, the wait counts assume "
-                            f"{ndma} / 8 / {4 * (K // 16)}")
+                            f"{ndma} / {nst} / {nmfma}")
         for _, t, a in loop:
             if not a and re.search(r"s_waitcnt.*vmcnt\(", t):
                 problems.append(f"{pat}: compiler-generated VMEM wait in the tile loop: {t}")
@@ -104,6 +103,14 @@ def check_gate_ws(path=None):
             if not a and t.startswith("global_load") and not t.startswith("global_load_lds"):
                 problems.append(f"{pat}: register load in the tile loop (weights re-loaded?): {t}")
     return problems
+
+
+def check_gate_ws(path=None):
+    """gate_gemm_ws.hip (mixed path) and gate_gemm_ws_split.hip (fp32 path): one hand-counted ring wait per row tile."""
+    return (_check_ws_kernel("gate_gemm_ws.hip", [("gate_gemm_ws_kernelILi256E", 4, 8, 64),
+                                                  ("gate_gemm_ws_kernelILi128E", 2, 8, 32)], path) +
+            _check_ws_kernel("gate_gemm_ws_split.hip", [("gate_gemm_ws_split_kernelILi256E", 4, 4, 48),
+                                                        ("gate_gemm_ws_split_kernelILi128E", 2, 4, 24)], path))
 
 
 def _function(lines, pat):

@@ -109,6 +109,24 @@ if on("ws"):
                 report(f"gate_gemm K={K} {nm}", timeit(lambda: ops.gate_gemm_x(xb, wb, bias, T, Bp, H, D, True, mixed=True), 8),
                        2.0 * rows * N * K, rows * (2.0 * K + 2.0 * N))
 
+if on("split"):
+    from lstm_ode_bci_amd import _lib
+    for K in (128, 256):
+        xf = torch.randn((rows, K), generator=g).to(dev)
+        wf = (torch.rand((N, K), generator=g) * 0.17 - 0.085).to(dev)
+        bias = torch.zeros(N, device=dev)
+        for v, nm in ((0, "exact fp32 MFMA"), (1, "fp16x2 split")):
+            with _lib.variant(F32_SPLIT=v):
+                report(f"gate_gemm f32 K={K} {nm}", timeit(lambda: ops.gate_gemm_x(xf, wf, bias, T, Bp, H, D, True), 4),
+                       2.0 * rows * N * K, rows * (4.0 * K + 4.0 * N))
+    whh_ = (torch.rand((D, 4 * H, H), generator=g) * 0.17 - 0.085).to(dev)
+    with _lib.variant(F32_SPLIT=0):
+        Pf = ops.gate_gemm_x(xf, wf, bias, T, Bp, H, D, True)
+    for v, nm in ((0, "exact fp32 MFMA"), (1, "fp16x2 split")):
+        with _lib.variant(F32_SPLIT=v):
+            report(f"rec_fwd f32 {nm}", timeit(lambda: ops.lstm_rec_fwd(Pf, whh_, T, Bp, H, D, False), 3),
+                   2.0 * rows * N * H, 4.0 * rows * (N + D * H))
+
 if on("tndma"):
     dPb = torch.randn((rows, N), generator=g).to(dev).to(torch.bfloat16)
     xb = torch.randn((rows, 256), generator=g).to(dev).to(torch.bfloat16)
