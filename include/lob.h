@@ -329,6 +329,25 @@ int lob_pad_cast_bf16(const float* in, void* out, int64_t rows, int C, int Cp, v
  * (07_explainability.py:257-258: X.grad[i].abs().mean(dim=0), summed over windows), gx [rows][C].    */
 int lob_abs_colsum_f32(const float* gx, int64_t rows, int C, float scale, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Derived weight images of one forward (+ backward) in ONE launch: what the reference's nn.LSTM / nn.Linear keep
+ * internally (cuDNN's packed weights, 04_lstm_model.py:181-188) and what this build's kernels take as operands --
+ * the two directions' W_ih concatenated, bf16 copies, transposes for the dX GEMMs, W_hh stacked, b_ih + b_hh.
+ * `ops` is a HOST array of `nop` <= LOB_PREP_MAX descriptors (copied into the kernel arguments):
+ *   dst[r][c] = src[r][c] (+ src2[r][c])          r < rows, c < cols; columns cols..pad_to-1 are written as 0
+ *   LOB_PREP_TRANSPOSE: dst[c][r] = src[r][c]     (no src2 / pad_to)
+ *   LOB_PREP_BF16: dst is bf16 (else fp32)
+ * ld_src / ld_dst are leading dimensions in elements.
+ * ---------------------------------------------------------------------------------- */
+#define LOB_PREP_MAX 64
+#define LOB_PREP_TRANSPOSE 1
+#define LOB_PREP_BF16 2
+typedef struct LobPrepOp {
+    const float* src; const float* src2; void* dst;
+    int rows, cols, ld_src, ld_dst, pad_to, kind, blk0 /* internal */, reserved;
+} LobPrepOp;
+int lob_prep_weights(const LobPrepOp* ops, int nop, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,7 +65,18 @@ _SIGS = {
                        C.c_int64, _f32p, C.c_float, C.c_float, C.c_void_p], C.c_int),
     "lob_pad_cast_bf16": ([_f32p, _f32p, C.c_int64, C.c_int, C.c_int, C.c_void_p], C.c_int),
     "lob_abs_colsum_f32": ([_f32p, C.c_int64, C.c_int, C.c_float, _f32p, C.c_void_p], C.c_int),
+    "lob_prep_weights": ([C.c_void_p, C.c_int, C.c_void_p], C.c_int),
 }
+
+
+class PrepOp(C.Structure):
+    """LobPrepOp of include/lob.h."""
+    _fields_ = [("src", C.c_void_p), ("src2", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int),
+                ("ld_src", C.c_int), ("ld_dst", C.c_int), ("pad_to", C.c_int), ("kind", C.c_int), ("blk0", C.c_int),
+                ("reserved", C.c_int)]
+
+
+PREP_MAX, PREP_TRANSPOSE, PREP_BF16 = 64, 1, 2
 
 
 class LobError(RuntimeError):

@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import torch
 
-from . import ops
+from . import images, ops
 from .ops import ACT_GELU, ACT_NONE, ACT_TANH, ceil32
 
 
@@ -57,6 +57,9 @@ def _forward_impl(x, ps, cfg, save):
     it = iter(ps)
     proj_w, proj_b, ln0_g, ln0_b = next(it), next(it), next(it), next(it)
     sv = {} if save else None
+    # every derived weight image (concatenations, bf16 copies, transposes, b_ih + b_hh) from one launch
+    img = images.build(ps, cfg, (B, T, C), save)
+    bf16 = torch.bfloat16
 
     # mixed mode: the windows as a padded bf16 operand (61 -> 64 columns: 16-B aligned rows) for the projection GEMM
     # and, in the backward, its weight gradient -- nn.Linear under autocast (04:174, 04:487); the fp32 kernels walk the
@@ -65,8 +68,10 @@ def _forward_impl(x, ps, cfg, save):
     if mixed and C % 8 != 0 and H % 8 == 0:
         Cp = (C + 7) // 8 * 8
         xb = ops.pad_cast_bf16(x2d, Cp)
-        wpad = torch.zeros((proj_w.shape[0], Cp), device=x.device, dtype=torch.float32)
-        wpad[:, :C] = proj_w
+        wpad = img.get("wpad")
+        if wpad is None:
+            wpad = torch.zeros((proj_w.shape[0], Cp), device=x.device, dtype=torch.float32)
+            wpad[:, :C] = proj_w
         pre = ops.gemm_nt(xb, wpad, proj_b, mixed=True)                      # (B*T, H), rows (b,t)
     else:
         pre = ops.gemm_nt(x2d, proj_w, proj_b)                               # (B*T, H), rows (b,t)
@@ -77,15 +82,17 @@ def _forward_impl(x, ps, cfg, save):
         sv["layers"] = []
     inp = a
     for layer in range(L):
-        dirs = [(next(it), next(it), next(it), next(it)) for _ in range(D)]
-        wih = torch.cat([d[0] for d in dirs], 0) if D > 1 else dirs[0][0]
-        whh = torch.stack([d[1] for d in dirs], 0)
-        bias = torch.cat([d[2] + d[3] for d in dirs], 0)
-        # bf16 x bf16 operands (bf16 activations from the layer below + a bf16 copy of the weights) take
-        # the LDS-DMA GEMM; everything else the register-staged kernels
-        w_in = wih.to(torch.bfloat16) if (inp.dtype == torch.bfloat16 and frag and
-                                          (ops.gate_ws_ok(inp.shape[1], H) or
-                                           ops.dma_ok(inp.shape[1], wih.shape[0], inp.shape[0]))) else wih
+        for _ in range(4 * D):
+            next(it)
+        wih, whh, bias = img[("wih", layer)], img[("whh", layer)], img[("bias", layer)]
+        # bf16 x bf16 operands (bf16 activations from the layer below + a bf16 copy of the weights) take the
+        # weight-stationary / LDS-DMA GEMMs; everything else the register-staged kernels
+        w_in = wih
+        if inp.dtype == bf16 and frag and (ops.gate_ws_ok(inp.shape[1], H) or
+                                           ops.dma_ok(inp.shape[1], wih.shape[0], inp.shape[0])):
+            w_in = img.get(("wih16", layer))
+            if w_in is None:
+                w_in = wih.to(bf16)
         P = ops.gate_gemm_x(inp, w_in, bias, T, Bp, H, D, frag, mixed=mixed)
         last = layer + 1 == L
         drop_here = not last and p_lstm > 0
@@ -106,7 +113,7 @@ def _forward_impl(x, ps, cfg, save):
             nxt = Y
         if save:
             sv["layers"].append({"inp": inp, "G": P, "C": Cs, "Y": Y16 if Y16 is not None else Y, "wih": wih,
-                                 "whh": whh, "fused_drop": fuse})
+                                 "whh": whh, "fused_drop": fuse, "wihT": img.get(("wihT", layer))})
         inp = nxt
     ln_g, ln_b = next(it), next(it)
     a0w, a0b, a2w, a2b = next(it), next(it), next(it), next(it)
@@ -117,8 +124,11 @@ def _forward_impl(x, ps, cfg, save):
         u = None
         ctx, attn = ops.attn_pool_fwd(v, None, None, None, T, B, Bp)
     else:
-        w1 = a0w.to(torch.bfloat16) if (v.dtype == torch.bfloat16 and
-                                        ops.dma_ok(v.shape[1], a0w.shape[0], v.shape[0])) else a0w
+        w1 = a0w
+        if v.dtype == bf16 and ops.dma_ok(v.shape[1], a0w.shape[0], v.shape[0]):
+            w1 = img.get("a0w16")
+            if w1 is None:
+                w1 = a0w.to(bf16)
         u = ops.gemm_nt(v, w1, a0b, act=ACT_TANH, mixed=mixed)               # (T*Bp, W/2)
         ctx, attn = ops.attn_pool_fwd(v, u, a2w.reshape(-1), a2b, T, B, Bp)
     if save:       # keep the pre-activations of the two classifier GELUs for their backward
@@ -135,7 +145,8 @@ def _forward_impl(x, ps, cfg, save):
     z2d = ops.dropout(z2, p_cls, _seed(seed, 21)) if p_cls > 0 else z2
     logits = ops.gemm_nt(z2d, c6w, c6b)
     if save:
-        sv.update(ylast=inp, v=v, u=u, ctx=ctx, attn=attn, z1p=z1p, z1d=z1d, z2p=z2p, z2d=z2d)
+        sv.update(ylast=inp, v=v, u=u, ctx=ctx, attn=attn, z1p=z1p, z1d=z1d, z2p=z2p, z2d=z2d,
+                  wT={k: img.get(k) for k in ("a0wT", "c0wT", "c3wT", "c6wT")})
     return logits, attn, sv
 
 

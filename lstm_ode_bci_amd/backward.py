@@ -18,15 +18,36 @@ def _t(w):
     return w.t().contiguous()
 
 
-def _linear_bwd(dy, x, w, need_dx=True, need_w=True, db=None):
-    """y = x w^T + b  ->  (dx, dw, db); db may be handed in when a producer of dy already summed its columns."""
+class _ZeroPool:
+    """Accumulation targets of the backward (weight-gradient GEMMs, bias / LayerNorm gradients: fp32 atomics into a
+    zeroed buffer) carved out of ONE zero-filled allocation: one fill launch instead of ~25."""
+    ALIGN = 64          # floats
+
+    def __init__(self, dev, capacity):
+        self.buf = torch.zeros(int(capacity), device=dev, dtype=torch.float32)
+        self.off = 0
+
+    def take(self, shape):
+        n = 1
+        for s in shape:
+            n *= int(s)
+        if self.off + n > self.buf.numel():
+            return torch.zeros(tuple(shape), device=self.buf.device, dtype=torch.float32)
+        out = self.buf[self.off:self.off + n].view(tuple(shape))
+        self.off += (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        return out
+
+
+def _linear_bwd(dy, x, w, need_dx=True, need_w=True, db=None, wt=None, pool=None):
+    """y = x w^T + b  ->  (dx, dw, db); db may be handed in when a producer of dy already summed its columns; wt is
+    the pre-built transpose of w (images.build)."""
     dw = None
     if need_w:
-        dw = torch.zeros_like(w)
+        dw = pool.take(w.shape) if pool is not None else torch.zeros_like(w)
         ops.gemm_tn(dy, x, dw)
         if db is None:
-            db = ops.colsum(dy)
-    dx = ops.gemm_nt(dy, _t(w)) if need_dx else None
+            db = ops.colsum(dy, pool.take((dy.shape[1],)) if pool is not None else None)
+    dx = ops.gemm_nt(dy, wt if wt is not None else _t(w)) if need_dx else None
     return dx, dw, db
 
 
@@ -43,64 +64,76 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad):
     need_w = any(needs_input_grad[2:])
     i_ln, i_a0w, i_a0b, i_a2w, i_a2b = n - 12, n - 10, n - 9, n - 8, n - 7
     i_c0w, i_c3w, i_c6w = n - 6, n - 4, n - 2
+    wT = sv.get("wT") or {}
+    # one zero-filled pool for every accumulation target (sized by the parameter count, with room for the padded /
+    # duplicated buffers); a fresh one per backward call, so retained-graph passes never share gradients
+    pool = _ZeroPool(dlogits.device, sum(p.numel() + 64 for p in ps if p is not None) + 8192) if need_w else None
+
+    def zeros(shape):
+        return pool.take(shape) if pool is not None else torch.zeros(tuple(shape), device=dlogits.device)
 
     # ---- classifier (04:196-204)
-    dz2d, g[i_c6w], g[i_c6w + 1] = _linear_bwd(dlogits, sv["z2d"], ps[i_c6w], need_w=need_w)
+    dz2d, g[i_c6w], g[i_c6w + 1] = _linear_bwd(dlogits, sv["z2d"], ps[i_c6w], need_w=need_w, wt=wT.get("c6wT"), pool=pool)
     dz2 = ops.dropout(dz2d, p_cls, _seed(seed, 21)) if p_cls > 0 else dz2d
     dz2p = ops.act_bwd(dz2, sv["z2p"], ACT_GELU)
-    dz1d, g[i_c3w], g[i_c3w + 1] = _linear_bwd(dz2p, sv["z1d"], ps[i_c3w], need_w=need_w)
+    dz1d, g[i_c3w], g[i_c3w + 1] = _linear_bwd(dz2p, sv["z1d"], ps[i_c3w], need_w=need_w, wt=wT.get("c3wT"), pool=pool)
     dz1 = ops.dropout(dz1d, p_cls, _seed(seed, 20)) if p_cls > 0 else dz1d
     dz1p = ops.act_bwd(dz1, sv["z1p"], ACT_GELU)
-    dctx, g[i_c0w], g[i_c0w + 1] = _linear_bwd(dz1p, sv["ctx"], ps[i_c0w], need_w=need_w)
+    dctx, g[i_c0w], g[i_c0w + 1] = _linear_bwd(dz1p, sv["ctx"], ps[i_c0w], need_w=need_w, wt=wT.get("c0wT"), pool=pool)
 
     # ---- attention pooling (04:123-128)
     v, u = sv["v"], sv["u"]
     a0w = ps[i_a0w]
     if a0w is None:          # mean pooling (09:236): dV = dctx / T, no parameters
         dV, _, _ = ops.attn_pool_bwd(v, None, sv["attn"], dctx, None, T, B, Bp)
-        pool = None
+        pool_ctx = None
     else:
         fused = v.dtype == torch.bfloat16        # mixed mode: bf16 v / dU, context path folded into the LN backward
         # the score MLP's first-bias gradient = column sums of dU: emitted by the pooling backward itself where it can
         cs_fused = need_w and ops.attn_bwd_fuses_colsum(v, u, not fused, fused)
-        du_cs = torch.zeros((u.shape[1],), device=u.device, dtype=torch.float32) if cs_fused else None
+        du_cs = zeros((u.shape[1],)) if cs_fused else None
         dV, dU, dw2 = ops.attn_pool_bwd(v, u, sv["attn"], dctx, ps[i_a2w].reshape(-1), T, B, Bp,
-                                        want_dv=not fused, du_bf16=fused, du_colsum=du_cs)
+                                        want_dv=not fused, du_bf16=fused, du_colsum=du_cs, dw2=zeros((u.shape[1],)))
         g[i_a2w] = dw2.reshape(1, -1)
-        g[i_a2b] = torch.zeros_like(ps[i_a2b])            # b2 cancels in the softmax: exactly 0
+        g[i_a2b] = zeros(ps[i_a2b].shape)                 # b2 cancels in the softmax: exactly 0
         if need_w:
-            g[i_a0w] = torch.zeros_like(a0w)
+            g[i_a0w] = zeros(a0w.shape)
             ops.gemm_tn(dU, v, g[i_a0w], mixed=mixed)
-            g[i_a0b] = du_cs if cs_fused else ops.colsum(dU)
+            g[i_a0b] = du_cs if cs_fused else ops.colsum(dU, zeros((dU.shape[1],)))
+        w1t = wT.get("a0wT")
         if fused:
-            w1t = _t(a0w)
-            if ops.dma_ok(dU.shape[1], w1t.shape[0], dU.shape[0]):
-                w1t = w1t.to(torch.bfloat16)
+            want16 = ops.dma_ok(dU.shape[1], a0w.shape[1], dU.shape[0])
+            if w1t is None or (w1t.dtype == torch.bfloat16) != want16:
+                w1t = _t(a0w).to(torch.bfloat16) if want16 else _t(a0w)
             dV = ops.gemm_nt(dU, w1t, mixed=mixed)                       # dU W1; + a[t] dctx is added below
-            pool = (sv["attn"], dctx, T, B, Bp)
+            pool_ctx = (sv["attn"], dctx, T, B, Bp)
         else:
-            ops.gemm_nt(dU, _t(a0w), out=dV, accumulate=True, mixed=mixed)
-            pool = None
+            if w1t is None or w1t.dtype != torch.float32:
+                w1t = _t(a0w)
+            ops.gemm_nt(dU, w1t, out=dV, accumulate=True, mixed=mixed)
+            pool_ctx = None
 
     # ---- post-LSTM LayerNorm (04:212)
-    dY, g[i_ln], g[i_ln + 1] = ops.layernorm_act_bwd(sv["ylast"], ps[i_ln], ps[i_ln + 1], dV, pool=pool)
+    dY, g[i_ln], g[i_ln + 1] = ops.layernorm_act_bwd(sv["ylast"], ps[i_ln], ps[i_ln + 1], dV, pool=pool_ctx, zeros=zeros)
 
     # ---- LSTM stack, last layer first (04:211)
     for layer in reversed(range(L)):
         lay = sv["layers"][layer]
         if layer + 1 < L and p_lstm > 0 and not lay["fused_drop"]:
             dY = ops.dropout(dY, p_lstm, _seed(seed, 10 + layer))
-        dP, dbias = ops.lstm_rec_bwd(lay["G"], lay["C"], lay["whh"], dY, T, Bp, H, D, dp_bf16=mixed)
+        dP, dbias = ops.lstm_rec_bwd(lay["G"], lay["C"], lay["whh"], dY, T, Bp, H, D, dp_bf16=mixed,
+                                     dbias=zeros((D * 4 * H,)))
         inp, Y, wih = lay["inp"], lay["Y"], lay["wih"]
         base = 4 + layer * 4 * D
         fused_dw = need_w and ops.can_fuse_dw(dP, inp, Y, T, Bp, H, D)
         if fused_dw:
-            dwih, dwhh_all = ops.lstm_dw(dP, inp, Y, T, Bp, H, D)
+            dwih, dwhh_all = ops.lstm_dw(dP, inp, Y, T, Bp, H, D, out=(zeros((D * 4 * H, inp.shape[1])), zeros((D, 4 * H, H))))
         elif need_w:
-            dwih = torch.zeros_like(wih)
+            dwih = zeros(wih.shape)
             ops.gemm_tn(dP, inp, dwih, mixed=mixed)
+        dbias2 = dbias.clone() if need_w else None        # b_ih and b_hh: equal gradients, distinct tensors (see below)
         for d in range(D if need_w else 0):
-            dwhh = dwhh_all[d] if fused_dw else torch.zeros_like(ps[base + 4 * d + 1])
+            dwhh = dwhh_all[d] if fused_dw else zeros(ps[base + 4 * d + 1].shape)
             if T > 1 and not fused_dw:
                 a_sl = dP[:, d * 4 * H:(d + 1) * 4 * H]
                 y_sl = Y[:, d * H:(d + 1) * H]
@@ -114,13 +147,14 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad):
             # then install one tensor as the .grad of both parameters, and an in-place clip_grad_norm_ (04:501) would
             # scale it twice
             g[base + 4 * d + 2] = dbias[d * 4 * H:(d + 1) * 4 * H]
-            g[base + 4 * d + 3] = dbias[d * 4 * H:(d + 1) * 4 * H].clone()
+            g[base + 4 * d + 3] = dbias2[d * 4 * H:(d + 1) * 4 * H]
         # dX of this layer = dY of the layer below; when that layer's output dropout was fused into its
         # producer, its backward (the same mask) is fused into this GEMM's epilogue
         below_fused = layer > 0 and sv["layers"][layer - 1]["fused_drop"]
-        wt = _t(wih)
-        if dP.dtype == torch.bfloat16 and ops.dma_ok(dP.shape[1], wt.shape[0], dP.shape[0]):
-            wt = wt.to(torch.bfloat16)                # bf16 x bf16 -> LDS-DMA kernel
+        want16 = dP.dtype == torch.bfloat16 and ops.dma_ok(dP.shape[1], wih.shape[1], dP.shape[0])
+        wt = lay.get("wihT")
+        if wt is None or (wt.dtype == torch.bfloat16) != want16:
+            wt = _t(wih).to(torch.bfloat16) if want16 else _t(wih)      # bf16 x bf16 -> LDS-DMA kernel
         dY = ops.gemm_nt(dP, wt, mixed=mixed, drop_p=p_lstm if below_fused else 0.0,
                          seed=_seed(seed, 10 + layer - 1))
         del dP
@@ -128,18 +162,18 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad):
     # ---- input projection: Linear -> LayerNorm -> GELU -> Dropout (04:173-178)
     # input_proj.0.bias gradient = column sums of dpre: emitted by the LayerNorm backward itself where it can
     db_fused = need_w and ops.can_fuse_colsum(sv["pre"].shape[1])
-    db0 = torch.zeros((sv["pre"].shape[1],), device=dY.device, dtype=torch.float32) if db_fused else None
+    db0 = zeros((sv["pre"].shape[1],)) if db_fused else None
     dpre, g[2], g[3] = ops.layernorm_act_bwd(sv["pre"], ps[2], ps[3], dY, act=ACT_GELU, remap=(T, B, Bp),
-                                             drop_p=p_in, seed=_seed(seed, 0), dx_colsum=db0)
+                                             drop_p=p_in, seed=_seed(seed, 0), dx_colsum=db0, zeros=zeros)
     if sv.get("xb") is not None and need_w:      # mixed: dW through the bf16 TN kernel on the padded bf16 windows
         xb = sv["xb"]
-        dwp = torch.zeros((ps[0].shape[0], xb.shape[1]), device=dY.device, dtype=torch.float32)
+        dwp = zeros((ps[0].shape[0], xb.shape[1]))
         ops.gemm_tn(dpre, xb, dwp, mixed=True)
         g[0] = dwp[:, :C].contiguous()
-        g[1] = db0 if db0 is not None else ops.colsum(dpre)
+        g[1] = db0 if db0 is not None else ops.colsum(dpre, zeros((dpre.shape[1],)))
         gx2d = ops.gemm_nt(dpre, _t(ps[0])) if needs_input_grad[0] else None
     else:
         gx2d, g[0], g[1] = _linear_bwd(dpre, sv["x2d"], ps[0], need_dx=bool(needs_input_grad[0]), need_w=need_w,
-                                       db=db0)
+                                       db=db0, pool=pool)
     gx = gx2d.reshape(B, T, C) if gx2d is not None else None
     return gx, g

@@ -142,10 +142,16 @@ def can_fuse_dw(dP, inp, Y, T, Bp, H, D):
             and dP.data_ptr() % 16 == 0 and inp.data_ptr() % 16 == 0 and Y.data_ptr() % 16 == 0)
 
 
-def lstm_dw(dP, inp, Y, T, Bp, H, D):
-    """(dW_ih (D*4H, nx), dW_hh (D, 4H, H)) fp32 from one pass over the bf16 gate gradients dP."""
-    dwih = torch.zeros((D * 4 * H, inp.shape[1]), device=dP.device, dtype=torch.float32)
-    dwhh = torch.zeros((D, 4 * H, H), device=dP.device, dtype=torch.float32)
+def lstm_dw(dP, inp, Y, T, Bp, H, D, out=None):
+    """(dW_ih (D*4H, nx), dW_hh (D, 4H, H)) fp32 from one pass over the bf16 gate gradients dP; out = zeroed (or
+    to-be-accumulated-into) destination pair."""
+    if out is not None:
+        dwih, dwhh = out
+        _chk(dwih, "dwih"); _chk(dwhh, "dwhh")
+        assert dwih.shape == (D * 4 * H, inp.shape[1]) and dwhh.shape == (D, 4 * H, H)
+    else:
+        dwih = torch.zeros((D * 4 * H, inp.shape[1]), device=dP.device, dtype=torch.float32)
+        dwhh = torch.zeros((D, 4 * H, H), device=dP.device, dtype=torch.float32)
     rc = _lib.lib().lob_lstm_dw_bf16(_ptr(dP), dP.stride(0), _ptr(inp), inp.stride(0), inp.shape[1], _ptr(Y),
                                      Y.stride(0), _ptr(dwih), _ptr(dwhh), T, Bp, H, D, _stream())
     _lib.check(rc, "lob_lstm_dw_bf16")
@@ -335,14 +341,16 @@ def ode_rk4(base_rates, n_points, t0, t1, substeps, *, probs=None, alpha=0.0, y0
 # ---------------------------------------------------------------------------------------------
 # backward-side wrappers
 # ---------------------------------------------------------------------------------------------
-def lstm_rec_bwd(G, Cs, whh, dY, T, Bp, H, D, dp_bf16=False):
-    """BPTT through one layer; returns (dP[T*Bp, D*4H] row-major fp32|bf16, dbias[D*4H])."""
+def lstm_rec_bwd(G, Cs, whh, dY, T, Bp, H, D, dp_bf16=False, dbias=None):
+    """BPTT through one layer; returns (dP[T*Bp, D*4H] row-major fp32|bf16, dbias[D*4H]); dbias: zeroed destination."""
     g16 = G.dtype == torch.bfloat16
     _chk(G, "G", G.dtype if g16 else torch.float32); _chk(Cs, "Csave"); _chk(whh, "whh"); _chk(dY, "dY")
     assert dY.shape == (T * Bp, D * H) and (not g16 or (dp_bf16 and bf16_rec(H, g16)))
     dP = torch.empty((T * Bp, D * 4 * H), device=G.device, dtype=torch.bfloat16 if dp_bf16 else torch.float32)
     fused_bias = uses_frag(H)
-    dbias = torch.zeros((D * 4 * H,), device=G.device, dtype=torch.float32)
+    if dbias is None:
+        dbias = torch.zeros((D * 4 * H,), device=G.device, dtype=torch.float32)
+    _chk(dbias, "dbias")
     if dp_bf16 and bf16_rec(H, g16):
         whht16 = None
         if H == 256:       # [D, ks 64, hi 2, j 8, w 8, l31 32] -> [D, w, ks, hi, l31, j]  (fragment order, lob.h)
@@ -387,7 +395,7 @@ def act_bwd(dy, pre, kind):
 
 
 def layernorm_act_bwd(x, gamma, beta, dy, act=ACT_NONE, eps=1e-5, remap=None, drop_p=0.0, seed=0, pool=None,
-                      dx_colsum=None):
+                      dx_colsum=None, zeros=None):
     """Returns (dx [rows,width] in INPUT row order, dgamma, dbeta).  pool=(attn [B,T], dctx [B,width], T, B, Bp)
     adds attn[b][t] * dctx[b] to dy on the fly (context path of the attention pooling).  dx_colsum [width]
     (widths 128/256/512): += column sums of dx (see ``can_fuse_colsum``)."""
@@ -399,8 +407,8 @@ def layernorm_act_bwd(x, gamma, beta, dy, act=ACT_NONE, eps=1e-5, remap=None, dr
         act = act | LN_IDENTITY
         dg = db = None
     else:
-        dg = torch.zeros_like(gamma)
-        db = torch.zeros_like(beta)
+        dg = zeros(gamma.shape) if zeros is not None else torch.zeros_like(gamma)
+        db = zeros(beta.shape) if zeros is not None else torch.zeros_like(beta)
     pa, pd, pT, pB, pBp = (None, None, 0, 0, 0) if pool is None else pool
     rc = _lib.lib().lob_layernorm_act_bwd_f32(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(dy), _ptr(dx), _ptr(dg), _ptr(db),
                                               rows, width, eps, act, rT, rB, rBp, float(drop_p), C.c_uint64(seed),
@@ -414,7 +422,7 @@ def can_fuse_colsum(width):
     return width in (128, 256, 512)
 
 
-def attn_pool_bwd(v, u, attn, dctx, w2, T, B, Bp, want_dv=True, du_bf16=False, du_colsum=None):
+def attn_pool_bwd(v, u, attn, dctx, w2, T, B, Bp, want_dv=True, du_bf16=False, du_colsum=None, dw2=None):
     """Returns (dV [T*Bp,W] fp32 or None, dPreU [T*Bp,W2] fp32|bf16, dw2 [W2]); pad rows are zero.
     want_dv=False: the direct term a[t]*dctx is left to layernorm_act_bwd(pool=...)."""
     v16 = v.dtype == torch.bfloat16
@@ -430,7 +438,8 @@ def attn_pool_bwd(v, u, attn, dctx, w2, T, B, Bp, want_dv=True, du_bf16=False, d
     W2 = u.shape[1]
     dV = alloc((T * Bp, W), device=v.device, dtype=torch.float32) if want_dv else None
     dU = alloc((T * Bp, W2), device=v.device, dtype=torch.bfloat16 if du_bf16 else torch.float32)
-    dw2 = torch.zeros((W2,), device=v.device, dtype=torch.float32)
+    if dw2 is None:
+        dw2 = torch.zeros((W2,), device=v.device, dtype=torch.float32)
     rc = _lib.lib().lob_attn_pool_bwd_f32(_ptr(v), int(v16), _ptr(u), _ptr(attn), _ptr(dctx), _ptr(w2), _ptr(dV),
                                           _ptr(dU), int(du_bf16), _ptr(dw2), _ptr(du_colsum), T, B, Bp, W, W2, _stream())
     _lib.check(rc, "lob_attn_pool_bwd_f32")
