@@ -36,6 +36,9 @@ extern "C" {
 #define LOB_ACT_TANH 1     /* nn.Tanh  (04_lstm_model.py:119)                        */
 #define LOB_ACT_GELU 2     /* nn.GELU, exact erf form (04_lstm_model.py:176,198,201) */
 #define LOB_ACCUMULATE 0x100  /* OR into `act` of lob_gemm_nt_f32: C += result instead of C = */
+#define LOB_OUT_BF16 0x400    /* OR into `act` of lob_gemm_nt_bf16 (bf16 x bf16 operands only) / lob_layernorm_act_bwd_f32:
+                               * the result C / dx is stored as bf16 (row-major, same leading dimension in elements)   */
+#define LOB_DY_BF16 0x800     /* OR into `act` of lob_layernorm_act_bwd_f32: dy is read as bf16                          */
 #define LOB_LN_IDENTITY 0x200 /* OR into `act` of lob_layernorm_act(_bwd)_f32: skip the normalisation and the
                                * affine (nn.Identity in place of nn.LayerNorm: the no-LayerNorm ablation,
                                * 09_sensitivity_analysis.py:190,209); gamma/beta/dgamma/dbeta may be NULL */
@@ -192,8 +195,11 @@ int lob_lstm_rec_fwd_bf16(void* P, int pg_bf16, const float* Whh, const void* Wh
  *   (04_lstm_model.py:186) fused into the producer.  In mixed mode the bf16 GEMMs of the next layer read
  *   Yd (or Y16 without dropout) and dW_hh reads Y16, so layers below the last never write fp32 Y.  */
 int lob_lstm_rec_bwd_bf16(const void* G, int pg_bf16, const float* Csave, const float* Whh, const void* WhhT16,
-                          const float* dY,
+                          const void* dY, int dy_bf16,
                           void* dP, float* dbias, int T, int Bp, int H, int D, void* stream);
+/*   dy_bf16 = 1 (H == 128, 16-row kernels): dY is stored as bf16 -- in the mixed path the gradient carried from layer
+ *   to layer (dX of the layer above, written by lob_gemm_nt_bf16 with LOB_OUT_BF16, or the LayerNorm backward's dx)
+ *   is a bf16 stream like dP; it is widened to fp32 on load and everything carried through time stays fp32.      */
 
 /* Element-wise activation and its backward (dx = dy * act'(pre)); classifier GELUs
  * (04_lstm_model.py:198, 201) in training mode.                                       */

@@ -51,6 +51,11 @@ def _linear_bwd(dy, x, w, need_dx=True, need_w=True, db=None, wt=None, pool=None
     return dx, dw, db
 
 
+def width_ok(w):
+    """Widths at which the LayerNorm backward reads / writes bf16 gradient streams."""
+    return w in (128, 256)
+
+
 def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad):
     if sv is None:
         raise RuntimeError("backward called on a forward that ran without grad tracking")
@@ -65,6 +70,10 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad):
     i_ln, i_a0w, i_a0b, i_a2w, i_a2b = n - 12, n - 10, n - 9, n - 8, n - 7
     i_c0w, i_c3w, i_c6w = n - 6, n - 4, n - 2
     wT = sv.get("wT") or {}
+    # mixed path, H = 128: the gradient between the LSTM layers / LayerNorms travels as bf16 (ops.DY_BF16_CARRY); it
+    # needs the fused dropout-backward epilogue of the dX GEMM (the stand-alone dropout kernel is fp32)
+    carry16 = ops.dy_bf16_ok(H, mixed) and all(l["fused_drop"] or p_lstm == 0 or i + 1 == L
+                                               for i, l in enumerate(sv["layers"]))
     # one zero-filled pool for every accumulation target (sized by the parameter count, with room for the padded /
     # duplicated buffers); a fresh one per backward call, so retained-graph passes never share gradients
     pool = _ZeroPool(dlogits.device, sum(p.numel() + 64 for p in ps if p is not None) + 8192) if need_w else None
@@ -105,7 +114,8 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad):
             want16 = ops.dma_ok(dU.shape[1], a0w.shape[1], dU.shape[0])
             if w1t is None or (w1t.dtype == torch.bfloat16) != want16:
                 w1t = _t(a0w).to(torch.bfloat16) if want16 else _t(a0w)
-            dV = ops.gemm_nt(dU, w1t, mixed=mixed)                       # dU W1; + a[t] dctx is added below
+            dV = ops.gemm_nt(dU, w1t, mixed=mixed,                       # dU W1; + a[t] dctx is added below
+                             out_bf16=carry16 and want16 and width_ok(sv["ylast"].shape[1]))
             pool_ctx = (sv["attn"], dctx, T, B, Bp)
         else:
             if w1t is None or w1t.dtype != torch.float32:
@@ -114,7 +124,8 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad):
             pool_ctx = None
 
     # ---- post-LSTM LayerNorm (04:212)
-    dY, g[i_ln], g[i_ln + 1] = ops.layernorm_act_bwd(sv["ylast"], ps[i_ln], ps[i_ln + 1], dV, pool=pool_ctx, zeros=zeros)
+    dY, g[i_ln], g[i_ln + 1] = ops.layernorm_act_bwd(sv["ylast"], ps[i_ln], ps[i_ln + 1], dV, pool=pool_ctx, zeros=zeros,
+                                                     dx_bf16=carry16 and width_ok(sv["ylast"].shape[1]))
 
     # ---- LSTM stack, last layer first (04:211)
     for layer in reversed(range(L)):
@@ -155,8 +166,10 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad):
         wt = lay.get("wihT")
         if wt is None or (wt.dtype == torch.bfloat16) != want16:
             wt = _t(wih).to(torch.bfloat16) if want16 else _t(wih)      # bf16 x bf16 -> LDS-DMA kernel
+        # the consumer of a bf16 dX: the BPTT kernel of the layer below, or (layer 0) the projection LayerNorm backward
+        dx16 = carry16 and want16 and (layer > 0 or width_ok(sv["pre"].shape[1]))
         dY = ops.gemm_nt(dP, wt, mixed=mixed, drop_p=p_lstm if below_fused else 0.0,
-                         seed=_seed(seed, 10 + layer - 1))
+                         seed=_seed(seed, 10 + layer - 1), out_bf16=dx16)
         del dP
 
     # ---- input projection: Linear -> LayerNorm -> GELU -> Dropout (04:173-178)

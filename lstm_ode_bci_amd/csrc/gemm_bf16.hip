@@ -420,10 +420,11 @@ void gemm_nt_dma_kernel(NTArgs g) {
                     for (int r = 0; r < 16; ++r) {
                         const int row = cm0 + 64 * wr + 32 * i + acc_row(r, lane);
                         if (row < g.M && col < g.N) {
-                            float* dst = g.C + (size_t)row * g.ldc + col;
                             float val = apply_act(acc[i][j][r] + bv, g.act);
                             if (g.drop_p > 0.f) val *= lob_dropout_scale(g.seed, (uint64_t)row * g.ldc + col, g.drop_p);
-                            *dst = val;      // no accumulate here: a read-modify-write would drain the DMA queue
+                            // no accumulate here: a read-modify-write would drain the DMA queue
+                            if (g.out_bf16) reinterpret_cast<__bf16*>(g.C)[(size_t)row * g.ldc + col] = (__bf16)val;
+                            else            g.C[(size_t)row * g.ldc + col] = val;
                         }
                         acc[i][j][r] = 0.f;
                     }
@@ -1040,11 +1041,13 @@ extern "C" int lob_gemm_nt_bf16(const void* A, int a_bf16, int lda, const void* 
     if (lda < K || ldw < K || ldc < N) return LOB_E_SHAPE;
     if ((act & 0xff) > LOB_ACT_GELU || act < 0) return LOB_E_ARG;
     if (!al16(A) || !al16(W) || (K % 8) || (lda % 8) || (ldw % 4)) return LOB_E_ALIGN;
+    const int out16 = (act & LOB_OUT_BF16) ? 1 : 0;
     NTArgs g{A, reinterpret_cast<const float*>(W), bias, C, lda, ldw, ldc, M, N, K, act & 0xff, (act >> 8) & 1,
-             0, 0, 0, 0, 0, drop_p, seed, 0};
+             0, 0, 0, 0, out16, drop_p, seed, 0};
     if (drop_p < 0.f || drop_p >= 1.f) return LOB_E_ARG;
+    if (out16 && !(a_bf16 && w_bf16)) return LOB_E_SHAPE;      // bf16 C: the LDS-DMA kernel's row-major epilogue only
     if (w_bf16) {      // both operands bf16 in HBM: LDS-DMA kernel (no bias / activation in its row-major epilogue)
-        if (!a_bf16 || (act >> 8) || N > 2048 || (K % DTK) || K / DTK < DS || (ldw % 8)) return LOB_E_SHAPE;
+        if (!a_bf16 || (act & LOB_ACCUMULATE) || N > 2048 || (K % DTK) || K / DTK < DS || (ldw % 8)) return LOB_E_SHAPE;
         launch_nt_dma<0>(g, (hipStream_t)stream);
         LOB_CHECK_LAUNCH();
         return 0;

@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_h128_bf16_kernel(
 // kernels of this file.
 int lob_rec_fwd_bf16_s16(void* P, int pg_bf16, const float* Whh, float* Y, float* Csave, void* Y16, void* Yd,
                          float drop_p, uint64_t seed, int T, int Bp, int D, int save, hipStream_t s);
-int lob_rec_bwd_bf16_s16(const void* G, int pg_bf16, const float* Csave, const float* Whh, const float* dY, void* dP,
+int lob_rec_bwd_bf16_s16(const void* G, int pg_bf16, const float* Csave, const float* Whh, const void* dY, int dy_bf16, void* dP,
                          float* dbias, int T, int Bp, int D, hipStream_t s);
 // H = 256: W_hh streamed from L2 (lstm_rec_h256_bf16.hip); bf16 P / saved gates only
 int lob_rec_fwd_h256_bf16(void* P, const void* Whh16, float* Y, float* Csave, void* Y16, void* Yd, float drop_p,
@@ -393,8 +393,12 @@ extern "C" int lob_lstm_rec_fwd_bf16(void* P, int pg_bf16, const float* Whh, con
 }
 
 extern "C" int lob_lstm_rec_bwd_bf16(const void* G, int pg_bf16, const float* Csave, const float* Whh, const void* WhhT16,
-                                     const float* dY, void* dP, float* dbias, int T, int Bp, int Hh, int D, void* stream) {
-    if (!G || !Csave || !Whh || !dY || !dP || T <= 0 || Bp <= 0 || (D != 1 && D != 2)) return LOB_E_ARG;
+                                     const void* dYv, int dy_bf16, void* dP, float* dbias, int T, int Bp, int Hh, int D,
+                                     void* stream) {
+    if (!G || !Csave || !Whh || !dYv || !dP || T <= 0 || Bp <= 0 || (D != 1 && D != 2)) return LOB_E_ARG;
+    // bf16 dY: the 16-row H = 128 kernels only
+    if (dy_bf16 && (Hh != 128 || !use_s16())) return LOB_E_SHAPE;
+    const float* dY = reinterpret_cast<const float*>(dYv);
     if (Hh == 256) {
         if (!pg_bf16 || (Bp % 32)) return LOB_E_SHAPE;
         if (!WhhT16) return LOB_E_ARG;
@@ -405,7 +409,7 @@ extern "C" int lob_lstm_rec_bwd_bf16(const void* G, int pg_bf16, const float* Cs
     if (Hh != 128 || (Bp % 32)) return LOB_E_SHAPE;
     if ((reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(Csave) |
          reinterpret_cast<uintptr_t>(dP)) & 15) return LOB_E_ALIGN;
-    if (use_s16()) return lob_rec_bwd_bf16_s16(G, pg_bf16, Csave, Whh, dY, dP, dbias, T, Bp, D, (hipStream_t)stream);
+    if (use_s16()) return lob_rec_bwd_bf16_s16(G, pg_bf16, Csave, Whh, dYv, dy_bf16, dP, dbias, T, Bp, D, (hipStream_t)stream);
     if (pg_bf16)
         hipLaunchKernelGGL((lstm_rec_bwd_h128_bf16_kernel<__bf16>), dim3(Bp / 32, D), dim3(256), 0, (hipStream_t)stream,
                            reinterpret_cast<const __bf16*>(G), Csave, Whh, dY, reinterpret_cast<__bf16*>(dP), dbias, T, Bp);

@@ -207,10 +207,10 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_fwd_h128_bf16_s16_kernel(
 // BPTT on 16-row tiles.  dgates are rounded to bf16 once: the LDS tile feeds the MFMA A operand AND is the dP
 // image copied to HBM.
 // ------------------------------------------------------------------------------------------
-template <typename PE>
+template <typename PE, typename DE>
 __global__ __launch_bounds__(256, 2) void lstm_rec_bwd_h128_bf16_s16_kernel(
     const PE* __restrict__ G, const float* __restrict__ Csave, const float* __restrict__ Whh,
-    const float* __restrict__ dY, __bf16* __restrict__ dP, float* __restrict__ dbias, int T, int Bp) {
+    const DE* __restrict__ dY, __bf16* __restrict__ dP, float* __restrict__ dbias, int T, int Bp) {
     __shared__ __attribute__((aligned(16))) __bf16 dgs[16 * DGB_LD];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_bwd_h128_bf16_s16_kernel(
     const unsigned lane_c = frag_lane<float>(rq, c16);     // c (always fp32)
     const int DH = D * H, D4H = D * 4 * H;
     const int row0 = bt * 32 + s0 * 16;
-    const float* dywave = dY + (size_t)row0 * DH + d * H + 32 * w;
+    const DE* dywave = dY + (size_t)row0 * DH + d * H + 32 * w;
     const unsigned dy_off = (unsigned)(4 * rq * DH + c16);
     const unsigned dp_off = (unsigned)((tid >> 6) * D4H + (tid & 63) * 8);
 
@@ -273,11 +273,11 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_bwd_h128_bf16_s16_kernel(
     auto load_step = [&](int t, Pre& s) {
         load_raw16(gwave + (size_t)t * gstep, lane_p, s.g);
         load_c(t + dt, s.cp);
-        const float* dp = dywave + (size_t)t * Bp * DH;
+        const DE* dp = dywave + (size_t)t * Bp * DH;
 #pragma unroll
         for (int cbu = 0; cbu < 2; ++cbu)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s.dy[cbu][j] = (dp + (size_t)j * DH + 16 * cbu)[dy_off];
+            for (int j = 0; j < 4; ++j) s.dy[cbu][j] = (float)(dp + (size_t)j * DH + 16 * cbu)[dy_off];
     };
     load_c(t_first, ct);
     load_step(t_first, pa);
@@ -356,10 +356,13 @@ typedef __attribute__((address_space(1))) const void gbl_cvoid;
 constexpr int RING_WAVE = 4096 + 2048;        // bytes per wave per slot: G (4 gates x 1 KB bf16) + c (2 KB fp32)
 constexpr int RING_SLOT = 4 * RING_WAVE;      // 24 KB
 
-template <int D>
+// DY16: the incoming gradient dY is stored as bf16 (the dX GEMM / LayerNorm backward above write it so): the eight
+// hand-issued loads per step become global_load_ushort (same count: the vmcnt bookkeeping is unchanged) and the
+// 16 bits are shifted into an fp32 after the wait.
+template <int D, bool DY16>
 __global__ __launch_bounds__(256, 2) void lstm_rec_bwd_h128_bf16_s16_dma_kernel(
     const __bf16* __restrict__ G, const float* __restrict__ Csave, const float* __restrict__ Whh,
-    const float* __restrict__ dY, __bf16* __restrict__ dP, float* __restrict__ dbias, int T, int Bp) {
+    const void* __restrict__ dYv, __bf16* __restrict__ dP, float* __restrict__ dbias, int T, int Bp) {
     __shared__ __attribute__((aligned(16))) __bf16 dgs[16 * DGB_LD];
     __shared__ __attribute__((aligned(1024))) unsigned char ring[2 * RING_SLOT];
     __shared__ float dbs[8 * 256];                 // bias-gradient partial sums, lane-private: [g][cbu][tid]
@@ -390,8 +393,9 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_bwd_h128_bf16_s16_dma_kernel(
     const unsigned lane_c = frag_lane<float>(rq, c16);        // element offset of this lane's c values
     constexpr int DH = D * H, D4H = D * 4 * H;
     const int row0 = bt * 32 + s0 * 16;
-    const float* dywave = dY + (size_t)row0 * DH + d * H + 32 * w;
-    const unsigned dy_off = (unsigned)(4 * rq * DH + c16);
+    constexpr int DYB = DY16 ? 2 : 4;                          // bytes per dY element
+    const char* dywave = reinterpret_cast<const char*>(dYv) + ((size_t)row0 * DH + d * H + 32 * w) * DYB;
+    const unsigned dy_off = (unsigned)(4 * rq * DH + c16) * DYB;
     const unsigned dp_off = (unsigned)((tid >> 6) * D4H + (tid & 63) * 8);
     const int t_first = d ? 0 : T - 1, dt = d ? 1 : -1;
 
@@ -432,24 +436,29 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_bwd_h128_bf16_s16_dma_kernel(
     // dY loads are issued by hand (inline asm), so that the compiler's own wait-count bookkeeping never sees a
     // pending register load in this loop -- it would drain the whole queue (vmcnt(0)) at the loop header.  The
     // matching wait is the s_waitcnt below, which names the registers so that no use can move above it.
-    const float* dylane = dywave + dy_off;
+    const char* dylane = dywave + dy_off;
     auto load_dy = [&](int u_, float (&dy)[2][4]) {
         const int u = u_ < T ? u_ : T - 1;
-        const float* dp = dylane + (size_t)(t_first + dt * u) * Bp * DH;
-        asm volatile(
-            "global_load_dword %0, %8, off offset:%9\n\t"
-            "global_load_dword %1, %8, off offset:%10\n\t"
-            "global_load_dword %2, %8, off offset:%11\n\t"
-            "global_load_dword %3, %8, off offset:%12\n\t"
-            "global_load_dword %4, %8, off offset:%13\n\t"
-            "global_load_dword %5, %8, off offset:%14\n\t"
-            "global_load_dword %6, %8, off offset:%15\n\t"
-            "global_load_dword %7, %8, off offset:%16"
-            : "=&v"(dy[0][0]), "=&v"(dy[0][1]), "=&v"(dy[0][2]), "=&v"(dy[0][3]),
-              "=&v"(dy[1][0]), "=&v"(dy[1][1]), "=&v"(dy[1][2]), "=&v"(dy[1][3])
-            : "v"(dp), "n"(0 * DH * 4), "n"(1 * DH * 4), "n"(2 * DH * 4), "n"(3 * DH * 4),
-              "n"(0 * DH * 4 + 64), "n"(1 * DH * 4 + 64), "n"(2 * DH * 4 + 64), "n"(3 * DH * 4 + 64)
-            : "memory");
+        const char* dp = dylane + (size_t)(t_first + dt * u) * Bp * DH * DYB;
+#define LOB_DY_LOADS(OP)                                                                                    \
+        asm volatile(                                                                                       \
+            OP " %0, %8, off offset:%9\n\t"                                                                 \
+            OP " %1, %8, off offset:%10\n\t"                                                                \
+            OP " %2, %8, off offset:%11\n\t"                                                                \
+            OP " %3, %8, off offset:%12\n\t"                                                                \
+            OP " %4, %8, off offset:%13\n\t"                                                                \
+            OP " %5, %8, off offset:%14\n\t"                                                                \
+            OP " %6, %8, off offset:%15\n\t"                                                                \
+            OP " %7, %8, off offset:%16"                                                                    \
+            : "=&v"(dy[0][0]), "=&v"(dy[0][1]), "=&v"(dy[0][2]), "=&v"(dy[0][3]),                           \
+              "=&v"(dy[1][0]), "=&v"(dy[1][1]), "=&v"(dy[1][2]), "=&v"(dy[1][3])                            \
+            : "v"(dp), "n"(0 * DH * DYB), "n"(1 * DH * DYB), "n"(2 * DH * DYB), "n"(3 * DH * DYB),          \
+              "n"(0 * DH * DYB + 16 * DYB), "n"(1 * DH * DYB + 16 * DYB), "n"(2 * DH * DYB + 16 * DYB),      \
+              "n"(3 * DH * DYB + 16 * DYB)                                                                  \
+            : "memory")
+        if constexpr (DY16) LOB_DY_LOADS("global_load_ushort");
+        else                LOB_DY_LOADS("global_load_dword");
+#undef LOB_DY_LOADS
     };
     load_dy(0, dya);
     dma_step(0);
@@ -463,6 +472,13 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_bwd_h128_bf16_s16_dma_kernel(
         asm volatile("s_waitcnt vmcnt(18)"
                      : "+v"(dy[0][0]), "+v"(dy[0][1]), "+v"(dy[0][2]), "+v"(dy[0][3]),
                        "+v"(dy[1][0]), "+v"(dy[1][1]), "+v"(dy[1][2]), "+v"(dy[1][3]) :: "memory");
+        if constexpr (DY16) {               // zero-extended bf16 bits -> fp32
+#pragma unroll
+            for (int cbu = 0; cbu < 2; ++cbu)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    dy[cbu][j] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, dy[cbu][j]) << 16);
+        }
         // ring reads through inline asm: an ordinary LDS read of a DMA target makes hipcc wait for ALL outstanding
         // DMAs (vmcnt(0)), i.e. also for the slot that is being filled for the step after next
         const unsigned ring_a = ring_base + (unsigned)((step & 1) * RING_SLOT);
@@ -572,25 +588,31 @@ int lob_rec_fwd_bf16_s16(void* P, int pg_bf16, const float* Whh, float* Y, float
     return 0;
 }
 
-int lob_rec_bwd_bf16_s16(const void* G, int pg_bf16, const float* Csave, const float* Whh, const float* dY, void* dP,
-                         float* dbias, int T, int Bp, int D, hipStream_t s) {
+int lob_rec_bwd_bf16_s16(const void* G, int pg_bf16, const float* Csave, const float* Whh, const void* dY, int dy_bf16,
+                         void* dP, float* dbias, int T, int Bp, int D, hipStream_t s) {
     const dim3 grid(Bp / 16, D), block(256);
     // LOB_VAR_REC_BWD_DMA = 0 selects the register-prefetch kernel (also the only one for fp32 saved gates)
     const bool dma = lob_variant(LOB_VAR_REC_BWD_DMA) != 0;
+    const __bf16* g16 = reinterpret_cast<const __bf16*>(G);
+    __bf16* dp16 = reinterpret_cast<__bf16*>(dP);
     if (pg_bf16 && dma) {
-        if (D == 2)
-            hipLaunchKernelGGL(lstm_rec_bwd_h128_bf16_s16_dma_kernel<2>, grid, block, 0, s,
-                               reinterpret_cast<const __bf16*>(G), Csave, Whh, dY, reinterpret_cast<__bf16*>(dP), dbias, T, Bp);
-        else
-            hipLaunchKernelGGL(lstm_rec_bwd_h128_bf16_s16_dma_kernel<1>, grid, block, 0, s,
-                               reinterpret_cast<const __bf16*>(G), Csave, Whh, dY, reinterpret_cast<__bf16*>(dP), dbias, T, Bp);
+#define LOB_BWD_DMA(DD, Y16) hipLaunchKernelGGL((lstm_rec_bwd_h128_bf16_s16_dma_kernel<DD, Y16>), grid, block, 0, s, \
+                                                g16, Csave, Whh, dY, dp16, dbias, T, Bp)
+        if (D == 2) { if (dy_bf16) LOB_BWD_DMA(2, true); else LOB_BWD_DMA(2, false); }
+        else        { if (dy_bf16) LOB_BWD_DMA(1, true); else LOB_BWD_DMA(1, false); }
+#undef LOB_BWD_DMA
     }
+    else if (pg_bf16 && dy_bf16)
+        hipLaunchKernelGGL((lstm_rec_bwd_h128_bf16_s16_kernel<__bf16, __bf16>), grid, block, 0, s,
+                           g16, Csave, Whh, reinterpret_cast<const __bf16*>(dY), dp16, dbias, T, Bp);
     else if (pg_bf16)
-        hipLaunchKernelGGL((lstm_rec_bwd_h128_bf16_s16_kernel<__bf16>), grid, block, 0, s,
-                           reinterpret_cast<const __bf16*>(G), Csave, Whh, dY, reinterpret_cast<__bf16*>(dP), dbias, T, Bp);
+        hipLaunchKernelGGL((lstm_rec_bwd_h128_bf16_s16_kernel<__bf16, float>), grid, block, 0, s,
+                           g16, Csave, Whh, reinterpret_cast<const float*>(dY), dp16, dbias, T, Bp);
+    else if (dy_bf16)
+        return LOB_E_SHAPE;                 // bf16 dY only with bf16 saved gates
     else
-        hipLaunchKernelGGL((lstm_rec_bwd_h128_bf16_s16_kernel<float>), grid, block, 0, s,
-                           reinterpret_cast<const float*>(G), Csave, Whh, dY, reinterpret_cast<__bf16*>(dP), dbias, T, Bp);
+        hipLaunchKernelGGL((lstm_rec_bwd_h128_bf16_s16_kernel<float, float>), grid, block, 0, s,
+                           reinterpret_cast<const float*>(G), Csave, Whh, reinterpret_cast<const float*>(dY), dp16, dbias, T, Bp);
     LOB_CHECK_LAUNCH();
     return 0;
 }

@@ -250,6 +250,25 @@ __device__ __forceinline__ void stv_bf16(__bf16* p, const float (&v)[VPL]) {
     *reinterpret_cast<bvec*>(p) = t;
 }
 
+// typed row-segment access for the backward kernel: fp32 or bf16 storage, fp32 in registers
+template <int VPL>
+__device__ __forceinline__ void ldv_bf16(const __bf16* p, float (&v)[VPL]) {
+    typedef __bf16 bvec __attribute__((ext_vector_type(VPL)));
+    const bvec t = *reinterpret_cast<const bvec*>(p);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) v[i] = (float)t[i];
+}
+template <int VPL, typename E>
+__device__ __forceinline__ void ldv_t(const E* p, float (&v)[VPL]) {
+    if constexpr (sizeof(E) == 4) ldv<VPL>(reinterpret_cast<const float*>(p), v);
+    else                          ldv_bf16<VPL>(reinterpret_cast<const __bf16*>(p), v);
+}
+template <int VPL, typename E>
+__device__ __forceinline__ void stv_t(E* p, const float (&v)[VPL]) {
+    if constexpr (sizeof(E) == 4) stv<VPL>(reinterpret_cast<float*>(p), v);
+    else                          stv_bf16<VPL>(reinterpret_cast<__bf16*>(p), v);
+}
+
 // Row enumeration for the (b,t) -> (t,b) relayout: index g walks 8 x 8 (window, time) tiles, so that 64 consecutive
 // waves touch 8 runs of 8 consecutive rows on the (b,t)-ordered side AND 8 runs of 8 consecutive rows on the
 // time-major side (a plain row-by-row walk reads one side in 512-B pieces 2 MB apart).
@@ -350,10 +369,12 @@ __device__ __forceinline__ float red_sum(const float (&r)[N][W], int c) {
     return t;
 }
 
-template <int VPL, int LPR = 64>
+// DYE / DXE: storage type of the incoming gradient dy / the outgoing dx (mixed path: the gradient carried between the
+// LSTM layers and into / out of the LayerNorms is a bf16 stream; LOB_DY_BF16 / LOB_OUT_BF16)
+template <int VPL, int LPR = 64, typename DYE = float, typename DXE = float>
 __global__ __launch_bounds__(256) void layernorm_act_bwd_vec_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-    const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
+    const DYE* __restrict__ dy, DXE* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
     int rows, float eps, int act, int remap_T, int remap_B, int remap_Bp, float drop_p, uint64_t seed,
     const float* __restrict__ pool_attn, const float* __restrict__ pool_dctx, int pool_T, int pool_B, int pool_Bp,
     float* __restrict__ dx_colsum) {
@@ -382,7 +403,7 @@ __global__ __launch_bounds__(256) void layernorm_act_bwd_vec_kernel(
             ok[r] = g < count && (remap_T <= 0 || tiled_row(g, remap_T, remap_B, remap_Bp, rowv[r], orowv[r]));
             if (ok[r]) {
                 ldv<VPL>(x + (size_t)rowv[r] * width + sl * VPL, vv[r]);
-                ldv<VPL>(dy + (size_t)orowv[r] * width + sl * VPL, gov[r]);
+                ldv_t<VPL, DYE>(dy + (size_t)orowv[r] * width + sl * VPL, gov[r]);
             }
         }
 #pragma unroll
@@ -431,7 +452,7 @@ __global__ __launch_bounds__(256) void layernorm_act_bwd_vec_kernel(
             m2 = norm ? row_sum<LPR>(m2) * invw : 0.f;
 #pragma unroll
             for (int i = 0; i < VPL; ++i) { v[i] = rstd * (go[i] - m1 - v[i] * m2); dxs[i] += v[i]; }
-            stv<VPL>(dx + (size_t)row * width + sl * VPL, v);
+            stv_t<VPL, DXE>(dx + (size_t)row * width + sl * VPL, v);
         }
     }
     if (dx_colsum) {      // column sums of dx = the bias gradient of the Linear that feeds this LayerNorm (04:174-175)
@@ -748,12 +769,44 @@ extern "C" int lob_layernorm_act_bwd_f32(const float* x, const float* gamma, con
                                          uint64_t seed, const float* pool_attn, const float* pool_dctx,
                                          int pool_T, int pool_B, int pool_Bp, float* dx_colsum, void* stream) {
     const bool ident = (act & LOB_LN_IDENTITY) != 0;
+    const bool dy16 = (act & LOB_DY_BF16) != 0, dx16 = (act & LOB_OUT_BF16) != 0;
+    act &= ~(LOB_DY_BF16 | LOB_OUT_BF16);
     if (!x || !dy || !dx || rows <= 0 || width <= 0) return LOB_E_ARG;
     if (!ident && (!gamma || !beta || !dgamma || !dbeta)) return LOB_E_ARG;
     if (width > 64 * LN_MAX_PER_LANE) return LOB_E_SHAPE;
     if (drop_p < 0.f || drop_p >= 1.f) return LOB_E_ARG;
     if (remap_T > 0 && (remap_B <= 0 || remap_Bp < remap_B || rows != remap_T * remap_B)) return LOB_E_SHAPE;
     int blocks = (rows + 3) / 4;
+    if (dy16 || dx16) {
+        // bf16 gradient streams: the two shapes of the mixed path (post-LSTM LayerNorm, width 256: dx bf16, dy fp32 or
+        // bf16; input-projection LayerNorm, width 128: dy bf16, dx fp32), vectorised kernels only
+        const bool al16b = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx) |
+                             reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) == 0;
+        if (!al16b) return LOB_E_ALIGN;
+        if (pool_attn && (!pool_dctx || pool_T <= 0 || pool_Bp <= 0 || rows != pool_T * pool_Bp || remap_T)) return LOB_E_SHAPE;
+        const __bf16* dyb = reinterpret_cast<const __bf16*>(dy);
+        __bf16* dxb = reinterpret_cast<__bf16*>(dx);
+#define LOB_LNB_T(V, L, DYT, DXT, DYP, DXP) hipLaunchKernelGGL((layernorm_act_bwd_vec_kernel<V, L, DYT, DXT>), dim3(blocks), \
+                       dim3(256), 0, (hipStream_t)stream, x, gamma, beta, DYP, DXP, dgamma, dbeta, rows, eps, act, remap_T,    \
+                       remap_B, remap_Bp, drop_p, seed, pool_attn, pool_dctx, pool_T, pool_B, pool_Bp, dx_colsum)
+        if (width == 256) {
+            if (blocks > 256 * 8) blocks = 256 * 8;
+            if (dy16 && dx16)       LOB_LNB_T(4, 64, __bf16, __bf16, dyb, dxb);
+            else if (dx16)          LOB_LNB_T(4, 64, float, __bf16, dy, dxb);
+            else                    LOB_LNB_T(4, 64, __bf16, float, dyb, dx);
+        } else if (width == 128) {
+            blocks = (rows + 31) / 32;
+            if (blocks > 256 * 8) blocks = 256 * 8;
+            if (dy16 && dx16)       LOB_LNB_T(8, 16, __bf16, __bf16, dyb, dxb);
+            else if (dx16)          LOB_LNB_T(8, 16, float, __bf16, dy, dxb);
+            else                    LOB_LNB_T(8, 16, __bf16, float, dyb, dx);
+        } else {
+            return LOB_E_SHAPE;
+        }
+#undef LOB_LNB_T
+        LOB_CHECK_LAUNCH();
+        return 0;
+    }
     const bool al = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx) |
                       reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) == 0;
     if (al && (width == 128 || width == 256 || width == 512)) {

@@ -13,6 +13,17 @@ from . import _lib
 
 ACT_NONE, ACT_TANH, ACT_GELU = 0, 1, 2
 LN_IDENTITY = 0x200          # LOB_LN_IDENTITY: OR into `act` of the LayerNorm entry points
+OUT_BF16, DY_BF16 = 0x400, 0x800      # LOB_OUT_BF16 / LOB_DY_BF16 (include/lob.h)
+
+#: mixed mode, H == 128: carry the gradient between the LSTM layers (dX of the layer above = dY of the layer below), out
+#: of the post-LSTM LayerNorm and into the input-projection LayerNorm as bf16 -- like dP, it is only consumed after
+#: widening to fp32 (half the bytes of three streams of the backward).  Set to False to keep those carries fp32.
+DY_BF16_CARRY = True
+
+
+def dy_bf16_ok(H, mixed):
+    """The 16-row bf16 BPTT kernels (H == 128) read a bf16 dY."""
+    return bool(mixed) and DY_BF16_CARRY and PG_BF16 and H == 128 and _lib.get_variant("REC_BF16_ROWS") != 32
 
 
 def _stream():
@@ -75,9 +86,10 @@ def _bf16_ok(a, K, lda):
     return K % 8 == 0 and lda % 8 == 0 and a.data_ptr() % 16 == 0
 
 
-def gemm_nt(a, w, bias=None, act=ACT_NONE, out=None, accumulate=False, mixed=False, drop_p=0.0, seed=0):
+def gemm_nt(a, w, bias=None, act=ACT_NONE, out=None, accumulate=False, mixed=False, drop_p=0.0, seed=0, out_bf16=False):
     """out[M,N] (+)= act(a[M,K] @ w[N,K]^T + bias).  mixed=True (or a bf16 `a`): bf16 MFMA inputs,
-    fp32 accumulate/output; falls back to the exact-fp32 kernel for shapes the bf16 kernel refuses."""
+    fp32 accumulate/output; falls back to the exact-fp32 kernel for shapes the bf16 kernel refuses.
+    out_bf16 (bf16 a AND w only): the result is stored as bf16."""
     a_bf16 = a.dtype == torch.bfloat16
     w_bf16 = w.dtype == torch.bfloat16
     _chk(a, "a", a.dtype if a_bf16 else torch.float32); _chk(w, "w", w.dtype if w_bf16 else torch.float32)
@@ -85,16 +97,22 @@ def gemm_nt(a, w, bias=None, act=ACT_NONE, out=None, accumulate=False, mixed=Fal
     M, K = a.shape
     N = w.shape[0]
     assert w.shape[1] == K
+    if out_bf16 and not (a_bf16 and w_bf16):
+        raise _lib.LobError("gemm_nt: out_bf16 needs bf16 operands (the LDS-DMA kernel's epilogue)")
     if out is None:
-        out = torch.empty((M, N), device=a.device, dtype=torch.float32)
-    _chk(out, "out")
+        out = torch.empty((M, N), device=a.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    _chk(out, "out", torch.bfloat16 if out_bf16 else torch.float32)
     if accumulate:
         act = act | 0x100
+    if out_bf16:
+        act = act | OUT_BF16
     if (mixed or a_bf16) and _bf16_ok(a, K, K) and w.data_ptr() % 16 == 0:
         rc = _lib.lib().lob_gemm_nt_bf16(_ptr(a), 1 if a_bf16 else 0, K, _ptr(w), int(w_bf16), K, _ptr(bias),
                                          _ptr(out), N, M, N, K, act, float(drop_p), C.c_uint64(seed), _stream())
         _lib.check(rc, "lob_gemm_nt_bf16")
         return out
+    if out_bf16:
+        raise _lib.LobError("gemm_nt: out_bf16 with operands the bf16 LDS-DMA kernel does not take (alignment / K % 8)")
     if drop_p > 0:
         raise _lib.LobError("gemm_nt: the fused dropout epilogue exists on the bf16 kernel only")
     if a_bf16:
@@ -344,8 +362,12 @@ def ode_rk4(base_rates, n_points, t0, t1, substeps, *, probs=None, alpha=0.0, y0
 def lstm_rec_bwd(G, Cs, whh, dY, T, Bp, H, D, dp_bf16=False, dbias=None):
     """BPTT through one layer; returns (dP[T*Bp, D*4H] row-major fp32|bf16, dbias[D*4H]); dbias: zeroed destination."""
     g16 = G.dtype == torch.bfloat16
-    _chk(G, "G", G.dtype if g16 else torch.float32); _chk(Cs, "Csave"); _chk(whh, "whh"); _chk(dY, "dY")
+    dy16 = dY.dtype == torch.bfloat16
+    _chk(G, "G", G.dtype if g16 else torch.float32); _chk(Cs, "Csave"); _chk(whh, "whh")
+    _chk(dY, "dY", torch.bfloat16 if dy16 else torch.float32)
     assert dY.shape == (T * Bp, D * H) and (not g16 or (dp_bf16 and bf16_rec(H, g16)))
+    if dy16 and not (dp_bf16 and bf16_rec(H, g16) and H == 128):
+        raise _lib.LobError("lstm_rec_bwd: a bf16 dY is read by the H = 128 bf16 BPTT kernels only")
     dP = torch.empty((T * Bp, D * 4 * H), device=G.device, dtype=torch.bfloat16 if dp_bf16 else torch.float32)
     fused_bias = uses_frag(H)
     if dbias is None:
@@ -355,8 +377,8 @@ def lstm_rec_bwd(G, Cs, whh, dY, T, Bp, H, D, dp_bf16=False, dbias=None):
         whht16 = None
         if H == 256:       # [D, ks 64, hi 2, j 8, w 8, l31 32] -> [D, w, ks, hi, l31, j]  (fragment order, lob.h)
             whht16 = (whh.to(torch.bfloat16).reshape(D, 64, 2, 8, 8, 32).permute(0, 4, 1, 2, 5, 3).contiguous())
-        rc = _lib.lib().lob_lstm_rec_bwd_bf16(_ptr(G), int(g16), _ptr(Cs), _ptr(whh), _ptr(whht16), _ptr(dY), _ptr(dP),
-                                              _ptr(dbias), T, Bp, H, D, _stream())
+        rc = _lib.lib().lob_lstm_rec_bwd_bf16(_ptr(G), int(g16), _ptr(Cs), _ptr(whh), _ptr(whht16), _ptr(dY), int(dy16),
+                                              _ptr(dP), _ptr(dbias), T, Bp, H, D, _stream())
     else:
         rc = _lib.lib().lob_lstm_rec_bwd_f32(_ptr(G), _ptr(Cs), _ptr(whh), _ptr(dY), _ptr(dP), int(dp_bf16),
                                              _ptr(dbias) if fused_bias else _ptr(None), T, Bp, H, D, _stream())
@@ -395,14 +417,20 @@ def act_bwd(dy, pre, kind):
 
 
 def layernorm_act_bwd(x, gamma, beta, dy, act=ACT_NONE, eps=1e-5, remap=None, drop_p=0.0, seed=0, pool=None,
-                      dx_colsum=None, zeros=None):
+                      dx_colsum=None, zeros=None, dx_bf16=False):
     """Returns (dx [rows,width] in INPUT row order, dgamma, dbeta).  pool=(attn [B,T], dctx [B,width], T, B, Bp)
     adds attn[b][t] * dctx[b] to dy on the fly (context path of the attention pooling).  dx_colsum [width]
-    (widths 128/256/512): += column sums of dx (see ``can_fuse_colsum``)."""
-    _chk(x, "x"); _chk(gamma, "gamma"); _chk(beta, "beta"); _chk(dy, "dy")
+    (widths 128/256/512): += column sums of dx (see ``can_fuse_colsum``).  dy may be bf16 and dx_bf16 stores dx as
+    bf16 (widths 128 / 256: the mixed path's gradient carries, ``DY_BF16_CARRY``)."""
+    dy16 = dy.dtype == torch.bfloat16
+    _chk(x, "x"); _chk(gamma, "gamma"); _chk(beta, "beta"); _chk(dy, "dy", torch.bfloat16 if dy16 else torch.float32)
     rows, width = x.shape
     rT, rB, rBp = (0, 0, 0) if remap is None else remap
-    dx = torch.empty_like(x)
+    dx = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16 if dx_bf16 else torch.float32)
+    if dy16:
+        act = act | DY_BF16
+    if dx_bf16:
+        act = act | OUT_BF16
     if gamma is None:            # identity "LayerNorm": dx = dy * act' * mask, no affine gradients
         act = act | LN_IDENTITY
         dg = db = None

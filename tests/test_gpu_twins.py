@@ -90,16 +90,23 @@ def test_gate_gemm_weight_stationary_ragged(dev, Tn, Bn, K):
         assert torch.equal(p_ws, p_tl), (Tn, Bn, K, D)
 
 
-def test_bptt_dma_ring_bit_identical_to_register_prefetch(dev, layer_state):
+@pytest.mark.parametrize("dy_dtype", [torch.float32, torch.bfloat16])
+def test_bptt_dma_ring_bit_identical_to_register_prefetch(dev, layer_state, dy_dtype):
     """lstm_rec_bwd_h128_bf16_s16_dma_kernel (wave-private LDS-DMA ring, vmcnt(14)/(18)) against the register-prefetch
     kernel: same arithmetic in the same order -> dP bit-identical over all 1M rows; the bias gradient (fp32 atomics
-    over 512 workgroups) to rounding."""
+    over 512 workgroups) to rounding.  Both storage types of the incoming gradient (fp32; bf16 = the mixed path's
+    default carry, hand-issued global_load_ushort)."""
     from lstm_ode_bci_amd import _lib, ops
     s = layer_state
+    dY = s["dY"].to(dy_dtype)
     with _lib.variant(REC_BWD_DMA=1):
-        dP1, db1 = ops.lstm_rec_bwd(s["G"], s["Cs"], s["whh"], s["dY"], T, s["Bp"], s["H"], s["D"], dp_bf16=True)
+        dP1, db1 = ops.lstm_rec_bwd(s["G"], s["Cs"], s["whh"], dY, T, s["Bp"], s["H"], s["D"], dp_bf16=True)
     with _lib.variant(REC_BWD_DMA=0):
-        dP0, db0 = ops.lstm_rec_bwd(s["G"], s["Cs"], s["whh"], s["dY"], T, s["Bp"], s["H"], s["D"], dp_bf16=True)
+        dP0, db0 = ops.lstm_rec_bwd(s["G"], s["Cs"], s["whh"], dY, T, s["Bp"], s["H"], s["D"], dp_bf16=True)
+    if dy_dtype == torch.bfloat16:          # a bf16 dY == the same values handed over as fp32
+        with _lib.variant(REC_BWD_DMA=1):
+            dPf, _ = ops.lstm_rec_bwd(s["G"], s["Cs"], s["whh"], dY.float(), T, s["Bp"], s["H"], s["D"], dp_bf16=True)
+        assert torch.equal(dP1.view(torch.int16), dPf.view(torch.int16))
     nbad = int((dP1.view(torch.int16) != dP0.view(torch.int16)).sum())
     assert nbad == 0, f"{nbad} of {dP1.numel()} dP elements differ"
     assert torch.isfinite(dP1.float()).all() and dP1.float().abs().max().item() > 0
@@ -285,3 +292,82 @@ def test_fp32_split_gate_gemm_and_recurrence_vs_exact_fp32_mfma(dev):
     print(f"recurrent layer, 256 steps: |h_split - h_exact| max {dy:.2e}")
     assert dy < 5e-6 and torch.equal(y_s, y_sv)                    # save mode computes the same h
     assert (pk - pk2).abs().max().item() < 5e-6 and (c_sv - c_ev).abs().max().item() < 2e-5      # saved gates, c
+
+
+def test_bf16_gradient_carries_round_the_same_fp32_values(dev, layer_state):
+    """ops.DY_BF16_CARRY: dX = dP W_ih written as bf16 by the NT GEMM's epilogue and the LayerNorm backward's bf16 dy in /
+    dx out are the fp32 kernels' values rounded once (RNE) -- bit-exact against rounding the fp32 results on the host
+    side; at the step's real shapes."""
+    from lstm_ode_bci_amd import ops
+    s = layer_state
+    rows = s["rows"]
+    dP = _rand((rows, s["D"] * 4 * s["H"]), dev, 61, 1e-2, dtype=torch.bfloat16)
+    wt = s["wih"].t().contiguous()
+    for kw in (dict(), dict(drop_p=0.4, seed=5)):
+        o32 = ops.gemm_nt(dP, wt, mixed=True, **kw)
+        o16 = ops.gemm_nt(dP, wt, mixed=True, out_bf16=True, **kw)
+        assert o16.dtype == torch.bfloat16 and torch.equal(o16, o32.to(torch.bfloat16))
+    # LayerNorm backward, width 256 (post-LSTM): dy fp32|bf16 -> dx bf16, with the fused attention-context term
+    W = 256
+    x = _rand((rows, W), dev, 62)
+    gam, bet = _rand((W,), dev, 63) + 1.0, _rand((W,), dev, 64)
+    dy = _rand((rows, W), dev, 65, 1e-2)
+    attn = torch.softmax(_rand((B, T), dev, 66), 1).contiguous()
+    dctx = _rand((B, W), dev, 67, 1e-2)
+    pool = (attn, dctx, T, B, s["Bp"])
+    ref, rg, rb = ops.layernorm_act_bwd(x, gam, bet, dy, pool=pool)
+    got, gg, gb = ops.layernorm_act_bwd(x, gam, bet, dy, pool=pool, dx_bf16=True)
+    assert got.dtype == torch.bfloat16 and torch.equal(got, ref.to(torch.bfloat16))
+    assert (gg - rg).abs().max().item() <= 1e-4 * rg.abs().max().item()          # atomics: order only
+    dy16 = dy.to(torch.bfloat16)
+    ref2, _, _ = ops.layernorm_act_bwd(x, gam, bet, dy16.float(), pool=pool)
+    got2, _, _ = ops.layernorm_act_bwd(x, gam, bet, dy16, pool=pool, dx_bf16=True)
+    assert torch.equal(got2, ref2.to(torch.bfloat16))
+    # width 128 with the (b,t) -> (t,b) relayout, GELU and dropout (input projection): dy bf16 -> dx fp32
+    Bs, Ts, W1 = 96, 40, 128
+    x1 = _rand((Bs * Ts, W1), dev, 71)
+    g1, b1 = _rand((W1,), dev, 72) + 1.0, _rand((W1,), dev, 73)
+    dy1 = _rand((Ts * Bs, W1), dev, 74, 1e-2).to(torch.bfloat16)
+    kw = dict(act=ops.ACT_GELU, remap=(Ts, Bs, Bs), drop_p=0.2, seed=9)
+    r32, _, _ = ops.layernorm_act_bwd(x1, g1, b1, dy1.float(), **kw)
+    r16, _, _ = ops.layernorm_act_bwd(x1, g1, b1, dy1, **kw)
+    assert r16.dtype == torch.float32 and torch.equal(r16, r32)
+
+
+def test_mixed_step_with_and_without_bf16_carries(dev):
+    """The whole mixed backward with the gradient carries in bf16 (default) against fp32 carries: the two differ by the
+    one extra rounding per layer boundary -- well inside the mixed tolerance; worst tensor printed."""
+    from lstm_ode_bci_amd import EnhancedLSTMModel, ops
+    sd = syn.make_state_dict(61, 128, 3, 2, True)
+    x, y = syn.make_windows(256)
+    m = EnhancedLSTMModel(input_size=61, hidden_size=128, num_layers=3, num_classes=2, dropout=0.4, bidirectional=True)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    m = m.to(dev).train()
+    xt, yt = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+
+    def grads(mixed=True):
+        m.zero_grad(set_to_none=True)
+        torch.manual_seed(3)                           # same dropout masks
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=mixed):
+            torch.nn.functional.cross_entropy(m(xt).float(), yt).backward()
+        return {k: p.grad.clone() for k, p in m.named_parameters()}
+    assert ops.DY_BF16_CARRY
+    g16 = grads()
+    ops.DY_BF16_CARRY = False
+    try:
+        g32 = grads()
+    finally:
+        ops.DY_BF16_CARRY = True
+    gref = grads(mixed=False)                          # fp32 path, same masks
+    worst = (0.0, None, 0.0)
+    for k in g32:
+        sc = gref[k].abs().max().item()
+        if sc < 1e-7:
+            continue
+        e16 = (g16[k] - gref[k]).abs().max().item() / sc
+        e32 = (g32[k] - gref[k]).abs().max().item() / sc
+        if e16 > worst[0]:
+            worst = (e16, k, e32)
+        assert e16 <= 2e-2, (k, e16)
+    print(f"bf16 carries: worst tensor {worst[1]} rel err {worst[0]:.3e} (fp32 carries: {worst[2]:.3e})")
+    assert any(not torch.equal(g16[k], g32[k]) for k in g16), "the bf16-carry switch changed nothing"

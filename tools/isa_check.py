@@ -20,7 +20,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "lstm_ode_bci_amd", "csrc", "lstm_rec_bf16_s16.hip")
-KERNEL = r"lstm_rec_bwd_h128_bf16_s16_dma_kernelILi%dE"
+KERNEL = r"lstm_rec_bwd_h128_bf16_s16_dma_kernelILi%dELb%dEE"
 
 
 def compile_to_isa(path=None):
@@ -168,12 +168,14 @@ def check_kernel(body):
             problems.append(f"spill traffic in the loop: {t}")
     # hazard 1: walk the loop cyclically from each group of hand-issued loads to the SECOND following hand wait
     n = len(loop)
-    starts = [k for k, (_, t, a) in enumerate(loop) if a and t.startswith("global_load_dword ")
-              and not (k and loop[k - 1][2] and loop[k - 1][1].startswith("global_load_dword "))]
+    def is_dy(t):
+        return t.startswith("global_load_dword ") or t.startswith("global_load_ushort ")
+    starts = [k for k, (_, t, a) in enumerate(loop) if a and is_dy(t)
+              and not (k and loop[k - 1][2] and is_dy(loop[k - 1][1]))]
     assert len(starts) == 2, f"expected two groups of hand-issued dY loads, found {len(starts)}"
     for s in starts:
         dst, k = set(), s
-        while loop[k][2] and loop[k][1].startswith("global_load_dword "):
+        while loop[k][2] and is_dy(loop[k][1]):
             dst |= _regs(loop[k][1].split(",")[0])
             k += 1
         seen_waits = 0
@@ -193,7 +195,8 @@ def main(path=None):
     lines = open(path or compile_to_isa()).read().split("\n")
     problems = []
     for D in (1, 2):
-        problems += [f"D={D}: {p}" for p in check_kernel(_function(lines, KERNEL % D))]
+        for y16 in (0, 1):
+            problems += [f"D={D} dy_bf16={y16}: {p}" for p in check_kernel(_function(lines, KERNEL % (D, y16)))]
     return problems
 
 
