@@ -33,7 +33,16 @@ sys.path.insert(0, ROOT)
 
 T, C, L, D = 256, 61, 3, 2
 # MI355X_MICROARCH.md: dense MFMA peaks per arithmetic dtype, HBM3E spec peak
-MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}
+# "f16x2": the fp32 path's default arithmetic at H = 128 -- every fp32 product as three fp16 MFMAs (two-way operand
+# split, 22-bit products, fp32 accumulate): the peak in fp32-equivalent FLOPs is a third of the dense fp16 peak
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16x2": 2500.0 / 3}
+
+
+def fp32_mfma_kind(H):
+    """Matrix arithmetic of the fp32 path: 'f16x2' where the split kernels run (H = 128, LOB_VAR_F32_SPLIT), else the
+    exact-fp32 MFMA."""
+    from lstm_ode_bci_amd import _lib
+    return "f16x2" if (H == 128 and _lib.get_variant("F32_SPLIT") != 0) else "f32"
 HBM_PEAK_GBPS = 8000.0
 
 
@@ -96,6 +105,8 @@ def kernel_roofline(dev, B, mode, precision, H):
     bf16_rec = mixed and ops.bf16_rec(H, ops.PG_BF16)   # bf16-MFMA recurrent kernels: H = 128 and 256
     pe = 2.0 if (bf16_rec and ops.PG_BF16) else 4.0     # bytes per stored pre-activation / saved gate
     de = 2.0 if mixed else 4.0                          # bytes per dP element
+    ce = 2.0 if ops.c_bf16_ok(H, mixed, bf16_rec and ops.PG_BF16) else 4.0     # bytes per saved cell state
+    ye = 2.0 if ops.dy_bf16_ok(H, mixed) else 4.0       # bytes per element of the gradient carried between layers
     # operand storage types as the step itself uses them: in mixed mode the layer below hands over bf16
     # activations and the weights are cast once per step -> the bf16 x bf16 GEMM kernels
     act16 = bf16_rec and (ops.gate_ws_ok(K, H) or ops.dma_ok(K, N, rows))
@@ -109,8 +120,9 @@ def kernel_roofline(dev, B, mode, precision, H):
     bias = torch.zeros(N, device=dev)
     whh = (torch.rand((D, 4 * H, H), generator=g) * 0.17 - 0.085).to(dev)
     sec = timeit(lambda: ops.gate_gemm_x(x, w_in, bias, T, Bp, H, D, True, mixed=mixed))
+    f32k = fp32_mfma_kind(H)
     out[f"gate_gemm_x(K={K})"] = {"sec": sec, "flop": 2.0 * rows * N * K, "bytes": rows * (xe * K + pe * N) + xe * N * K,
-                                  "per_step": L - 1, "mfma": "bf16" if mixed else "f32"}
+                                  "per_step": L - 1, "mfma": "bf16" if mixed else f32k}
     P = ops.gate_gemm_x(x, w_in, bias, T, Bp, H, D, True, mixed=mixed)
     if train:
         Pk = P.clone()
@@ -122,13 +134,13 @@ def kernel_roofline(dev, B, mode, precision, H):
         sec = timeit(rec_fwd, n=3) - t_copy
         Y, Cs, _, _ = rec_fwd()
         out["lstm_rec_fwd(save)"] = {"sec": sec, "flop": 2.0 * rows * N * H, "per_step": L,
-                                     "mfma": "bf16" if bf16_rec else "f32",
-                                     "bytes": rows * (2 * pe * N + 8.0 * K)}   # P in, gates out, c out, Y out
-        dY = torch.randn((rows, K), generator=g).to(dev) * 1e-3
+                                     "mfma": "bf16" if bf16_rec else f32k,
+                                     "bytes": rows * (2 * pe * N + (ce + 4.0) * K)}   # P in, gates out, c out, Y out
+        dY = (torch.randn((rows, K), generator=g).to(dev) * 1e-3).to(torch.bfloat16 if ye == 2.0 else torch.float32)
         sec = timeit(lambda: ops.lstm_rec_bwd(Pk, Cs, whh, dY, T, Bp, H, D, dp_bf16=mixed), n=3)
         out["lstm_rec_bwd"] = {"sec": sec, "flop": 2.0 * rows * N * H, "per_step": L,
                                "mfma": "bf16" if bf16_rec else "f32",
-                               "bytes": rows * (pe * N + 8.0 * K + de * N)}   # gates in, c in, dY in, dP out
+                               "bytes": rows * (pe * N + (ce + ye) * K + de * N)}   # gates in, c in, dY in, dP out
         dP, _ = ops.lstm_rec_bwd(Pk, Cs, whh, dY, T, Bp, H, D, dp_bf16=mixed)
         Y16 = Y.to(torch.bfloat16) if (Y is not None and dP.dtype == torch.bfloat16) else None
         if Y16 is not None and ops.can_fuse_dw(dP, x, Y16, T, Bp, H, D):
@@ -146,22 +158,24 @@ def kernel_roofline(dev, B, mode, precision, H):
         wt = wih.t().contiguous()
         if dP.dtype == torch.bfloat16 and ops.dma_ok(N, K, rows):
             wt = wt.to(torch.bfloat16)
-        sec = timeit(lambda: ops.gemm_nt(dP, wt, mixed=mixed))
+        dx16 = ye == 2.0 and wt.dtype == torch.bfloat16
+        sec = timeit(lambda: ops.gemm_nt(dP, wt, mixed=mixed, out_bf16=dx16))
         out["gemm_nt(dX)"] = {"sec": sec, "flop": 2.0 * rows * N * K, "per_step": L - 1,
                               "mfma": "bf16" if mixed else "f32",
-                              "bytes": de * rows * N + 4.0 * rows * K}
+                              "bytes": de * rows * N + (2.0 if dx16 else 4.0) * rows * K}
     else:
         sec = timeit(lambda: ops.lstm_rec_fwd(P, whh, T, Bp, H, D, False, mixed=mixed), n=3)
         out["lstm_rec_fwd"] = {"sec": sec, "flop": 2.0 * rows * N * H, "per_step": L,
-                               "mfma": "bf16" if bf16_rec else "f32",
+                               "mfma": "bf16" if bf16_rec else f32k,
                                "bytes": rows * (pe * N + 4.0 * K)}
     return out
 
 
 def roofline_of(kr):
-    """The dominant kernel (largest time per step) priced against the roofline that bounds it: the fp32 kernels sit
-    under the fp32 MFMA roof; every bf16-MFMA kernel of this path (K <= 1024) sits under the HBM roof.  `all` lists
-    every hot kernel with BOTH fractions against its own arithmetic dtype's peaks."""
+    """The dominant kernel (largest time per step) priced against the roofline that bounds it: the exact-fp32 MFMA
+    kernels sit under the fp32 MFMA roof; every 16-bit-MFMA kernel of this path (bf16, and the fp16-split fp32 kernels;
+    K <= 1024) sits under the HBM roof.  `all` lists every hot kernel with BOTH fractions against its own arithmetic
+    dtype's peaks."""
     dom = max(kr, key=lambda k: kr[k]["sec"] * kr[k]["per_step"])
     v = kr[dom]
     allk = {k: {"ms": round(x["sec"] * 1e3, 3), "tflops": round(x["flop"] / x["sec"] / 1e12, 1),
@@ -351,16 +365,18 @@ class Leg:
     def describe(self, steps, warmup, dt, with_roofline=True):
         mode, precision, B, H, world = self.mode, self.precision, self.B, self.H, self.world
         value = world * B * steps / dt
-        mf = "f32" if precision == "fp32" else "bf16"
+        mf = fp32_mfma_kind(H) if precision == "fp32" else "bf16"
         flop_per_window = gate_flop_fwd(H) * (3 if mode == "train" else 1)
         res = {
             "metric": {"train": "eeg_windows_per_sec_fwd_bwd", "fwd": "eeg_windows_per_sec_fwd",
                        "coupled": "eeg_windows_per_sec_fwd_ode"}[mode],
             "value": value, "unit": "windows/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": mf, "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if precision == "fp32" else "bf16", "data": "synthetic",
             "config": {"workload": f"BiLSTM({L}x{H})+attn {mode}, (T={T},C={C}) windows, B={B}/GPU, " +
-                                   ("fp32 exact-MFMA" if precision == "fp32" else
+                                   (("fp32 (matrix products as two-way fp16 splits on the 16-bit MFMA pipe: 22-bit products, "
+                                     "fp32 accumulate / state; parity <= 1e-5)" if mf == "f16x2" else "fp32 exact-MFMA")
+                                    if precision == "fp32" else
                                     "bf16 gate GEMMs + fp32 recurrence/accumulate (autocast)")
                                    + (f", RK4 ODE {self.forecast_steps} points" if mode == "coupled" else "")
                                    + (", numpy in -> numpy out through predict_batch (PCIe inside the step)" if self.api_level else ""),

@@ -187,14 +187,17 @@ int lob_lstm_dw_bf16(const void* dP, int ldp, const void* X, int ldx, int nx, co
  *   Whh16  [D][w 8][ks 16][gate 4][lane 64][8]: W_hh[d][gate*H + 32w + (lane&31)][16ks + 8(lane>>5) + j]   (forward)
  *   WhhT16 [D][w 8][ks 64][lane 64][8]:         W_hh[d][16ks + 8(lane>>5) + j][32w + (lane&31)]            (BPTT)
  * Whh16 / WhhT16 are ignored (may be NULL) at H == 128.                                                  */
-int lob_lstm_rec_fwd_bf16(void* P, int pg_bf16, const float* Whh, const void* Whh16, float* Y, float* Csave,
+int lob_lstm_rec_fwd_bf16(void* P, int pg_bf16, const float* Whh, const void* Whh16, float* Y, void* Csave, int c_bf16,
                           void* Y16, void* Yd, float drop_p, uint64_t seed,
                           int T, int Bp, int H, int D, int save, void* stream);
+/*   c_bf16 = 1 (H == 128, 16-row kernels, bf16 saved gates): the cell states saved for BPTT are stored as bf16, in the
+ *   element order of one gate of the saved gates ([q pair][lane][8]); BPTT takes the matching flag.  The state carried
+ *   through time is fp32 in both kernels; only the saved copy is rounded.                                          */
 /*   Outputs, any non-empty subset with Y or Y16 present: Y (fp32 [T*Bp][D*H]), Y16 = bf16(Y) and
  *   Yd = bf16(dropout(Y; drop_p, seed)) (element index = position in Y) -- nn.LSTM's inter-layer dropout
  *   (04_lstm_model.py:186) fused into the producer.  In mixed mode the bf16 GEMMs of the next layer read
  *   Yd (or Y16 without dropout) and dW_hh reads Y16, so layers below the last never write fp32 Y.  */
-int lob_lstm_rec_bwd_bf16(const void* G, int pg_bf16, const float* Csave, const float* Whh, const void* WhhT16,
+int lob_lstm_rec_bwd_bf16(const void* G, int pg_bf16, const void* Csave, int c_bf16, const float* Whh, const void* WhhT16,
                           const void* dY, int dy_bf16,
                           void* dP, float* dbias, int T, int Bp, int H, int D, void* stream);
 /*   dy_bf16 = 1 (H == 128, 16-row kernels): dY is stored as bf16 -- in the mixed path the gradient carried from layer

@@ -338,10 +338,10 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_h128_bf16_kernel(
 
 // 16-row tiles, two workgroups per CU (lstm_rec_bf16_s16.hip): the default.  LOB_REC_BF16=32 selects the 32-row
 // kernels of this file.
-int lob_rec_fwd_bf16_s16(void* P, int pg_bf16, const float* Whh, float* Y, float* Csave, void* Y16, void* Yd,
+int lob_rec_fwd_bf16_s16(void* P, int pg_bf16, const float* Whh, float* Y, void* Csave, int c_bf16, void* Y16, void* Yd,
                          float drop_p, uint64_t seed, int T, int Bp, int D, int save, hipStream_t s);
-int lob_rec_bwd_bf16_s16(const void* G, int pg_bf16, const float* Csave, const float* Whh, const void* dY, int dy_bf16, void* dP,
-                         float* dbias, int T, int Bp, int D, hipStream_t s);
+int lob_rec_bwd_bf16_s16(const void* G, int pg_bf16, const void* Csave, int c_bf16, const float* Whh, const void* dY,
+                         int dy_bf16, void* dP, float* dbias, int T, int Bp, int D, hipStream_t s);
 // H = 256: W_hh streamed from L2 (lstm_rec_h256_bf16.hip); bf16 P / saved gates only
 int lob_rec_fwd_h256_bf16(void* P, const void* Whh16, float* Y, float* Csave, void* Y16, void* Yd, float drop_p,
                           uint64_t seed, int T, int Bp, int D, int save, hipStream_t s);
@@ -352,12 +352,15 @@ static bool use_s16() {
     return v;
 }
 
-extern "C" int lob_lstm_rec_fwd_bf16(void* P, int pg_bf16, const float* Whh, const void* Whh16, float* Y, float* Csave,
-                                     void* Y16, void* Yd, float drop_p, uint64_t seed,
+extern "C" int lob_lstm_rec_fwd_bf16(void* P, int pg_bf16, const float* Whh, const void* Whh16, float* Y, void* Csavev,
+                                     int c_bf16, void* Y16, void* Yd, float drop_p, uint64_t seed,
                                      int T, int Bp, int Hh, int D, int save, void* stream) {
     if (!P || !Whh || T <= 0 || Bp <= 0 || (D != 1 && D != 2)) return LOB_E_ARG;
     if (!Y && !Y16) return LOB_E_ARG;
-    if (save && !Csave) return LOB_E_ARG;
+    if (save && !Csavev) return LOB_E_ARG;
+    // bf16 cell-state storage: the 16-row H = 128 kernels only
+    if (c_bf16 && (Hh != 128 || !use_s16())) return LOB_E_SHAPE;
+    float* Csave = reinterpret_cast<float*>(Csavev);
     if (Yd && (drop_p <= 0.f || drop_p >= 1.f)) return LOB_E_ARG;
     if (Hh == 256) {
         if (!pg_bf16 || (Bp % 32)) return LOB_E_SHAPE;
@@ -370,7 +373,7 @@ extern "C" int lob_lstm_rec_fwd_bf16(void* P, int pg_bf16, const float* Whh, con
     if ((reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(Whh) | reinterpret_cast<uintptr_t>(Csave) |
          reinterpret_cast<uintptr_t>(Y16) | reinterpret_cast<uintptr_t>(Yd)) & 15) return LOB_E_ALIGN;
     hipStream_t s = (hipStream_t)stream;
-    if (use_s16()) return lob_rec_fwd_bf16_s16(P, pg_bf16, Whh, Y, Csave, Y16, Yd, drop_p, seed, T, Bp, D, save, s);
+    if (use_s16()) return lob_rec_fwd_bf16_s16(P, pg_bf16, Whh, Y, Csavev, c_bf16, Y16, Yd, drop_p, seed, T, Bp, D, save, s);
     const dim3 grid(Bp / 32, D), block(256);
     __bf16* y16 = reinterpret_cast<__bf16*>(Y16);
     __bf16* yd = reinterpret_cast<__bf16*>(Yd);
@@ -392,12 +395,13 @@ extern "C" int lob_lstm_rec_fwd_bf16(void* P, int pg_bf16, const float* Whh, con
     return 0;
 }
 
-extern "C" int lob_lstm_rec_bwd_bf16(const void* G, int pg_bf16, const float* Csave, const float* Whh, const void* WhhT16,
-                                     const void* dYv, int dy_bf16, void* dP, float* dbias, int T, int Bp, int Hh, int D,
-                                     void* stream) {
-    if (!G || !Csave || !Whh || !dYv || !dP || T <= 0 || Bp <= 0 || (D != 1 && D != 2)) return LOB_E_ARG;
-    // bf16 dY: the 16-row H = 128 kernels only
-    if (dy_bf16 && (Hh != 128 || !use_s16())) return LOB_E_SHAPE;
+extern "C" int lob_lstm_rec_bwd_bf16(const void* G, int pg_bf16, const void* Csavev, int c_bf16, const float* Whh,
+                                     const void* WhhT16, const void* dYv, int dy_bf16, void* dP, float* dbias, int T, int Bp,
+                                     int Hh, int D, void* stream) {
+    if (!G || !Csavev || !Whh || !dYv || !dP || T <= 0 || Bp <= 0 || (D != 1 && D != 2)) return LOB_E_ARG;
+    // bf16 dY / bf16 cell state: the 16-row H = 128 kernels only
+    if ((dy_bf16 || c_bf16) && (Hh != 128 || !use_s16())) return LOB_E_SHAPE;
+    const float* Csave = reinterpret_cast<const float*>(Csavev);
     const float* dY = reinterpret_cast<const float*>(dYv);
     if (Hh == 256) {
         if (!pg_bf16 || (Bp % 32)) return LOB_E_SHAPE;
@@ -409,7 +413,7 @@ extern "C" int lob_lstm_rec_bwd_bf16(const void* G, int pg_bf16, const float* Cs
     if (Hh != 128 || (Bp % 32)) return LOB_E_SHAPE;
     if ((reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(Csave) |
          reinterpret_cast<uintptr_t>(dP)) & 15) return LOB_E_ALIGN;
-    if (use_s16()) return lob_rec_bwd_bf16_s16(G, pg_bf16, Csave, Whh, dYv, dy_bf16, dP, dbias, T, Bp, D, (hipStream_t)stream);
+    if (use_s16()) return lob_rec_bwd_bf16_s16(G, pg_bf16, Csavev, c_bf16, Whh, dYv, dy_bf16, dP, dbias, T, Bp, D, (hipStream_t)stream);
     if (pg_bf16)
         hipLaunchKernelGGL((lstm_rec_bwd_h128_bf16_kernel<__bf16>), dim3(Bp / 32, D), dim3(256), 0, (hipStream_t)stream,
                            reinterpret_cast<const __bf16*>(G), Csave, Whh, dY, reinterpret_cast<__bf16*>(dP), dbias, T, Bp);

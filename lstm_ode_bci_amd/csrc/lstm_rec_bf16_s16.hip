@@ -75,10 +75,14 @@ __device__ __forceinline__ void store_frag16(E* p, unsigned off, const f32x4 (&s
         }
 }
 
-template <bool SAVE, bool YF32, bool Y16, bool DROP, typename PE>
+// CE: storage type of the saved cell state c_t (fp32, or bf16 in the same [q pair][lane][8] order as one gate of the
+// saved gates: BPTT only ever uses c_t inside tanh(c_t) and as the factor of the forget-gate gradient, next to gate
+// values that are bf16 already -- half the bytes of that stream, forward and backward).  The state carried through
+// time stays fp32 in registers.
+template <bool SAVE, bool YF32, bool Y16, bool DROP, typename PE, typename CE>
 __global__ __launch_bounds__(256, 2) void lstm_rec_fwd_h128_bf16_s16_kernel(
     PE* __restrict__ P, const float* __restrict__ Whh, float* __restrict__ Y,
-    float* __restrict__ Csave, __bf16* __restrict__ Y16p, __bf16* __restrict__ Yd, float drop_p, uint64_t seed,
+    CE* __restrict__ Csave, __bf16* __restrict__ Y16p, __bf16* __restrict__ Yd, float drop_p, uint64_t seed,
     int T, int Bp) {
     __shared__ __attribute__((aligned(16))) __bf16 hs[2 * 16 * HB_LD];
     // fp32 h of the step (last layer only), staged so that it leaves as 32-B-per-lane row segments instead of eight
@@ -112,9 +116,9 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_fwd_h128_bf16_s16_kernel(
 
     const size_t pstep = (size_t)NBT * 16 * 1024, cstep = (size_t)NBT * 4096;
     PE* pblk = P + ((size_t)d * T * NBT + bt) * 16 * 1024 + (size_t)w * 4096 + s0 * 512;
-    float* cblk = SAVE ? Csave + ((size_t)d * T * NBT + bt) * 4096 + (size_t)w * 1024 + s0 * 512 : nullptr;
+    CE* cblk = SAVE ? Csave + ((size_t)d * T * NBT + bt) * 4096 + (size_t)w * 1024 + s0 * 512 : nullptr;
     const unsigned lane_p = frag_lane<PE>(rq, c16);        // P / saved gates (storage type PE)
-    const unsigned lane_c = frag_lane<float>(rq, c16);     // c (always fp32)
+    const unsigned lane_c = frag_lane<CE>(rq, c16);        // c (storage type CE)
     const int DH = D * H;
     const int t_first = d ? T - 1 : 0, dt = d ? -1 : 1;
     const int row0 = bt * 32 + s0 * 16;
@@ -162,11 +166,16 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_fwd_h128_bf16_s16_kernel(
             }
         if (SAVE) {
             store_frag16(pblk + (size_t)t * pstep, lane_p, acc);
-            float* cp = cblk + (size_t)t * cstep;
+            CE* cp = cblk + (size_t)t * cstep;
 #pragma unroll
             for (int cbu = 0; cbu < 2; ++cbu) {
-                f32x4 v = {c[cbu][0], c[cbu][1], c[cbu][2], c[cbu][3]};
-                *reinterpret_cast<f32x4*>((cp + cbu * 64) + lane_c) = v;
+                if constexpr (sizeof(CE) == 4) {
+                    f32x4 v = {c[cbu][0], c[cbu][1], c[cbu][2], c[cbu][3]};
+                    *reinterpret_cast<f32x4*>((cp + cbu * FRAG_CBU<CE>) + lane_c) = v;
+                } else {
+                    bf16x4 v = {(__bf16)c[cbu][0], (__bf16)c[cbu][1], (__bf16)c[cbu][2], (__bf16)c[cbu][3]};
+                    *reinterpret_cast<bf16x4*>((cp + cbu * FRAG_CBU<CE>) + lane_c) = v;
+                }
             }
         }
         __syncthreads();
@@ -207,9 +216,9 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_fwd_h128_bf16_s16_kernel(
 // BPTT on 16-row tiles.  dgates are rounded to bf16 once: the LDS tile feeds the MFMA A operand AND is the dP
 // image copied to HBM.
 // ------------------------------------------------------------------------------------------
-template <typename PE, typename DE>
+template <typename PE, typename DE, typename CE>
 __global__ __launch_bounds__(256, 2) void lstm_rec_bwd_h128_bf16_s16_kernel(
-    const PE* __restrict__ G, const float* __restrict__ Csave, const float* __restrict__ Whh,
+    const PE* __restrict__ G, const CE* __restrict__ Csave, const float* __restrict__ Whh,
     const DE* __restrict__ dY, __bf16* __restrict__ dP, float* __restrict__ dbias, int T, int Bp) {
     __shared__ __attribute__((aligned(16))) __bf16 dgs[16 * DGB_LD];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -235,9 +244,9 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_bwd_h128_bf16_s16_kernel(
     }
     const size_t gstep = (size_t)NBT * 16 * 1024, cstep = (size_t)NBT * 4096;
     const PE* gwave = G + ((size_t)d * T * NBT + bt) * 16 * 1024 + (size_t)w * 4096 + s0 * 512;
-    const float* cwave = Csave + ((size_t)d * T * NBT + bt) * 4096 + (size_t)w * 1024 + s0 * 512;
+    const CE* cwave = Csave + ((size_t)d * T * NBT + bt) * 4096 + (size_t)w * 1024 + s0 * 512;
     const unsigned lane_p = frag_lane<PE>(rq, c16);        // saved gates (storage type PE)
-    const unsigned lane_c = frag_lane<float>(rq, c16);     // c (always fp32)
+    const unsigned lane_c = frag_lane<CE>(rq, c16);        // c (storage type CE)
     const int DH = D * H, D4H = D * 4 * H;
     const int row0 = bt * 32 + s0 * 16;
     const DE* dywave = dY + (size_t)row0 * DH + d * H + 32 * w;
@@ -258,9 +267,16 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_bwd_h128_bf16_s16_kernel(
 
     auto load_c = [&](int t, f32x4 (&dst)[2]) {
         if (t >= 0 && t < T) {
-            const float* cq = cwave + (size_t)t * cstep;
+            const CE* cq = cwave + (size_t)t * cstep;
 #pragma unroll
-            for (int cbu = 0; cbu < 2; ++cbu) dst[cbu] = *reinterpret_cast<const f32x4*>((cq + cbu * 64) + lane_c);
+            for (int cbu = 0; cbu < 2; ++cbu) {
+                if constexpr (sizeof(CE) == 4) dst[cbu] = *reinterpret_cast<const f32x4*>((cq + cbu * FRAG_CBU<CE>) + lane_c);
+                else {
+                    const bf16x4 v = *reinterpret_cast<const bf16x4*>((cq + cbu * FRAG_CBU<CE>) + lane_c);
+                    f32x4 f = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+                    dst[cbu] = f;
+                }
+            }
         } else {
 #pragma unroll
             for (int cbu = 0; cbu < 2; ++cbu) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; dst[cbu] = z; }
@@ -353,18 +369,23 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_bwd_h128_bf16_s16_kernel(
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_cvoid;
 
-constexpr int RING_WAVE = 4096 + 2048;        // bytes per wave per slot: G (4 gates x 1 KB bf16) + c (2 KB fp32)
-constexpr int RING_SLOT = 4 * RING_WAVE;      // 24 KB
+template <bool C16> constexpr int RING_WAVE = 4096 + (C16 ? 1024 : 2048);   // bytes per wave per slot: G (4 gates x 1 KB bf16) + c (1 KB bf16 / 2 KB fp32)
+template <bool C16> constexpr int RING_SLOT = 4 * RING_WAVE<C16>;          // 20 / 24 KB
 
 // DY16: the incoming gradient dY is stored as bf16 (the dX GEMM / LayerNorm backward above write it so): the eight
 // hand-issued loads per step become global_load_ushort (same count: the vmcnt bookkeeping is unchanged) and the
 // 16 bits are shifted into an fp32 after the wait.
-template <int D, bool DY16>
+// C16: the saved cell state is bf16 ([q pair][lane][8], one 1-KB DMA instruction per step instead of two fp32 ones):
+// every step then issues 8 + 5 + 4 = 17 VMEM operations instead of 18, and both counted waits drop by one.
+template <int D, bool DY16, bool C16>
 __global__ __launch_bounds__(256, 2) void lstm_rec_bwd_h128_bf16_s16_dma_kernel(
-    const __bf16* __restrict__ G, const float* __restrict__ Csave, const float* __restrict__ Whh,
+    const __bf16* __restrict__ G, const void* __restrict__ Csavev, const float* __restrict__ Whh,
     const void* __restrict__ dYv, __bf16* __restrict__ dP, float* __restrict__ dbias, int T, int Bp) {
+    constexpr int NCD = C16 ? 1 : 2;                         // DMA instructions for c per step
+    constexpr int VM_FIRST = 8 + 4 + NCD, VM_LOOP = VM_FIRST + 4;     // see the wait before the loop
+    constexpr int CB = C16 ? 2 : 4;                          // bytes per stored c element
     __shared__ __attribute__((aligned(16))) __bf16 dgs[16 * DGB_LD];
-    __shared__ __attribute__((aligned(1024))) unsigned char ring[2 * RING_SLOT];
+    __shared__ __attribute__((aligned(1024))) unsigned char ring[2 * RING_SLOT<C16>];
     __shared__ float dbs[8 * 256];                 // bias-gradient partial sums, lane-private: [g][cbu][tid]
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -388,9 +409,10 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_bwd_h128_bf16_s16_dma_kernel(
     }
     const size_t gstep = (size_t)NBT * 16 * 1024, cstep = (size_t)NBT * 4096;
     const __bf16* gwave = G + ((size_t)d * T * NBT + bt) * 16 * 1024 + (size_t)w * 4096 + s0 * 512;
-    const float* cwave = Csave + ((size_t)d * T * NBT + bt) * 4096 + (size_t)w * 1024 + s0 * 512;
+    const char* cwave = reinterpret_cast<const char*>(Csavev) +
+                        (((size_t)d * T * NBT + bt) * 4096 + (size_t)w * 1024 + s0 * 512) * CB;
     const unsigned lane_g = 2 * frag_lane<__bf16>(rq, c16);   // byte offset of this lane's gates in a 1-KB gate chunk
-    const unsigned lane_c = frag_lane<float>(rq, c16);        // element offset of this lane's c values
+    const unsigned lane_c = frag_lane<float>(rq, c16);        // element offset of this lane's c values (fp32 c)
     constexpr int DH = D * H, D4H = D * 4 * H;
     const int row0 = bt * 32 + s0 * 16;
     constexpr int DYB = DY16 ? 2 : 4;                          // bytes per dY element
@@ -409,28 +431,36 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_bwd_h128_bf16_s16_dma_kernel(
 #pragma unroll
     for (int i = 0; i < 8; ++i) dbs[i * 256 + tid] = 0.f;
     {   // c of the first step: plain load
-        const float* cq = cwave + (size_t)t_first * cstep;
+        const char* cq = cwave + (size_t)t_first * cstep * CB;
 #pragma unroll
-        for (int cbu = 0; cbu < 2; ++cbu) ct[cbu] = *reinterpret_cast<const f32x4*>((cq + cbu * 64) + lane_c);
+        for (int cbu = 0; cbu < 2; ++cbu) {
+            if constexpr (C16) {
+                const bf16x4 v = *reinterpret_cast<const bf16x4*>(cq + lane_g + cbu * 256);
+                f32x4 f = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+                ct[cbu] = f;
+            } else {
+                ct[cbu] = *reinterpret_cast<const f32x4*>(cq + 4 * (cbu * 64 + lane_c));
+            }
+        }
     }
-    unsigned char* wring = ring + w * RING_WAVE;          // this wave's part of slot 0; slot 1 at + RING_SLOT
+    unsigned char* wring = ring + w * RING_WAVE<C16>;     // this wave's part of slot 0; slot 1 at + RING_SLOT
     const unsigned ring_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)wring;
-    // DMA of step u into slot u & 1: 4 x 1 KB of saved gates, 2 x 1 KB of c_{t-1} (absent at the last step)
+    // DMA of step u into slot u & 1: 4 x 1 KB of saved gates, NCD x 1 KB of c_{t-1} (absent at the last step)
     // (u is clamped to the last step: the tail re-fetches it into a slot nobody reads again, so that every step
     //  issues the same number of VMEM operations and one counted wait is valid for all of them)
     auto dma_step = [&](int u_) {
         const int u = u_ < T ? u_ : T - 1;
         const int t = t_first + dt * u;
-        unsigned char* dst = wring + (u_ & 1) * RING_SLOT;
+        unsigned char* dst = wring + (u_ & 1) * RING_SLOT<C16>;
         const __bf16* gsrc = gwave + (size_t)t * gstep + lane * 8;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             __builtin_amdgcn_global_load_lds((gbl_cvoid*)(gsrc + g * 1024), (lds_void*)(dst + g * 1024), 16, 0, 0);
         const int tc = u + 1 < T ? t + dt : t;            // c_{t-1}; the last step has none (cp = 0 there): any valid block
-        const float* csrc = cwave + (size_t)tc * cstep + lane * 4;
+        const char* csrc = cwave + (size_t)tc * cstep * CB + lane * 16;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_cvoid*)(csrc + i * 256), (lds_void*)(dst + 4096 + i * 1024), 16, 0, 0);
+        for (int i = 0; i < NCD; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_cvoid*)(csrc + i * 1024), (lds_void*)(dst + 4096 + i * 1024), 16, 0, 0);
     };
     float dya[2][4], dyb[2][4];
     // dY loads are issued by hand (inline asm), so that the compiler's own wait-count bookkeeping never sees a
@@ -464,14 +494,15 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_bwd_h128_bf16_s16_dma_kernel(
     dma_step(0);
     load_dy(1, dyb);
     dma_step(1);
-    // VMEM operations of this wave younger than DMA(s) when step s starts: step 0: dy(1) 8 + DMA(1) 6 = 14 (waited
-    // for here); step 1: dy(2) 8 + DMA(2) 6 + stores(0) 4 = 18; later steps 22 -> one in-loop wait, vmcnt(18)
-    asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+    // VMEM operations of this wave younger than DMA(s) when step s starts (fp32 c: 6 DMA instructions per step, bf16
+    // c: 5): step 0: dy(1) 8 + DMA(1) 6|5 = 14|13 (waited for here); step 1: dy(2) 8 + DMA(2) 6|5 + stores(0) 4 = 18|17;
+    // later steps 22|21 -> one in-loop wait, vmcnt(18|17)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_FIRST) : "memory");
     auto one_step = [&](int step, float (&dy)[2][4]) {
         const int t = t_first + dt * step;
-        asm volatile("s_waitcnt vmcnt(18)"
+        asm volatile("s_waitcnt vmcnt(%8)"
                      : "+v"(dy[0][0]), "+v"(dy[0][1]), "+v"(dy[0][2]), "+v"(dy[0][3]),
-                       "+v"(dy[1][0]), "+v"(dy[1][1]), "+v"(dy[1][2]), "+v"(dy[1][3]) :: "memory");
+                       "+v"(dy[1][0]), "+v"(dy[1][1]), "+v"(dy[1][2]), "+v"(dy[1][3]) : "n"(VM_LOOP) : "memory");
         if constexpr (DY16) {               // zero-extended bf16 bits -> fp32
 #pragma unroll
             for (int cbu = 0; cbu < 2; ++cbu)
@@ -481,14 +512,31 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_bwd_h128_bf16_s16_dma_kernel(
         }
         // ring reads through inline asm: an ordinary LDS read of a DMA target makes hipcc wait for ALL outstanding
         // DMAs (vmcnt(0)), i.e. also for the slot that is being filled for the step after next
-        const unsigned ring_a = ring_base + (unsigned)((step & 1) * RING_SLOT);
+        const unsigned ring_a = ring_base + (unsigned)((step & 1) * RING_SLOT<C16>);
         __bf16* dgw = dgs + 4 * rq * DGB_LD + 32 * w + c16;
         f32x4 cp[2];
 #pragma unroll
         for (int cbu = 0; cbu < 2; ++cbu) {
             u32x2 ri, rf, rc, ro;
             f32x4 cpl;
-            if (cbu == 0)
+            if constexpr (C16) {            // c_{t-1} as bf16, same lane mapping as one gate chunk
+                u32x2 rcp;
+                if (cbu == 0)
+                    asm volatile("ds_read_b64 %0, %5 offset:0\n\tds_read_b64 %1, %5 offset:1024\n\t"
+                                 "ds_read_b64 %2, %5 offset:2048\n\tds_read_b64 %3, %5 offset:3072\n\t"
+                                 "ds_read_b64 %4, %5 offset:4096\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(ri), "=&v"(rf), "=&v"(rc), "=&v"(ro), "=&v"(rcp)
+                                 : "v"(ring_a + lane_g) : "memory");
+                else
+                    asm volatile("ds_read_b64 %0, %5 offset:256\n\tds_read_b64 %1, %5 offset:1280\n\t"
+                                 "ds_read_b64 %2, %5 offset:2304\n\tds_read_b64 %3, %5 offset:3328\n\t"
+                                 "ds_read_b64 %4, %5 offset:4352\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(ri), "=&v"(rf), "=&v"(rc), "=&v"(ro), "=&v"(rcp)
+                                 : "v"(ring_a + lane_g) : "memory");
+                const bf16x4 cb4 = __builtin_bit_cast(bf16x4, rcp);
+                f32x4 f = {(float)cb4[0], (float)cb4[1], (float)cb4[2], (float)cb4[3]};
+                cpl = f;
+            } else if (cbu == 0)
                 asm volatile("ds_read_b64 %0, %5 offset:0\n\tds_read_b64 %1, %5 offset:1024\n\t"
                              "ds_read_b64 %2, %5 offset:2048\n\tds_read_b64 %3, %5 offset:3072\n\t"
                              "ds_read_b128 %4, %6 offset:4096\n\ts_waitcnt lgkmcnt(0)"
@@ -566,53 +614,63 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_bwd_h128_bf16_s16_dma_kernel(
 }  // namespace
 
 // Internal entry points used by lob_lstm_rec_fwd_bf16 / lob_lstm_rec_bwd_bf16 (lstm_rec_bf16.hip).
-int lob_rec_fwd_bf16_s16(void* P, int pg_bf16, const float* Whh, float* Y, float* Csave, void* Y16, void* Yd,
+int lob_rec_fwd_bf16_s16(void* P, int pg_bf16, const float* Whh, float* Y, void* Csave, int c_bf16, void* Y16, void* Yd,
                          float drop_p, uint64_t seed, int T, int Bp, int D, int save, hipStream_t s) {
     const dim3 grid(Bp / 16, D), block(256);
     __bf16* y16 = reinterpret_cast<__bf16*>(Y16);
     __bf16* yd = reinterpret_cast<__bf16*>(Yd);
-#define LOB_FWD(SV, YF, Y6, DR, PE) hipLaunchKernelGGL((lstm_rec_fwd_h128_bf16_s16_kernel<SV, YF, Y6, DR, PE>), grid, block, \
-        0, s, reinterpret_cast<PE*>(P), Whh, Y, Csave, y16, yd, drop_p, seed, T, Bp)
-#define LOB_FWD_OUT(SV, PE) do {                                                     \
-        if (Y && !y16 && !yd) LOB_FWD(SV, true, false, false, PE);                   \
-        else if (Y && y16 && !yd) LOB_FWD(SV, true, true, false, PE);                \
-        else if (Y && !y16 && yd) LOB_FWD(SV, true, false, true, PE);                \
-        else if (Y && y16 && yd) LOB_FWD(SV, true, true, true, PE);                  \
-        else if (!Y && y16 && !yd) LOB_FWD(SV, false, true, false, PE);              \
-        else LOB_FWD(SV, false, true, true, PE); } while (0)
-    if (pg_bf16) { if (save) LOB_FWD_OUT(true, __bf16); else LOB_FWD_OUT(false, __bf16); }
-    else         { if (save) LOB_FWD_OUT(true, float); else LOB_FWD_OUT(false, float); }
+    if (c_bf16 && !(pg_bf16 && save)) return LOB_E_SHAPE;          // bf16 c: with bf16 saved gates only
+#define LOB_FWD(SV, YF, Y6, DR, PE, CE) hipLaunchKernelGGL((lstm_rec_fwd_h128_bf16_s16_kernel<SV, YF, Y6, DR, PE, CE>), grid, block, \
+        0, s, reinterpret_cast<PE*>(P), Whh, Y, reinterpret_cast<CE*>(Csave), y16, yd, drop_p, seed, T, Bp)
+#define LOB_FWD_OUT(SV, PE, CE) do {                                                     \
+        if (Y && !y16 && !yd) LOB_FWD(SV, true, false, false, PE, CE);                   \
+        else if (Y && y16 && !yd) LOB_FWD(SV, true, true, false, PE, CE);                \
+        else if (Y && !y16 && yd) LOB_FWD(SV, true, false, true, PE, CE);                \
+        else if (Y && y16 && yd) LOB_FWD(SV, true, true, true, PE, CE);                  \
+        else if (!Y && y16 && !yd) LOB_FWD(SV, false, true, false, PE, CE);              \
+        else LOB_FWD(SV, false, true, true, PE, CE); } while (0)
+    if (pg_bf16 && c_bf16) LOB_FWD_OUT(true, __bf16, __bf16);
+    else if (pg_bf16) { if (save) LOB_FWD_OUT(true, __bf16, float); else LOB_FWD_OUT(false, __bf16, float); }
+    else              { if (save) LOB_FWD_OUT(true, float, float); else LOB_FWD_OUT(false, float, float); }
 #undef LOB_FWD_OUT
 #undef LOB_FWD
     LOB_CHECK_LAUNCH();
     return 0;
 }
 
-int lob_rec_bwd_bf16_s16(const void* G, int pg_bf16, const float* Csave, const float* Whh, const void* dY, int dy_bf16,
-                         void* dP, float* dbias, int T, int Bp, int D, hipStream_t s) {
+int lob_rec_bwd_bf16_s16(const void* G, int pg_bf16, const void* Csave, int c_bf16, const float* Whh, const void* dY,
+                         int dy_bf16, void* dP, float* dbias, int T, int Bp, int D, hipStream_t s) {
     const dim3 grid(Bp / 16, D), block(256);
     // LOB_VAR_REC_BWD_DMA = 0 selects the register-prefetch kernel (also the only one for fp32 saved gates)
     const bool dma = lob_variant(LOB_VAR_REC_BWD_DMA) != 0;
     const __bf16* g16 = reinterpret_cast<const __bf16*>(G);
     __bf16* dp16 = reinterpret_cast<__bf16*>(dP);
+    if ((dy_bf16 || c_bf16) && !pg_bf16) return LOB_E_SHAPE;       // bf16 dY / c only with bf16 saved gates
     if (pg_bf16 && dma) {
-#define LOB_BWD_DMA(DD, Y16) hipLaunchKernelGGL((lstm_rec_bwd_h128_bf16_s16_dma_kernel<DD, Y16>), grid, block, 0, s, \
-                                                g16, Csave, Whh, dY, dp16, dbias, T, Bp)
-        if (D == 2) { if (dy_bf16) LOB_BWD_DMA(2, true); else LOB_BWD_DMA(2, false); }
-        else        { if (dy_bf16) LOB_BWD_DMA(1, true); else LOB_BWD_DMA(1, false); }
+#define LOB_BWD_DMA(DD, Y16, C16) hipLaunchKernelGGL((lstm_rec_bwd_h128_bf16_s16_dma_kernel<DD, Y16, C16>), grid, block, 0, s, \
+                                                     g16, Csave, Whh, dY, dp16, dbias, T, Bp)
+#define LOB_BWD_DMA_D(DD) do {                                                               \
+        if (dy_bf16 && c_bf16) LOB_BWD_DMA(DD, true, true);                                  \
+        else if (dy_bf16)      LOB_BWD_DMA(DD, true, false);                                 \
+        else if (c_bf16)       LOB_BWD_DMA(DD, false, true);                                 \
+        else                   LOB_BWD_DMA(DD, false, false); } while (0)
+        if (D == 2) LOB_BWD_DMA_D(2); else LOB_BWD_DMA_D(1);
+#undef LOB_BWD_DMA_D
 #undef LOB_BWD_DMA
     }
-    else if (pg_bf16 && dy_bf16)
-        hipLaunchKernelGGL((lstm_rec_bwd_h128_bf16_s16_kernel<__bf16, __bf16>), grid, block, 0, s,
-                           g16, Csave, Whh, reinterpret_cast<const __bf16*>(dY), dp16, dbias, T, Bp);
-    else if (pg_bf16)
-        hipLaunchKernelGGL((lstm_rec_bwd_h128_bf16_s16_kernel<__bf16, float>), grid, block, 0, s,
-                           g16, Csave, Whh, reinterpret_cast<const float*>(dY), dp16, dbias, T, Bp);
-    else if (dy_bf16)
-        return LOB_E_SHAPE;                 // bf16 dY only with bf16 saved gates
+    else if (pg_bf16) {
+#define LOB_BWD_REG(DE, CE) hipLaunchKernelGGL((lstm_rec_bwd_h128_bf16_s16_kernel<__bf16, DE, CE>), grid, block, 0, s, g16, \
+                            reinterpret_cast<const CE*>(Csave), Whh, reinterpret_cast<const DE*>(dY), dp16, dbias, T, Bp)
+        if (dy_bf16 && c_bf16) LOB_BWD_REG(__bf16, __bf16);
+        else if (dy_bf16)      LOB_BWD_REG(__bf16, float);
+        else if (c_bf16)       LOB_BWD_REG(float, __bf16);
+        else                   LOB_BWD_REG(float, float);
+#undef LOB_BWD_REG
+    }
     else
-        hipLaunchKernelGGL((lstm_rec_bwd_h128_bf16_s16_kernel<float, float>), grid, block, 0, s,
-                           reinterpret_cast<const float*>(G), Csave, Whh, reinterpret_cast<const float*>(dY), dp16, dbias, T, Bp);
+        hipLaunchKernelGGL((lstm_rec_bwd_h128_bf16_s16_kernel<float, float, float>), grid, block, 0, s,
+                           reinterpret_cast<const float*>(G), reinterpret_cast<const float*>(Csave), Whh,
+                           reinterpret_cast<const float*>(dY), dp16, dbias, T, Bp);
     LOB_CHECK_LAUNCH();
     return 0;
 }

@@ -21,6 +21,15 @@ OUT_BF16, DY_BF16 = 0x400, 0x800      # LOB_OUT_BF16 / LOB_DY_BF16 (include/lob.
 DY_BF16_CARRY = True
 
 
+#: mixed mode, H == 128: the cell states saved for BPTT are stored as bf16 (the state carried through time stays fp32).
+C_BF16 = True
+
+
+def c_bf16_ok(H, mixed, p16):
+    """bf16 storage of the saved cell states: the 16-row H == 128 bf16 kernels with bf16 saved gates."""
+    return bool(mixed) and C_BF16 and bool(p16) and H == 128 and _lib.get_variant("REC_BF16_ROWS") != 32
+
+
 def dy_bf16_ok(H, mixed):
     """The 16-row bf16 BPTT kernels (H == 128) read a bf16 dY."""
     return bool(mixed) and DY_BF16_CARRY and PG_BF16 and H == 128 and _lib.get_variant("REC_BF16_ROWS") != 32
@@ -243,7 +252,8 @@ def lstm_rec_fwd(P, whh, T, Bp, H, D, save, mixed=False, drop_p=0.0, seed=0, wan
     _chk(P, "P", P.dtype if p16 else torch.float32); _chk(whh, "whh")
     assert whh.shape == (D, 4 * H, H)
     dev = P.device
-    Cs = torch.empty((D * T * Bp * H,), device=dev, dtype=torch.float32) if save else None
+    c16 = bool(save) and c_bf16_ok(H, mixed, p16)
+    Cs = torch.empty((D * T * Bp * H,), device=dev, dtype=torch.bfloat16 if c16 else torch.float32) if save else None
     Y = Y16 = Yd = None
     if mixed and bf16_rec(H, p16):
         # H == 256 streams the weights from L2: hand them over as bf16 in MFMA fragment order (include/lob.h), so
@@ -257,8 +267,8 @@ def lstm_rec_fwd(P, whh, T, Bp, H, D, save, mixed=False, drop_p=0.0, seed=0, wan
             Y16 = torch.empty((T * Bp, D * H), device=dev, dtype=torch.bfloat16)
         if drop_p > 0:
             Yd = torch.empty((T * Bp, D * H), device=dev, dtype=torch.bfloat16)
-        rc = _lib.lib().lob_lstm_rec_fwd_bf16(_ptr(P), int(p16), _ptr(whh), _ptr(whh16), _ptr(Y), _ptr(Cs), _ptr(Y16), _ptr(Yd),
-                                              float(drop_p), C.c_uint64(seed), T, Bp, H, D, 1 if save else 0,
+        rc = _lib.lib().lob_lstm_rec_fwd_bf16(_ptr(P), int(p16), _ptr(whh), _ptr(whh16), _ptr(Y), _ptr(Cs), int(c16), _ptr(Y16),
+                                              _ptr(Yd), float(drop_p), C.c_uint64(seed), T, Bp, H, D, 1 if save else 0,
                                               _stream())
     else:
         assert drop_p == 0 and not p16 and not want_bf16
@@ -363,11 +373,12 @@ def lstm_rec_bwd(G, Cs, whh, dY, T, Bp, H, D, dp_bf16=False, dbias=None):
     """BPTT through one layer; returns (dP[T*Bp, D*4H] row-major fp32|bf16, dbias[D*4H]); dbias: zeroed destination."""
     g16 = G.dtype == torch.bfloat16
     dy16 = dY.dtype == torch.bfloat16
-    _chk(G, "G", G.dtype if g16 else torch.float32); _chk(Cs, "Csave"); _chk(whh, "whh")
-    _chk(dY, "dY", torch.bfloat16 if dy16 else torch.float32)
+    c16 = Cs.dtype == torch.bfloat16
+    _chk(G, "G", G.dtype if g16 else torch.float32); _chk(Cs, "Csave", torch.bfloat16 if c16 else torch.float32)
+    _chk(whh, "whh"); _chk(dY, "dY", torch.bfloat16 if dy16 else torch.float32)
     assert dY.shape == (T * Bp, D * H) and (not g16 or (dp_bf16 and bf16_rec(H, g16)))
-    if dy16 and not (dp_bf16 and bf16_rec(H, g16) and H == 128):
-        raise _lib.LobError("lstm_rec_bwd: a bf16 dY is read by the H = 128 bf16 BPTT kernels only")
+    if (dy16 or c16) and not (dp_bf16 and bf16_rec(H, g16) and H == 128):
+        raise _lib.LobError("lstm_rec_bwd: bf16 dY / cell states are read by the H = 128 bf16 BPTT kernels only")
     dP = torch.empty((T * Bp, D * 4 * H), device=G.device, dtype=torch.bfloat16 if dp_bf16 else torch.float32)
     fused_bias = uses_frag(H)
     if dbias is None:
@@ -377,8 +388,8 @@ def lstm_rec_bwd(G, Cs, whh, dY, T, Bp, H, D, dp_bf16=False, dbias=None):
         whht16 = None
         if H == 256:       # [D, ks 64, hi 2, j 8, w 8, l31 32] -> [D, w, ks, hi, l31, j]  (fragment order, lob.h)
             whht16 = (whh.to(torch.bfloat16).reshape(D, 64, 2, 8, 8, 32).permute(0, 4, 1, 2, 5, 3).contiguous())
-        rc = _lib.lib().lob_lstm_rec_bwd_bf16(_ptr(G), int(g16), _ptr(Cs), _ptr(whh), _ptr(whht16), _ptr(dY), int(dy16),
-                                              _ptr(dP), _ptr(dbias), T, Bp, H, D, _stream())
+        rc = _lib.lib().lob_lstm_rec_bwd_bf16(_ptr(G), int(g16), _ptr(Cs), int(c16), _ptr(whh), _ptr(whht16), _ptr(dY),
+                                              int(dy16), _ptr(dP), _ptr(dbias), T, Bp, H, D, _stream())
     else:
         rc = _lib.lib().lob_lstm_rec_bwd_f32(_ptr(G), _ptr(Cs), _ptr(whh), _ptr(dY), _ptr(dP), int(dp_bf16),
                                              _ptr(dbias) if fused_bias else _ptr(None), T, Bp, H, D, _stream())

@@ -49,9 +49,19 @@ def layer_state(dev):
     whh = _rand((D, 4 * H, H), dev, 4, 0.06)
     P = ops.gate_gemm_x(x, wih, bias, T, Bp, H, D, True, mixed=True)
     G = P.clone()
+    assert ops.C_BF16
     Y, Cs, Y16, _ = ops.lstm_rec_fwd(G, whh, T, Bp, H, D, True, mixed=True, want_f32=False, want_bf16=True)
+    assert Cs.dtype == torch.bfloat16                 # default: bf16 saved cell states
+    ops.C_BF16 = False
+    try:
+        G32 = P.clone()
+        _, Cs32, Y16b, _ = ops.lstm_rec_fwd(G32, whh, T, Bp, H, D, True, mixed=True, want_f32=False, want_bf16=True)
+    finally:
+        ops.C_BF16 = True
+    # the storage type of c changes nothing the forward computes
+    assert Cs32.dtype == torch.float32 and torch.equal(G32, G) and torch.equal(Y16b, Y16)
     dY = _rand((rows, D * H), dev, 5, 1e-3)
-    return dict(H=H, D=D, K=K, Bp=Bp, rows=rows, x=x, wih=wih, bias=bias, whh=whh, P=P, G=G, Cs=Cs, Y16=Y16, dY=dY)
+    return dict(H=H, D=D, K=K, Bp=Bp, rows=rows, x=x, wih=wih, bias=bias, whh=whh, P=P, G=G, Cs=Cs, Cs32=Cs32, Y16=Y16, dY=dY)
 
 
 def test_gate_gemm_weight_stationary_bit_identical_to_tiled(dev, layer_state):
@@ -90,23 +100,30 @@ def test_gate_gemm_weight_stationary_ragged(dev, Tn, Bn, K):
         assert torch.equal(p_ws, p_tl), (Tn, Bn, K, D)
 
 
+@pytest.mark.parametrize("c_key", ["Cs", "Cs32"])
 @pytest.mark.parametrize("dy_dtype", [torch.float32, torch.bfloat16])
-def test_bptt_dma_ring_bit_identical_to_register_prefetch(dev, layer_state, dy_dtype):
-    """lstm_rec_bwd_h128_bf16_s16_dma_kernel (wave-private LDS-DMA ring, vmcnt(14)/(18)) against the register-prefetch
-    kernel: same arithmetic in the same order -> dP bit-identical over all 1M rows; the bias gradient (fp32 atomics
-    over 512 workgroups) to rounding.  Both storage types of the incoming gradient (fp32; bf16 = the mixed path's
-    default carry, hand-issued global_load_ushort)."""
+def test_bptt_dma_ring_bit_identical_to_register_prefetch(dev, layer_state, dy_dtype, c_key):
+    """lstm_rec_bwd_h128_bf16_s16_dma_kernel (wave-private LDS-DMA ring, counted vmcnt: 14/18 with fp32 cell states,
+    13/17 with bf16 ones) against the register-prefetch kernel: same arithmetic in the same order -> dP bit-identical
+    over all 1M rows; the bias gradient (fp32 atomics over 512 workgroups) to rounding.  All four combinations of the
+    storage types of the incoming gradient (fp32 | bf16: hand-issued global_load_ushort) and of the saved cell state."""
     from lstm_ode_bci_amd import _lib, ops
     s = layer_state
     dY = s["dY"].to(dy_dtype)
+    Cs = s[c_key]
     with _lib.variant(REC_BWD_DMA=1):
-        dP1, db1 = ops.lstm_rec_bwd(s["G"], s["Cs"], s["whh"], dY, T, s["Bp"], s["H"], s["D"], dp_bf16=True)
+        dP1, db1 = ops.lstm_rec_bwd(s["G"], Cs, s["whh"], dY, T, s["Bp"], s["H"], s["D"], dp_bf16=True)
     with _lib.variant(REC_BWD_DMA=0):
-        dP0, db0 = ops.lstm_rec_bwd(s["G"], s["Cs"], s["whh"], dY, T, s["Bp"], s["H"], s["D"], dp_bf16=True)
+        dP0, db0 = ops.lstm_rec_bwd(s["G"], Cs, s["whh"], dY, T, s["Bp"], s["H"], s["D"], dp_bf16=True)
     if dy_dtype == torch.bfloat16:          # a bf16 dY == the same values handed over as fp32
         with _lib.variant(REC_BWD_DMA=1):
-            dPf, _ = ops.lstm_rec_bwd(s["G"], s["Cs"], s["whh"], dY.float(), T, s["Bp"], s["H"], s["D"], dp_bf16=True)
+            dPf, _ = ops.lstm_rec_bwd(s["G"], Cs, s["whh"], dY.float(), T, s["Bp"], s["H"], s["D"], dp_bf16=True)
         assert torch.equal(dP1.view(torch.int16), dPf.view(torch.int16))
+    if c_key == "Cs":                       # bf16 cell states: close to the fp32-c result (one rounding of c per use)
+        with _lib.variant(REC_BWD_DMA=1):
+            dPc, _ = ops.lstm_rec_bwd(s["G"], s["Cs32"], s["whh"], dY, T, s["Bp"], s["H"], s["D"], dp_bf16=True)
+        rel = (dP1.float() - dPc.float()).abs().max().item() / dPc.float().abs().max().item()
+        assert 0 < rel < 2e-2, rel
     nbad = int((dP1.view(torch.int16) != dP0.view(torch.int16)).sum())
     assert nbad == 0, f"{nbad} of {dP1.numel()} dP elements differ"
     assert torch.isfinite(dP1.float()).all() and dP1.float().abs().max().item() > 0
@@ -335,8 +352,9 @@ def test_bf16_gradient_carries_round_the_same_fp32_values(dev, layer_state):
 
 
 def test_mixed_step_with_and_without_bf16_carries(dev):
-    """The whole mixed backward with the gradient carries in bf16 (default) against fp32 carries: the two differ by the
-    one extra rounding per layer boundary -- well inside the mixed tolerance; worst tensor printed."""
+    """The whole mixed backward with the gradient carries and the saved cell states in bf16 (default) against fp32
+    storage of both: the two differ by one extra rounding per layer boundary / per use of c -- well inside the mixed
+    tolerance; worst tensor printed."""
     from lstm_ode_bci_amd import EnhancedLSTMModel, ops
     sd = syn.make_state_dict(61, 128, 3, 2, True)
     x, y = syn.make_windows(256)
@@ -354,10 +372,12 @@ def test_mixed_step_with_and_without_bf16_carries(dev):
     assert ops.DY_BF16_CARRY
     g16 = grads()
     ops.DY_BF16_CARRY = False
+    ops.C_BF16 = False
     try:
         g32 = grads()
     finally:
         ops.DY_BF16_CARRY = True
+        ops.C_BF16 = True
     gref = grads(mixed=False)                          # fp32 path, same masks
     worst = (0.0, None, 0.0)
     for k in g32:
@@ -369,5 +389,5 @@ def test_mixed_step_with_and_without_bf16_carries(dev):
         if e16 > worst[0]:
             worst = (e16, k, e32)
         assert e16 <= 2e-2, (k, e16)
-    print(f"bf16 carries: worst tensor {worst[1]} rel err {worst[0]:.3e} (fp32 carries: {worst[2]:.3e})")
+    print(f"bf16 carries + bf16 c: worst tensor {worst[1]} rel err {worst[0]:.3e} (fp32 storage of both: {worst[2]:.3e})")
     assert any(not torch.equal(g16[k], g32[k]) for k in g16), "the bf16-carry switch changed nothing"

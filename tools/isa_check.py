@@ -20,7 +20,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "lstm_ode_bci_amd", "csrc", "lstm_rec_bf16_s16.hip")
-KERNEL = r"lstm_rec_bwd_h128_bf16_s16_dma_kernelILi%dELb%dEE"
+KERNEL = r"lstm_rec_bwd_h128_bf16_s16_dma_kernelILi%dELb%dELb%dEE"
 
 
 def compile_to_isa(path=None):
@@ -147,11 +147,11 @@ def _regs(text):
     return regs
 
 
-def check_kernel(body):
+def check_kernel(body, vm_loop=18):
     ins = _instrs(body)
     # the steady-state loop: from the first hand-written vmcnt(18) to the last backward branch after it
     labels = {m.group(1): i for i, l in enumerate(body) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
-    waits = [k for k, (_, t, a) in enumerate(ins) if a and t.startswith("s_waitcnt vmcnt(18)")]
+    waits = [k for k, (_, t, a) in enumerate(ins) if a and t.startswith(f"s_waitcnt vmcnt({vm_loop})")]
     assert len(waits) == 2, f"expected the two unrolled half-iterations, found {len(waits)} hand-written waits"
     back = [k for k, (i, t, _) in enumerate(ins)
             for m in [re.search(r"s_c?branch\S*\s+(\.LBB\d+_\d+)", t)] if m and labels.get(m.group(1), 1 << 30) < i]
@@ -181,7 +181,7 @@ def check_kernel(body):
         seen_waits = 0
         for step in range(n):
             _, t, a = loop[(k + step) % n]
-            if a and t.startswith("s_waitcnt vmcnt(18)"):
+            if a and t.startswith(f"s_waitcnt vmcnt({vm_loop})"):
                 seen_waits += 1
                 if seen_waits == 2:
                     break
@@ -196,7 +196,9 @@ def main(path=None):
     problems = []
     for D in (1, 2):
         for y16 in (0, 1):
-            problems += [f"D={D} dy_bf16={y16}: {p}" for p in check_kernel(_function(lines, KERNEL % (D, y16)))]
+            for c16 in (0, 1):     # bf16 cell states: one DMA instruction fewer per step -> vmcnt(17)
+                problems += [f"D={D} dy_bf16={y16} c_bf16={c16}: {p}"
+                             for p in check_kernel(_function(lines, KERNEL % (D, y16, c16)), 17 if c16 else 18)]
     return problems
 
 
