@@ -151,10 +151,17 @@ class LSTMODEIntegration:
             X_batch = X_batch.numpy()
         shape = tuple(X_batch.shape[1:])
         nb = min(chunk, n)
-        copy_stream = torch.cuda.Stream(device=dev)
         main = torch.cuda.current_stream(dev)
-        stage = [torch.empty((nb,) + shape, dtype=torch.float32).pin_memory() for _ in range(2)]
-        dbuf = [torch.empty((nb,) + shape, dtype=torch.float32, device=dev) for _ in range(2)]
+        # page-locked staging buffers and the copy stream are kept on the object: pinning 2 x 256 MB costs more than
+        # moving it (hipHostMalloc + first touch), and predict_batch is called once per evaluation pass (06:461, 537)
+        key = (nb,) + shape + (str(dev),)
+        if getattr(self, "_h2d_key", None) != key:
+            self._h2d_key = key
+            self._h2d_stream = torch.cuda.Stream(device=dev)
+            self._h2d_stage = [torch.empty((nb,) + shape, dtype=torch.float32).pin_memory() for _ in range(2)]
+            self._h2d_dbuf = [torch.empty((nb,) + shape, dtype=torch.float32, device=dev) for _ in range(2)]
+        copy_stream, stage, dbuf = self._h2d_stream, self._h2d_stage, self._h2d_dbuf
+        torch.cuda.current_stream(dev).synchronize()      # a previous call's kernels may still read dbuf
         done = [None, None]          # events: device buffer b may be overwritten (its consumer kernels finished)
         starts = list(range(0, n, chunk))
 
