@@ -971,6 +971,9 @@ inline int nt_tk() {
 
 }  // namespace
 
+int lob_dx_ksplit(const void* A, int lda, const void* Wt, void* C, int ldc, int M, int N, int K, int out_bf16, float drop_p,
+                  uint64_t seed, hipStream_t s);         // dx_ksplit.hip
+
 // A: fp32 (a_bf16 = 0) or bf16 (a_bf16 = 1) row-major [M][lda]; W fp32 [N][ldw]; C fp32.
 inline int nt_stagger() {       // tuning knob LOB_NT_STAGGER (units of s_sleep(32) = 2048 clocks per group step)
     const int v = lob_variant(LOB_VAR_NT_STAGGER);
@@ -1048,6 +1051,10 @@ extern "C" int lob_gemm_nt_bf16(const void* A, int a_bf16, int lda, const void* 
     if (out16 && !(a_bf16 && w_bf16)) return LOB_E_SHAPE;      // bf16 C: the LDS-DMA kernel's row-major epilogue only
     if (w_bf16) {      // both operands bf16 in HBM: LDS-DMA kernel (no bias / activation in its row-major epilogue)
         if (!a_bf16 || (act & LOB_ACCUMULATE) || N > 2048 || (K % DTK) || K / DTK < DS || (ldw % 8)) return LOB_E_SHAPE;
+        // dX = dP W_ih (wide contraction, narrow output): weights stationary, contraction split over the waves
+        if (!bias && (act & 0xff) == LOB_ACT_NONE && (K == 512 || K == 1024) && (N == 128 || N == 256) && (M % 16) == 0 &&
+            ldw == K && (ldc % 4) == 0 && al16(C) && lob_variant(LOB_VAR_DX_KSPLIT) != 0)
+            return lob_dx_ksplit(A, lda, W, C, ldc, M, N, K, out16, drop_p, seed, (hipStream_t)stream);
         launch_nt_dma<0>(g, (hipStream_t)stream);
         LOB_CHECK_LAUNCH();
         return 0;

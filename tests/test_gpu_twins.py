@@ -391,3 +391,31 @@ def test_mixed_step_with_and_without_bf16_carries(dev):
         assert e16 <= 2e-2, (k, e16)
     print(f"bf16 carries + bf16 c: worst tensor {worst[1]} rel err {worst[0]:.3e} (fp32 storage of both: {worst[2]:.3e})")
     assert any(not torch.equal(g16[k], g32[k]) for k in g16), "the bf16-carry switch changed nothing"
+
+
+@pytest.mark.parametrize("M,N,K", [(T * 4096, 256, 1024), (T * 4096, 128, 1024), (16, 256, 1024), (48, 128, 512),
+                                   (4096 + 16, 256, 512), (2064, 128, 1024)])
+def test_dx_ksplit_kernel_vs_tiled_twin(dev, M, N, K):
+    """dx_ksplit_kernel (weights stationary, contraction split over the eight waves, hand-issued A loads three tiles
+    ahead with a counted vmcnt, cross-wave reduction through LDS) against the tiled LDS-DMA NT GEMM / the register-staged
+    kernel on the same bf16 operands: equal to fp32 summation order (the k-split adds eight partial sums); fp32 and bf16
+    outputs, with and without the fused dropout-backward mask; full size and tile counts below the look-ahead depth."""
+    from lstm_ode_bci_amd import _lib, ops
+    a = _rand((M, K), dev, 81, 1e-2, dtype=torch.bfloat16)
+    wt = _rand((N, K), dev, 82, 0.06, dtype=torch.bfloat16)
+    for kw in (dict(), dict(drop_p=0.4, seed=11)):
+        with _lib.variant(DX_KSPLIT=1):
+            o_ks = ops.gemm_nt(a, wt, mixed=True, **kw)
+            o_ks2 = ops.gemm_nt(a, wt, mixed=True, **kw)
+            o_ks16 = ops.gemm_nt(a, wt, mixed=True, out_bf16=True, **kw)
+        with _lib.variant(DX_KSPLIT=0):
+            o_tl = ops.gemm_nt(a, wt if M % 256 == 0 else wt.float(), mixed=True, **kw)
+        assert torch.equal(o_ks, o_ks2)                               # deterministic (no atomics)
+        sc = o_tl.abs().max().item()
+        assert (o_ks - o_tl).abs().max().item() <= 2e-6 * sc, (kw, (o_ks - o_tl).abs().max().item(), sc)
+        assert torch.equal(o_ks16, o_ks.to(torch.bfloat16))
+    if M <= 4096 + 16:                                                # float64 truth on the small cases
+        ref = a.double() @ wt.double().T
+        with _lib.variant(DX_KSPLIT=1):
+            o = ops.gemm_nt(a, wt, mixed=True)
+        assert (o.double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()

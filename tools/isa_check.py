@@ -113,6 +113,84 @@ def check_gate_ws(path=None):
                                                         ("gate_gemm_ws_split_kernelILi128E", 2, 4, 24)], path))
 
 
+def check_dx_ksplit(path=None):
+    """dx_ksplit.hip: the A-fragment loads are hand-issued (inline asm) three tiles ahead and retired by one counted
+    `s_waitcnt vmcnt(3 KS [+ 3])` per tile.  Inside the tile loop: no compiler-generated VMEM wait, no spill traffic,
+    exactly one store per tile body, and the registers of the in-flight loads are touched by nothing but the asm
+    statements and the MFMAs that consume them (a compiler copy or spill would read them before the data lands)."""
+    src = os.path.join(ROOT, "lstm_ode_bci_amd", "csrc", "dx_ksplit.hip")
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    out = path or os.path.join(tempfile.mkdtemp(prefix="lob_isa_"), "dx.s")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"),
+                    "-I", os.path.dirname(src), "-S", "--cuda-device-only", src, "-o", out],
+                   check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    lines = open(out).read().split("\n")
+    problems = []
+    for KS in (4, 2):
+        pat = "dx_ksplit_kernelILi%dE" % KS
+        body = _function(lines, pat)
+        ins = _instrs(body)
+        # the steady-state tile loop = the blocks hipcc annotates as belonging to the inner loop
+        lab = [(i, l) for i, l in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", l)]
+        hdr = [l.split(":")[0] for i, l in lab if "Inner Loop Header" in l]
+        if len(hdr) != 1:
+            problems.append(f"{pat}: expected one inner loop, found {len(hdr)}")
+            continue
+        tagname = hdr[0].lstrip(".L")
+        inloop = [i for i, l in lab if "Inner Loop Header" in l or f"Header={tagname}" in l]
+        tgt = min(inloop)
+        after = [i for i, l in lab if i > max(inloop)]
+        last_line = (after[0] - 1) if after else len(body) - 1
+        kend = max(k for k, x in enumerate(ins) if x[0] <= last_line)
+        loop = [x for x in ins[:kend + 1] if x[0] >= tgt]
+        if not loop:
+            problems.append(f"{pat}: tile loop not found")
+            continue
+        waits = [t for _, t, a in loop if a and t.startswith("s_waitcnt vmcnt(")]
+        if set(waits) != {f"s_waitcnt vmcnt({3 * KS + 3})"}:
+            problems.append(f"{pat}: hand-written waits in the loop {sorted(set(waits))}, expected vmcnt({3 * KS + 3})")
+        for _, t, a in loop:
+            if not a and re.search(r"s_waitcnt.*vmcnt\(", t):
+                problems.append(f"{pat}: compiler-generated VMEM wait in the tile loop: {t}")
+            if t.startswith("scratch_"):
+                problems.append(f"{pat}: spill traffic in the tile loop: {t}")
+            if not a and t.startswith("global_load"):
+                problems.append(f"{pat}: compiler-visible load in the tile loop: {t}")
+        # every hand-issued load group: its destination registers must not be touched by compiler code until the wait
+        # that retires it -- the THIRD hand-written wait after it (the loads run three tiles ahead); the three groups of
+        # the prologue are retired by the first, second and third wait.  The walk is cyclic inside the loop.
+        ls = next(k for k, x in enumerate(ins) if x[0] >= tgt)
+        n_pro = 0
+
+        def is_ld(k):
+            return ins[k][2] and ins[k][1].startswith("global_load_dwordx4")
+        k = 0
+        while k <= kend:
+            if not is_ld(k) or (k and is_ld(k - 1)):
+                k += 1
+                continue
+            regs, j = set(), k
+            while is_ld(j):
+                regs |= _regs(ins[j][1].split(",")[0])
+                j += 1
+            before_first_wait = not any(x[2] and x[1].startswith("s_waitcnt vmcnt(") and "vmcnt(0)" not in x[1]
+                                        for x in ins[:k])
+            need = (n_pro + 1) if before_first_wait else 3
+            if before_first_wait:
+                n_pro += 1
+            seen, pos, steps = 0, j, 0
+            while seen < need and steps < 4 * len(ins):
+                _, t, a = ins[pos]
+                if a and t.startswith("s_waitcnt vmcnt(") and "vmcnt(0)" not in t:
+                    seen += 1
+                elif not a and (_regs(t) & regs):
+                    problems.append(f"{pat}: register of an in-flight hand-issued load touched before its wait: {t}")
+                pos = ls if pos == kend else pos + 1
+                steps += 1
+            k = j
+    return problems
+
+
 def _function(lines, pat):
     st = next(i for i, l in enumerate(lines) if re.match(r"^_ZN.*" + pat + r".*:", l))
     end = next(i for i in range(st + 1, len(lines)) if lines[i].startswith(".Lfunc_end"))
@@ -203,6 +281,6 @@ def main(path=None):
 
 
 if __name__ == "__main__":
-    probs = main(sys.argv[1] if len(sys.argv) > 1 else None) + check_dma_gemms() + check_gate_ws()
+    probs = main(sys.argv[1] if len(sys.argv) > 1 else None) + check_dma_gemms() + check_gate_ws() + check_dx_ksplit()
     print("\n".join(probs) if probs else "isa_check: ok")
     sys.exit(1 if probs else 0)
