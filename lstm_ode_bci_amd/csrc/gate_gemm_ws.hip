@@ -37,11 +37,20 @@ typedef __attribute__((address_space(1))) const void gbl_cvoid;
 struct WSArgs {
     const __bf16* A; const __bf16* W; const float* bias; __bf16* P;
     int lda, M, T, Bp, D;
+    int ldc, out_bf16;           // EPI = 1 (row-major C): leading dimension in elements, bf16 or fp32 C
 };
 
-template <int K>
+// EPI = 0: the gate GEMM -- 64 columns per wave, 512 per workgroup (one direction), bf16 fragment-order P, bias.
+// EPI = 1 (bf16 C) / 2 (fp32 C): a plain row-major C[M, N] = A W^T (no bias) for narrow contractions -- the attention pooling's
+//          dV = dPreU W1 (K = 128, N = 256; 04_lstm_model.py:118 in the backward of 04:482-512): 32 columns per wave,
+//          256 per workgroup, `D` = number of 256-column groups.  The MFMA runs with its operands SWAPPED (the weights as
+//          the A operand), so a lane holds 4 consecutive columns of one row per accumulator quad: 8-B (bf16) / 16-B
+//          (fp32) stores -- and, as in the fragment epilogue, exactly 8 store instructions per wave and tile.
+template <int K, int EPI>
 __global__ __launch_bounds__(512, 2) void gate_gemm_ws_kernel(WSArgs g) {
     constexpr int MT = 64;                          // rows per tile
+    constexpr int NCB = EPI == 0 ? 2 : 1;           // 32-column blocks per wave
+    constexpr int WGN = 8 * 32 * NCB;               // columns per workgroup
     constexpr int NSLOT = K == 256 ? 4 : 6, LA = NSLOT - 1;
     constexpr int ROWB = 2 * K, SLOTB = MT * ROWB;  // bytes per LDS row / slot
     constexpr int RPI = 1024 / ROWB;                // rows per DMA instruction
@@ -62,21 +71,22 @@ __global__ __launch_bounds__(512, 2) void gate_gemm_ws_kernel(WSArgs g) {
     if (pair >= panels) return;
     const int total = (panels - pair + npair - 1) / npair;
 
-    // ---- stationary B fragments: wreg[cb][s] = W[d*512 + 64 wv + 32 cb + r31][16 s + 8 hi .. + 7]
-    bf16x8 wreg[2][KS];
-    float bv[2];
+    // ---- stationary B fragments: wreg[cb][s] = W[d*WGN + 32 NCB wv + 32 cb + r31][16 s + 8 hi .. + 7]
+    bf16x8 wreg[NCB][KS];
+    float bv[NCB];
+    const int ncol0 = d * WGN + 32 * NCB * wv;
     {
-        const __bf16* wb = g.W + (size_t)(d * 512 + 64 * wv + r31) * K + 8 * hi;
+        const __bf16* wb = g.W + (size_t)(ncol0 + r31) * K + 8 * hi;
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
+        for (int cb = 0; cb < NCB; ++cb) {
 #pragma unroll
             for (int s = 0; s < KS; ++s) wreg[cb][s] = *reinterpret_cast<const bf16x8*>(wb + (size_t)(32 * cb) * K + 16 * s);
-            bv[cb] = g.bias ? g.bias[d * 512 + 64 * wv + 32 * cb + r31] : 0.f;
+            bv[cb] = (EPI == 0 && g.bias) ? g.bias[ncol0 + 32 * cb + r31] : 0.f;
         }
     }
     // make the weights opaque: hipcc otherwise feels free to re-load them inside the loop (256 VGPRs are tight)
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
+    for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
         for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(wreg[cb][s]));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -112,8 +122,8 @@ __global__ __launch_bounds__(512, 2) void gate_gemm_ws_kernel(WSArgs g) {
 #pragma unroll
     for (int s = 0; s < 8; ++s) aoff[s] = (unsigned)(r31 * ROWB + (((2 * s + hi) ^ (r31 & 15)) * 16));
 
-    f32x16 acc[2][2];
-    const int NBT = g.Bp >> 5;
+    f32x16 acc[2][NCB];
+    const int NBT = EPI == 0 ? g.Bp >> 5 : 1;
     const int gate = wv >> 1, w4 = 2 * (wv & 1);
 
     for (int q = 0; q < total; ++q) {
@@ -126,7 +136,7 @@ __global__ __launch_bounds__(512, 2) void gate_gemm_ws_kernel(WSArgs g) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
+            for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][cb][r] = 0.f;
         // fragment reads as inline asm (compiler-visible LDS reads of a DMA target may get an s_waitcnt vmcnt(0) in
@@ -144,16 +154,44 @@ __global__ __launch_bounds__(512, 2) void gate_gemm_ws_kernel(WSArgs g) {
             } else {
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1));
             }
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wreg[0][s], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wreg[1][s], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wreg[0][s], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wreg[1][s], acc[1][1], 0, 0, 0);
+            if constexpr (EPI == 0) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wreg[0][s], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wreg[1][s], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wreg[0][s], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wreg[1][s], acc[1][1], 0, 0, 0);
+            } else {        // operands swapped: D[n][m] -- this lane: row m = r31, columns acc_row(r)
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[0][s], a0, acc[0][0], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[0][s], a1, acc[1][0], 0, 0, 0);
+            }
             a0 = n0; a1 = n1;
         }
 #undef LOB_RD
 
         // ---- epilogue: + bias, bf16, fragment order [d][t][bt][w 4][gate 4][q pair 2][lane 64][8]
         const int m0 = ((pair + npair * q) * 8 + xcd) * MT;
+        if constexpr (EPI >= 1) {
+            // row-major C: lane = row m0 + 32 i + r31; accumulator quad qd = columns ncol0 + 8 qd + 4 hi .. + 3
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = m0 + 32 * i + r31;
+                const bool ok = m0 + 32 * i < g.M;            // wave-uniform (M % 32 == 0): see below
+                const size_t o = (size_t)row * g.ldc + ncol0 + 4 * hi;
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    if (!ok) continue;
+                    if constexpr (EPI == 1) {
+                        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                        bf16x4 v = {(__bf16)acc[i][0][4 * qd], (__bf16)acc[i][0][4 * qd + 1], (__bf16)acc[i][0][4 * qd + 2],
+                                    (__bf16)acc[i][0][4 * qd + 3]};
+                        *reinterpret_cast<bf16x4*>(g.P + o + 8 * qd) = v;
+                    } else {
+                        f32x4 v = {acc[i][0][4 * qd], acc[i][0][4 * qd + 1], acc[i][0][4 * qd + 2], acc[i][0][4 * qd + 3]};
+                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.P) + o + 8 * qd) = v;
+                    }
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int mrow = m0 + 32 * i;
@@ -161,7 +199,7 @@ __global__ __launch_bounds__(512, 2) void gate_gemm_ws_kernel(WSArgs g) {
             const int mr = ok ? mrow : 0;
             const int t = mr / g.Bp, bt = (mr - t * g.Bp) >> 5;
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
+            for (int cb = 0; cb < NCB; ++cb) {
                 const size_t fo = ((((size_t)(d * g.T + t) * NBT + bt) * 4 + (w4 + cb)) * 4 + gate) * 1024;
                 __bf16* dst = g.P + fo + lane * 8;
 #pragma unroll
@@ -190,10 +228,28 @@ int lob_gate_gemm_ws(const void* X, int ldx, const void* Wih, const float* bias,
     int npx = (ntile + 7) / 8;                       // pairs per XCD, one workgroup per CU at most
     const int cap = 32 / D;
     if (npx > cap) npx = cap;
-    WSArgs g{(const __bf16*)X, (const __bf16*)Wih, bias, (__bf16*)P, ldx, M, T, Bp, D};
+    WSArgs g{(const __bf16*)X, (const __bf16*)Wih, bias, (__bf16*)P, ldx, M, T, Bp, D, 0, 0};
     const dim3 grid((unsigned)(8 * D * npx)), block(512);
-    if (K == 256) hipLaunchKernelGGL(gate_gemm_ws_kernel<256>, grid, block, 0, s, g);
-    else          hipLaunchKernelGGL(gate_gemm_ws_kernel<128>, grid, block, 0, s, g);
+    if (K == 256) hipLaunchKernelGGL((gate_gemm_ws_kernel<256, 0>), grid, block, 0, s, g);
+    else          hipLaunchKernelGGL((gate_gemm_ws_kernel<128, 0>), grid, block, 0, s, g);
+    LOB_CHECK_LAUNCH();
+    return 0;
+}
+
+// Row-major C[M, N] = A[M, K] W[N, K]^T, bf16 operands, K in {128, 256}, N a multiple of 256 (<= 1024), M % 32 == 0, no
+// bias / activation; C bf16 or fp32.  Used by lob_gemm_nt_bf16 for the narrow-contraction GEMMs of the backward.
+int lob_gemm_nt_ws(const void* A, int lda, const void* W, void* C, int ldc, int M, int N, int K, int out_bf16, hipStream_t s) {
+    const int ncg = N / 256;
+    const int ntile = (M + 63) / 64;
+    int npx = (ntile + 7) / 8;
+    const int cap = 32 / ncg;
+    if (npx > cap) npx = cap;
+    WSArgs g{(const __bf16*)A, (const __bf16*)W, nullptr, (__bf16*)C, lda, M, 1, 32, ncg, ldc, out_bf16};
+    const dim3 grid((unsigned)(8 * ncg * npx)), block(512);
+    if (K == 256) { if (out_bf16) hipLaunchKernelGGL((gate_gemm_ws_kernel<256, 1>), grid, block, 0, s, g);
+                    else          hipLaunchKernelGGL((gate_gemm_ws_kernel<256, 2>), grid, block, 0, s, g); }
+    else          { if (out_bf16) hipLaunchKernelGGL((gate_gemm_ws_kernel<128, 1>), grid, block, 0, s, g);
+                    else          hipLaunchKernelGGL((gate_gemm_ws_kernel<128, 2>), grid, block, 0, s, g); }
     LOB_CHECK_LAUNCH();
     return 0;
 }

@@ -971,6 +971,8 @@ inline int nt_tk() {
 
 }  // namespace
 
+int lob_gemm_nt_ws(const void* A, int lda, const void* W, void* C, int ldc, int M, int N, int K, int out_bf16,
+                   hipStream_t s);                        // gate_gemm_ws.hip
 int lob_dx_ksplit(const void* A, int lda, const void* Wt, void* C, int ldc, int M, int N, int K, int out_bf16, float drop_p,
                   uint64_t seed, hipStream_t s);         // dx_ksplit.hip
 
@@ -1055,6 +1057,10 @@ extern "C" int lob_gemm_nt_bf16(const void* A, int a_bf16, int lda, const void* 
         if (!bias && (act & 0xff) == LOB_ACT_NONE && (K == 512 || K == 1024) && (N == 128 || N == 256) && (M % 16) == 0 &&
             ldw == K && (ldc % 4) == 0 && al16(C) && lob_variant(LOB_VAR_DX_KSPLIT) != 0)
             return lob_dx_ksplit(A, lda, W, C, ldc, M, N, K, out16, drop_p, seed, (hipStream_t)stream);
+        // narrow contraction, no bias / activation / dropout (dV = dPreU W1 of the attention pooling): weights stationary
+        if (!bias && (act & 0xff) == LOB_ACT_NONE && drop_p == 0.f && (K == 128 || K == 256) && (N % 256) == 0 && N <= 1024 &&
+            (M % 32) == 0 && ldw == K && (ldc % 4) == 0 && al16(C) && lob_variant(LOB_VAR_GATE_WS) != 0)
+            return lob_gemm_nt_ws(A, lda, W, C, ldc, M, N, K, out16, (hipStream_t)stream);
         launch_nt_dma<0>(g, (hipStream_t)stream);
         LOB_CHECK_LAUNCH();
         return 0;

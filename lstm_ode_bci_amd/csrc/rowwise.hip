@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void layernorm_act_bwd_vec_kernel(
     for (int i = 0; i < VPL; ++i) { dga[i] = 0.f; dba[i] = 0.f; dxs[i] = 0.f; if (!norm) { gm[i] = 1.f; bt[i] = 0.f; } }
     const float invw = 1.0f / (float)width;
     const int count = remap_T > 0 ? tiled_count(remap_T, remap_B) : rows;
-    constexpr int RPW = VPL <= 2 ? 4 : 2;       // rows per wave in flight (see the forward kernel)
+    constexpr int RPW = VPL <= 4 ? 4 : 2;       // rows per wave in flight (see the forward kernel)
     for (int g0 = wave * RPW * GPW; g0 < count; g0 += nwaves * RPW * GPW) {
         float vv[RPW][VPL], gov[RPW][VPL];
         int rowv[RPW], orowv[RPW];

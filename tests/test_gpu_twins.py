@@ -419,3 +419,20 @@ def test_dx_ksplit_kernel_vs_tiled_twin(dev, M, N, K):
         with _lib.variant(DX_KSPLIT=1):
             o = ops.gemm_nt(a, wt, mixed=True)
         assert (o.double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("M,N,K", [(T * 4096, 256, 128), (T * 4096, 512, 256), (96, 256, 128), (32, 256, 256), (4096 + 32, 256, 128)])
+def test_row_major_weight_stationary_gemm_vs_tiled_twin(dev, M, N, K):
+    """The row-major epilogue of the weight-stationary kernel (operands swapped so that a lane holds 4 consecutive
+    columns: dV = dPreU W1 of the attention pooling's backward, K = 128, N = 256) against the tiled LDS-DMA / register-
+    staged kernels: same MFMA products in the same k order -> bit-identical; bf16 and fp32 C; M % 64 == 32 tails."""
+    from lstm_ode_bci_amd import _lib, ops
+    a = _rand((M, K), dev, 91, 1e-2, dtype=torch.bfloat16)
+    w = _rand((N, K), dev, 92, 0.06, dtype=torch.bfloat16)
+    with _lib.variant(GATE_WS=1):
+        o_ws = ops.gemm_nt(a, w, mixed=True)
+        o_ws16 = ops.gemm_nt(a, w, mixed=True, out_bf16=True)
+    with _lib.variant(GATE_WS=0):
+        o_tl = ops.gemm_nt(a, w if M % 256 == 0 else w.float(), mixed=True)
+    assert torch.equal(o_ws, o_tl), (o_ws - o_tl).abs().max().item()
+    assert torch.equal(o_ws16, o_tl.to(torch.bfloat16))

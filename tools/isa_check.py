@@ -77,18 +77,12 @@ def _check_ws_kernel(srcname, cases, path=None):
     for pat, ndma, nst, nmfma in cases:
         body = _function(lines, pat)
         ins = _instrs(body)
-        labels = {m.group(1): i for i, l in enumerate(body) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
-        # the tile loop: the innermost backward branch that encloses the MFMAs
-        mf = [k for k, (_, t, _) in enumerate(ins) if t.startswith("v_mfma")]
-        back = [(k, labels[m.group(1)]) for k, (i, t, _) in enumerate(ins)
-                for m in [re.search(r"s_c?branch\S*\s+(\.LBB\d+_\d+)", t)] if m and labels.get(m.group(1), 1 << 30) < i]
-        encl = [(k, tgt) for k, tgt in back if k > mf[-1] and tgt < ins[mf[0]][0]]
-        if not encl:
+        # the tile loop: the annotated inner loop that holds the MFMAs
+        loops = [(a, b) for a, b in _inner_loops(body) if any(x[0] >= a and x[0] <= b and x[1].startswith("v_mfma") for x in ins)]
+        if len(loops) != 1:
             problems.append(f"{pat}: tile loop not found")
             continue
-        tgt = max(t for _, t in encl)                          # innermost loop header in front of the MFMAs
-        kend = max(k for k, t in encl if t == tgt)             # ... and its last backward branch
-        loop = [x for x in ins[:kend + 1] if x[0] >= tgt]
+        loop = [x for x in ins if loops[0][0] <= x[0] <= loops[0][1]]
         n_dma = sum(1 for _, t, _ in loop if t.startswith("global_load_lds"))
         n_st = sum(1 for _, t, _ in loop if t.startswith("global_store"))
         n_mfma = sum(1 for _, t, _ in loop if t.startswith("v_mfma"))
@@ -107,8 +101,12 @@ def _check_ws_kernel(srcname, cases, path=None):
 
 def check_gate_ws(path=None):
     """gate_gemm_ws.hip (mixed path) and gate_gemm_ws_split.hip (fp32 path): one hand-counted ring wait per row tile."""
-    return (_check_ws_kernel("gate_gemm_ws.hip", [("gate_gemm_ws_kernelILi256E", 4, 8, 64),
-                                                  ("gate_gemm_ws_kernelILi128E", 2, 8, 32)], path) +
+    return (_check_ws_kernel("gate_gemm_ws.hip", [("gate_gemm_ws_kernelILi256ELi0E", 4, 8, 64),
+                                                  ("gate_gemm_ws_kernelILi128ELi0E", 2, 8, 32),
+                                                  ("gate_gemm_ws_kernelILi256ELi1E", 4, 8, 32),
+                                                  ("gate_gemm_ws_kernelILi128ELi1E", 2, 8, 16),
+                                                  ("gate_gemm_ws_kernelILi256ELi2E", 4, 8, 32),
+                                                  ("gate_gemm_ws_kernelILi128ELi2E", 2, 8, 16)], path) +
             _check_ws_kernel("gate_gemm_ws_split.hip", [("gate_gemm_ws_split_kernelILi256E", 4, 4, 48),
                                                         ("gate_gemm_ws_split_kernelILi128E", 2, 4, 24)], path))
 
@@ -130,22 +128,14 @@ def check_dx_ksplit(path=None):
         pat = "dx_ksplit_kernelILi%dE" % KS
         body = _function(lines, pat)
         ins = _instrs(body)
-        # the steady-state tile loop = the blocks hipcc annotates as belonging to the inner loop
-        lab = [(i, l) for i, l in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", l)]
-        hdr = [l.split(":")[0] for i, l in lab if "Inner Loop Header" in l]
-        if len(hdr) != 1:
-            problems.append(f"{pat}: expected one inner loop, found {len(hdr)}")
-            continue
-        tagname = hdr[0].lstrip(".L")
-        inloop = [i for i, l in lab if "Inner Loop Header" in l or f"Header={tagname}" in l]
-        tgt = min(inloop)
-        after = [i for i, l in lab if i > max(inloop)]
-        last_line = (after[0] - 1) if after else len(body) - 1
-        kend = max(k for k, x in enumerate(ins) if x[0] <= last_line)
-        loop = [x for x in ins[:kend + 1] if x[0] >= tgt]
-        if not loop:
+        # the steady-state tile loop = the annotated inner loop that holds MFMAs
+        loops = [(x, y) for x, y in _inner_loops(body) if any(x <= z[0] <= y and z[1].startswith("v_mfma") for z in ins)]
+        if len(loops) != 1:
             problems.append(f"{pat}: tile loop not found")
             continue
+        tgt, last_line = loops[0]
+        kend = max(k for k, z in enumerate(ins) if z[0] <= last_line)
+        loop = [z for z in ins[:kend + 1] if z[0] >= tgt]
         waits = [t for _, t, a in loop if a and t.startswith("s_waitcnt vmcnt(")]
         if set(waits) != {f"s_waitcnt vmcnt({3 * KS + 3})"}:
             problems.append(f"{pat}: hand-written waits in the loop {sorted(set(waits))}, expected vmcnt({3 * KS + 3})")
@@ -189,6 +179,26 @@ def check_dx_ksplit(path=None):
                 steps += 1
             k = j
     return problems
+
+
+def _inner_loops(body):
+    """[(first_line, last_line)] of every loop hipcc annotates: from the first block tagged with the loop's header to the
+    last branch that targets one of the loop's own labels."""
+    lab = [(i, l) for i, l in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", l)]
+    out = []
+    for i, l in lab:
+        if "Inner Loop Header" not in l:
+            continue
+        tag = l.split(":")[0].lstrip(".L")
+        inloop = {m.split(":")[0]: j for j, m in lab if j == i or re.search(rf"Header={tag}\b", m)}
+        first = min(inloop.values())
+        last = first
+        for j, t in enumerate(body):
+            m = re.search(r"s_c?branch\S*\s+(\.LBB\d+_\d+)", t)
+            if m and m.group(1) in inloop and j >= first:
+                last = max(last, j)
+        out.append((first, last))
+    return out
 
 
 def _function(lines, pat):
