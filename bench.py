@@ -313,7 +313,7 @@ class Leg:
             # [data-parallel: all-reduce of the flat gradient] -> clip 1.0 + AdamW, all inside the timed step
             from lstm_ode_bci_amd.training import FusedAdamW, WeightedCrossEntropy
             self.criterion = WeightedCrossEntropy(torch.tensor([1.0, 1.0], device=dev)).to(dev)
-            self.opt = FusedAdamW(self.model.parameters(), lr=3e-4, weight_decay=1e-4)
+            self.opt = FusedAdamW(self.model.parameters(), lr=3e-4, weight_decay=1e-4, model=self.model)
 
     def step(self):
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(self.precision == "mixed")):

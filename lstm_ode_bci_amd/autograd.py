@@ -152,13 +152,14 @@ def _forward_impl(x, ps, cfg, save):
 
 class _LobModelFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, cfg, *params):
+    def forward(ctx, x, cfg, sink, *params):
         ps = [_f32c(p) for p in params]
         xf = _f32c(x)
         need_grad = any(ctx.needs_input_grad)      # grad mode is off inside Function.forward
         logits, attn, sv = _forward_impl(xf, ps, cfg, save=need_grad)
         ctx.cfg = cfg
         ctx.sv = sv
+        ctx.sink = sink
         ctx.ps = ps if need_grad else None
         ctx.x_shape = tuple(x.shape)
         ctx.mark_non_differentiable(attn)
@@ -167,11 +168,13 @@ class _LobModelFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits, _dattn):
         from .backward import backward_impl
-        with ops.on_device(dlogits.device):
-            gx, gps = backward_impl(ctx.sv, ctx.ps, ctx.cfg, ctx.x_shape, dlogits.contiguous().float(),
-                                    ctx.needs_input_grad)
         need = ctx.needs_input_grad
-        return (gx, None) + tuple(g if need[2 + i] else None for i, g in enumerate(gps))
+        # need[] is (x, cfg, sink, *params): backward_impl indexes the parameters from position 2
+        nig = (need[0], False) + tuple(need[3:])
+        with ops.on_device(dlogits.device):
+            gx, gps = backward_impl(ctx.sv, ctx.ps, ctx.cfg, ctx.x_shape, dlogits.contiguous().float(), nig,
+                                    sink=ctx.sink)
+        return (gx, None, None) + tuple(g if need[3 + i] else None for i, g in enumerate(gps))
 
 
 _PARAM_GRADS = True
@@ -203,10 +206,18 @@ def lob_forward(model, x, drops, seed):
            mixed)
     params = _collect(model)
     ops.same_device([x] + params, "EnhancedLSTMModel.forward (input and parameters)")
+    sink = None
     if not _PARAM_GRADS:
         params = [None if p is None else p.detach() for p in params]
+    elif torch.is_grad_enabled():
+        # an attached FusedAdamW (training.FusedAdamW(..., model=model)): the backward accumulates the parameter
+        # gradients straight into its flat gradient buffer and hands autograd None for them
+        ref = getattr(model, "_lob_grad_sink", None)
+        opt = ref() if ref is not None else None
+        if opt is not None:
+            sink = opt.sink_for(params, model.num_directions)
     with ops.on_device(x.device), torch.autocast(device_type="cuda", enabled=False):
-        return _LobModelFn.apply(x, cfg, *params)
+        return _LobModelFn.apply(x, cfg, sink, *params)
 
 
 def attention_forward(lstm_output, w1, b1, w2, b2):

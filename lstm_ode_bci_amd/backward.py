@@ -38,17 +38,53 @@ class _ZeroPool:
         return out
 
 
-def _linear_bwd(dy, x, w, need_dx=True, need_w=True, db=None, wt=None, pool=None):
+def _linear_bwd(dy, x, w, need_dx=True, need_w=True, db=None, wt=None, tgt=None, iw=None):
     """y = x w^T + b  ->  (dx, dw, db); db may be handed in when a producer of dy already summed its columns; wt is
-    the pre-built transpose of w (images.build)."""
+    the pre-built transpose of w (images.build); tgt / iw: accumulation targets of parameters iw (weight), iw + 1 (bias)."""
     dw = None
     if need_w:
-        dw = pool.take(w.shape) if pool is not None else torch.zeros_like(w)
+        dw = tgt.param(iw, w.shape) if tgt is not None else torch.zeros_like(w)
         ops.gemm_tn(dy, x, dw)
-        if db is None:
-            db = ops.colsum(dy, pool.take((dy.shape[1],)) if pool is not None else None)
+        if db is None:      # (a db that is handed in has already been accumulated into its target by the producer of dy)
+            db = ops.colsum(dy, tgt.param(iw + 1, (dy.shape[1],)) if tgt is not None else None)
     dx = ops.gemm_nt(dy, wt if wt is not None else _t(w)) if need_dx else None
     return dx, dw, db
+
+
+class _Targets:
+    """Where the backward accumulates parameter gradients.  Every weight-gradient kernel ADDS into its destination (fp32
+    atomics), so the destination can be either a zeroed piece of one pool (the gradients are then returned to autograd,
+    which adds them to p.grad with one launch per parameter) or -- with a gradient sink, i.e. an attached FusedAdamW --
+    the parameter's own slice of the optimizer's flat gradient buffer: no zero fill, no per-parameter accumulation
+    launches, and autograd receives None for the parameters."""
+
+    def __init__(self, ps, dev, sink):
+        self.sink = sink
+        self.pool = _ZeroPool(dev, sum(p.numel() + 64 for p in ps if p is not None) + 8192 if sink is None else 16384)
+
+    def zeros(self, shape):
+        return self.pool.take(shape)
+
+    def param(self, i, shape):
+        """Accumulation target of parameter i."""
+        return self.sink.view(i, shape) if self.sink is not None else self.pool.take(shape)
+
+    def span(self, i, step, count, shape):
+        """One contiguous target covering parameters i, i + step, ... (the two directions of an LSTM layer)."""
+        if self.sink is not None:
+            return self.sink.span(i, step, count, shape)
+        return self.pool.take(shape)
+
+    def deliver(self, i, value):
+        """A gradient that was computed into a temporary: with a sink it is added to the flat buffer here."""
+        if self.sink is None:
+            return value
+        self.sink.view(i, value.shape).add_(value)
+        return None
+
+    def result(self, g):
+        """What backward hands to autograd for parameter gradients."""
+        return [None] * len(g) if self.sink is not None else g
 
 
 def width_ok(w):
@@ -56,7 +92,7 @@ def width_ok(w):
     return w in (128, 256)
 
 
-def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad):
+def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad, sink=None):
     if sv is None:
         raise RuntimeError("backward called on a forward that ran without grad tracking")
     L, D, H, (p_in, p_lstm, p_cls), seed, mixed = cfg
@@ -74,21 +110,23 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad):
     # needs the fused dropout-backward epilogue of the dX GEMM (the stand-alone dropout kernel is fp32)
     carry16 = ops.dy_bf16_ok(H, mixed) and all(l["fused_drop"] or p_lstm == 0 or i + 1 == L
                                                for i, l in enumerate(sv["layers"]))
-    # one zero-filled pool for every accumulation target (sized by the parameter count, with room for the padded /
-    # duplicated buffers); a fresh one per backward call, so retained-graph passes never share gradients
-    pool = _ZeroPool(dlogits.device, sum(p.numel() + 64 for p in ps if p is not None) + 8192) if need_w else None
+    # accumulation targets: one zero-filled pool per backward call (retained-graph passes never share gradients), or the
+    # attached optimizer's flat gradient buffer (sink)
+    if not need_w:
+        sink = None
+    tgt = _Targets(ps, dlogits.device, sink) if need_w else None
 
     def zeros(shape):
-        return pool.take(shape) if pool is not None else torch.zeros(tuple(shape), device=dlogits.device)
+        return tgt.zeros(shape) if tgt is not None else torch.zeros(tuple(shape), device=dlogits.device)
 
     # ---- classifier (04:196-204)
-    dz2d, g[i_c6w], g[i_c6w + 1] = _linear_bwd(dlogits, sv["z2d"], ps[i_c6w], need_w=need_w, wt=wT.get("c6wT"), pool=pool)
+    dz2d, g[i_c6w], g[i_c6w + 1] = _linear_bwd(dlogits, sv["z2d"], ps[i_c6w], need_w=need_w, wt=wT.get("c6wT"), tgt=tgt, iw=i_c6w)
     dz2 = ops.dropout(dz2d, p_cls, _seed(seed, 21)) if p_cls > 0 else dz2d
     dz2p = ops.act_bwd(dz2, sv["z2p"], ACT_GELU)
-    dz1d, g[i_c3w], g[i_c3w + 1] = _linear_bwd(dz2p, sv["z1d"], ps[i_c3w], need_w=need_w, wt=wT.get("c3wT"), pool=pool)
+    dz1d, g[i_c3w], g[i_c3w + 1] = _linear_bwd(dz2p, sv["z1d"], ps[i_c3w], need_w=need_w, wt=wT.get("c3wT"), tgt=tgt, iw=i_c3w)
     dz1 = ops.dropout(dz1d, p_cls, _seed(seed, 20)) if p_cls > 0 else dz1d
     dz1p = ops.act_bwd(dz1, sv["z1p"], ACT_GELU)
-    dctx, g[i_c0w], g[i_c0w + 1] = _linear_bwd(dz1p, sv["ctx"], ps[i_c0w], need_w=need_w, wt=wT.get("c0wT"), pool=pool)
+    dctx, g[i_c0w], g[i_c0w + 1] = _linear_bwd(dz1p, sv["ctx"], ps[i_c0w], need_w=need_w, wt=wT.get("c0wT"), tgt=tgt, iw=i_c0w)
 
     # ---- attention pooling (04:123-128)
     v, u = sv["v"], sv["u"]
@@ -100,15 +138,17 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad):
         fused = v.dtype == torch.bfloat16        # mixed mode: bf16 v / dU, context path folded into the LN backward
         # the score MLP's first-bias gradient = column sums of dU: emitted by the pooling backward itself where it can
         cs_fused = need_w and ops.attn_bwd_fuses_colsum(v, u, not fused, fused)
-        du_cs = zeros((u.shape[1],)) if cs_fused else None
+        du_cs = tgt.param(i_a0b, (u.shape[1],)) if cs_fused else None
+        dw2_t = tgt.param(i_a2w, (u.shape[1],)) if need_w else zeros((u.shape[1],))
         dV, dU, dw2 = ops.attn_pool_bwd(v, u, sv["attn"], dctx, ps[i_a2w].reshape(-1), T, B, Bp,
-                                        want_dv=not fused, du_bf16=fused, du_colsum=du_cs, dw2=zeros((u.shape[1],)))
+                                        want_dv=not fused, du_bf16=fused, du_colsum=du_cs, dw2=dw2_t)
         g[i_a2w] = dw2.reshape(1, -1)
-        g[i_a2b] = zeros(ps[i_a2b].shape)                 # b2 cancels in the softmax: exactly 0
+        # b2 cancels in the softmax: its gradient is exactly 0 (a zero tensor for autograd; nothing to add to a sink)
+        g[i_a2b] = zeros(ps[i_a2b].shape) if (sink is None or not need_w) else None
         if need_w:
-            g[i_a0w] = zeros(a0w.shape)
+            g[i_a0w] = tgt.param(i_a0w, a0w.shape)
             ops.gemm_tn(dU, v, g[i_a0w], mixed=mixed)
-            g[i_a0b] = du_cs if cs_fused else ops.colsum(dU, zeros((dU.shape[1],)))
+            g[i_a0b] = du_cs if cs_fused else ops.colsum(dU, tgt.param(i_a0b, (dU.shape[1],)))
         w1t = wT.get("a0wT")
         if fused:
             want16 = ops.dma_ok(dU.shape[1], a0w.shape[1], dU.shape[0])
@@ -124,7 +164,12 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad):
             pool_ctx = None
 
     # ---- post-LSTM LayerNorm (04:212)
-    dY, g[i_ln], g[i_ln + 1] = ops.layernorm_act_bwd(sv["ylast"], ps[i_ln], ps[i_ln + 1], dV, pool=pool_ctx, zeros=zeros,
+    def affine(i):          # accumulation targets of a LayerNorm's weight / bias (None: nn.Identity in the ablation variants)
+        if tgt is None or ps[i] is None:
+            return None, None
+        return tgt.param(i, ps[i].shape), tgt.param(i + 1, ps[i + 1].shape)
+    dg_t, db_t = affine(i_ln)
+    dY, g[i_ln], g[i_ln + 1] = ops.layernorm_act_bwd(sv["ylast"], ps[i_ln], ps[i_ln + 1], dV, pool=pool_ctx, dg=dg_t, db=db_t,
                                                      dx_bf16=carry16 and width_ok(sv["ylast"].shape[1]))
 
     # ---- LSTM stack, last layer first (04:211)
@@ -132,19 +177,27 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad):
         lay = sv["layers"][layer]
         if layer + 1 < L and p_lstm > 0 and not lay["fused_drop"]:
             dY = ops.dropout(dY, p_lstm, _seed(seed, 10 + layer))
+        base = 4 + layer * 4 * D
+        # b_ih and b_hh have the same gradient: with a sink BPTT adds into a temporary that is then added to both
+        # parameters' slices (the slices hold earlier micro-batches: BPTT cannot add into one and copy to the other)
         dP, dbias = ops.lstm_rec_bwd(lay["G"], lay["C"], lay["whh"], dY, T, Bp, H, D, dp_bf16=mixed,
                                      dbias=zeros((D * 4 * H,)))
         inp, Y, wih = lay["inp"], lay["Y"], lay["wih"]
-        base = 4 + layer * 4 * D
         fused_dw = need_w and ops.can_fuse_dw(dP, inp, Y, T, Bp, H, D)
-        if fused_dw:
-            dwih, dwhh_all = ops.lstm_dw(dP, inp, Y, T, Bp, H, D, out=(zeros((D * 4 * H, inp.shape[1])), zeros((D, 4 * H, H))))
+        if fused_dw:     # one contiguous target over both directions (the sink lays the two directions out side by side)
+            dwih, dwhh_all = ops.lstm_dw(dP, inp, Y, T, Bp, H, D, out=(tgt.span(base, 4, D, (D * 4 * H, inp.shape[1])),
+                                                                        tgt.span(base + 1, 4, D, (D, 4 * H, H))))
         elif need_w:
-            dwih = zeros(wih.shape)
+            dwih = tgt.span(base, 4, D, wih.shape)
             ops.gemm_tn(dP, inp, dwih, mixed=mixed)
-        dbias2 = dbias.clone() if need_w else None        # b_ih and b_hh: equal gradients, distinct tensors (see below)
+        if need_w and sink is not None:
+            tgt.span(base + 2, 4, D, dbias.shape).add_(dbias)
+            tgt.span(base + 3, 4, D, dbias.shape).add_(dbias)
+        dbias2 = dbias.clone() if (need_w and sink is None) else None   # b_ih and b_hh: equal gradients, distinct tensors
         for d in range(D if need_w else 0):
-            dwhh = dwhh_all[d] if fused_dw else zeros(ps[base + 4 * d + 1].shape)
+            if sink is not None and fused_dw:
+                continue
+            dwhh = dwhh_all[d] if fused_dw else tgt.param(base + 4 * d + 1, ps[base + 4 * d + 1].shape)
             if T > 1 and not fused_dw:
                 a_sl = dP[:, d * 4 * H:(d + 1) * 4 * H]
                 y_sl = Y[:, d * H:(d + 1) * H]
@@ -152,6 +205,8 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad):
                     ops.gemm_tn(a_sl[Bp:], y_sl[:(T - 1) * Bp], dwhh, mixed=mixed)
                 else:           # reverse direction: h_prev(t) = h(t+1)
                     ops.gemm_tn(a_sl[:(T - 1) * Bp], y_sl[Bp:], dwhh, mixed=mixed)
+            if sink is not None:
+                continue
             g[base + 4 * d + 0] = dwih[d * 4 * H:(d + 1) * 4 * H]
             g[base + 4 * d + 1] = dwhh
             # b_ih and b_hh have the same gradient, but they must not receive the same tensor OBJECT: autograd may
@@ -175,18 +230,19 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad):
     # ---- input projection: Linear -> LayerNorm -> GELU -> Dropout (04:173-178)
     # input_proj.0.bias gradient = column sums of dpre: emitted by the LayerNorm backward itself where it can
     db_fused = need_w and ops.can_fuse_colsum(sv["pre"].shape[1])
-    db0 = zeros((sv["pre"].shape[1],)) if db_fused else None
+    db0 = tgt.param(1, (sv["pre"].shape[1],)) if db_fused else None
+    dg_t, db_t = affine(2)
     dpre, g[2], g[3] = ops.layernorm_act_bwd(sv["pre"], ps[2], ps[3], dY, act=ACT_GELU, remap=(T, B, Bp),
-                                             drop_p=p_in, seed=_seed(seed, 0), dx_colsum=db0, zeros=zeros)
+                                             drop_p=p_in, seed=_seed(seed, 0), dx_colsum=db0, dg=dg_t, db=db_t)
     if sv.get("xb") is not None and need_w:      # mixed: dW through the bf16 TN kernel on the padded bf16 windows
         xb = sv["xb"]
         dwp = zeros((ps[0].shape[0], xb.shape[1]))
         ops.gemm_tn(dpre, xb, dwp, mixed=True)
-        g[0] = dwp[:, :C].contiguous()
-        g[1] = db0 if db0 is not None else ops.colsum(dpre, zeros((dpre.shape[1],)))
+        g[0] = tgt.deliver(0, dwp[:, :C]) if sink is not None else dwp[:, :C].contiguous()
+        g[1] = db0 if db0 is not None else ops.colsum(dpre, tgt.param(1, (dpre.shape[1],)))
         gx2d = ops.gemm_nt(dpre, _t(ps[0])) if needs_input_grad[0] else None
     else:
         gx2d, g[0], g[1] = _linear_bwd(dpre, sv["x2d"], ps[0], need_dx=bool(needs_input_grad[0]), need_w=need_w,
-                                       db=db0, pool=pool)
+                                       db=db0, tgt=tgt, iw=0)
     gx = gx2d.reshape(B, T, C) if gx2d is not None else None
-    return gx, g
+    return gx, (tgt.result(g) if tgt is not None else g)

@@ -428,7 +428,7 @@ def act_bwd(dy, pre, kind):
 
 
 def layernorm_act_bwd(x, gamma, beta, dy, act=ACT_NONE, eps=1e-5, remap=None, drop_p=0.0, seed=0, pool=None,
-                      dx_colsum=None, zeros=None, dx_bf16=False):
+                      dx_colsum=None, dx_bf16=False, dg=None, db=None):
     """Returns (dx [rows,width] in INPUT row order, dgamma, dbeta).  pool=(attn [B,T], dctx [B,width], T, B, Bp)
     adds attn[b][t] * dctx[b] to dy on the fly (context path of the attention pooling).  dx_colsum [width]
     (widths 128/256/512): += column sums of dx (see ``can_fuse_colsum``).  dy may be bf16 and dx_bf16 stores dx as
@@ -446,8 +446,9 @@ def layernorm_act_bwd(x, gamma, beta, dy, act=ACT_NONE, eps=1e-5, remap=None, dr
         act = act | LN_IDENTITY
         dg = db = None
     else:
-        dg = zeros(gamma.shape) if zeros is not None else torch.zeros_like(gamma)
-        db = zeros(beta.shape) if zeros is not None else torch.zeros_like(beta)
+        dg = torch.zeros_like(gamma) if dg is None else dg           # accumulation targets (fp32 atomics)
+        db = torch.zeros_like(beta) if db is None else db
+        _chk(dg, "dgamma"); _chk(db, "dbeta")
     pa, pd, pT, pB, pBp = (None, None, 0, 0, 0) if pool is None else pool
     rc = _lib.lib().lob_layernorm_act_bwd_f32(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(dy), _ptr(dx), _ptr(dg), _ptr(db),
                                               rows, width, eps, act, rT, rB, rBp, float(drop_p), C.c_uint64(seed),

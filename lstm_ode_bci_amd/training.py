@@ -81,13 +81,42 @@ def warmup_cosine(current_epoch, warmup_epochs, epochs):
 # ---------------------------------------------------------------------------------------------
 # optimizer
 # ---------------------------------------------------------------------------------------------
+class _GradSink:
+    """Accumulation targets of one backward inside FusedAdamW's flat gradient buffer: `offs[i]` = offset of the i-th
+    parameter of autograd._collect(model) (None entries: absent sub-modules of the ablation variants)."""
+
+    def __init__(self, flat_grad, offs):
+        self.flat_grad, self.offs = flat_grad, offs
+
+    def view(self, i, shape):
+        n = 1
+        for s in shape:
+            n *= int(s)
+        return self.flat_grad[self.offs[i]:self.offs[i] + n].view(tuple(shape))
+
+    def span(self, i, step, count, shape):
+        """Parameters i, i + step, ..., laid out back to back (checked by FusedAdamW.sink_for)."""
+        return self.view(i, shape)
+
+
 class FusedAdamW(torch.optim.Optimizer):
     """torch.optim.AdamW semantics (04:438) on flat buffers; a torch Optimizer, so LambdaLR (04:450) drives its
-    ``param_groups[0]['lr']``.  Construct it AFTER ``model.to(device)``: it re-points ``p.data`` / ``p.grad``."""
+    ``param_groups[0]['lr']``.  Construct it AFTER ``model.to(device)``: it re-points ``p.data`` / ``p.grad``.
+
+    ``model=`` (optional; an EnhancedLSTMModel / AblationLSTMModel whose parameters these are) makes the optimizer the
+    model's GRADIENT SINK: the flat buffers are laid out in the order the backward kernels produce gradients (the two
+    directions' W_ih / W_hh / biases of a layer side by side), the model's backward accumulates every parameter gradient
+    straight into ``flat_grad`` and autograd receives None for the parameters -- no per-parameter accumulation launches.
+    ``p.grad`` stays a view of ``flat_grad``, so everything that reads gradients afterwards (clipping, the all-reduce,
+    hooks on ``.grad``) sees them; only ``torch.autograd.grad(loss, parameters)`` returns None while a sink is attached
+    (``detach_model()`` restores the plain autograd path)."""
 
     _ALIGN = 64        # floats: every tensor starts on a 256-B boundary of the flat buffers
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, model=None):
+        params = list(params)
+        if model is not None:
+            params = self._kernel_order(model, params)
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         if len(self.param_groups) != 1:
             raise ValueError("FusedAdamW: one parameter group (the reference uses model.parameters())")
@@ -112,6 +141,83 @@ class FusedAdamW(torch.optim.Optimizer):
                 view.copy_(p.data)
                 p.data = view
         self._attach_grads()
+        self._off_of = {id(p): off for p, off in zip(ps, self._offsets)}
+        self._model_ref = None
+        if model is not None:
+            import weakref
+            self._model_ref = weakref.ref(model)
+            model._lob_grad_sink = weakref.ref(self)
+
+    @staticmethod
+    def _kernel_order(model, params):
+        """The model's parameters with the two directions of every LSTM tensor side by side (what lob_lstm_dw_bf16 / the
+        BPTT bias gradient write as ONE buffer)."""
+        ids = {id(p) for p in params}
+        order, seen = [], set()
+
+        def put(p):
+            if p is not None and id(p) in ids and id(p) not in seen:
+                seen.add(id(p))
+                order.append(p)
+        lstm = getattr(model, "lstm", None)
+        for name, p in model.named_parameters():
+            if lstm is not None and name.startswith("lstm."):
+                continue
+            if name.startswith("layer_norm.") and lstm is not None:      # first parameter after the LSTM block
+                for layer in range(lstm.num_layers):
+                    dirs = lstm.layer_params(layer)
+                    for j in range(4):
+                        for d in dirs:
+                            put(d[j])
+            put(p)
+        if lstm is not None:                       # ablation variants without a post-LSTM LayerNorm
+            for layer in range(lstm.num_layers):
+                dirs = lstm.layer_params(layer)
+                for j in range(4):
+                    for d in dirs:
+                        put(d[j])
+        for p in params:
+            put(p)
+        return order
+
+    def detach_model(self):
+        m = self._model_ref() if self._model_ref is not None else None
+        if m is not None and getattr(m, "_lob_grad_sink", None) is not None:
+            m._lob_grad_sink = None
+        self._model_ref = None
+
+    def sink_for(self, params, D=None):
+        """A _GradSink for this list of parameters (autograd._collect order), or None when the backward cannot
+        accumulate in place: a parameter that is not ours / does not require grad, a .grad that is not our view, or LSTM
+        tensors of the two directions that are not back to back."""
+        offs = []
+        for p in params:
+            if p is None:
+                offs.append(None)
+                continue
+            off = self._off_of.get(id(p))
+            if off is None or not p.requires_grad:
+                return None
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * off:
+                # gradients were dropped (model.zero_grad(set_to_none=True)) or replaced: a fresh zero slice
+                view = self._grad_view(p, off)
+                if p.grad is None:
+                    view.zero_()
+                else:
+                    view.copy_(p.grad)
+                p.grad = view
+            offs.append(off)
+        n = len(params)
+        nl = n - 16                                   # 4 projection + 2 LayerNorm + 4 attention + 6 classifier tensors
+        if D is None or nl <= 0 or nl % (4 * D):
+            return None
+        for base in range(4, 4 + nl, 4 * D):
+            for j in range(4):
+                for d in range(1, D):
+                    a, b = offs[base + j], offs[base + j + 4 * d]
+                    if a is None or b is None or b != a + d * params[base + j].numel():
+                        return None
+        return _GradSink(self.flat_grad, offs)
 
     def _grad_view(self, p, off):
         return self.flat_grad[off:off + p.numel()].view_as(p)
@@ -263,7 +369,7 @@ def train_model(model, train_loader, val_loader, y_train, epochs=100, learning_r
                         process_group, "batches per epoch (train, val), accumulation steps, epochs")
 
     criterion = WeightedCrossEntropy(class_weights_from_labels(y_train)).to(dev)
-    optimizer = FusedAdamW(model.parameters(), lr=learning_rate, weight_decay=weight_decay)
+    optimizer = FusedAdamW(model.parameters(), lr=learning_rate, weight_decay=weight_decay, model=model)
     scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lambda e: warmup_cosine(e, warmup_epochs, epochs))
     acc_steps = gradient_accumulation_steps
     best_val_f1, best_state, stale = 0, None, 0
@@ -374,7 +480,7 @@ def quick_train_evaluate(model, X_train, y_train, X_val, y_val, X_test, y_test, 
                                       "shuffle", device)
     test_loader = DeviceWindowLoader(X_test, y_test, batch_size * 2, "sequential", device)
     criterion = WeightedCrossEntropy().to(device)
-    optimizer = FusedAdamW(model.parameters(), lr=lr)
+    optimizer = FusedAdamW(model.parameters(), lr=lr, model=model)
     model.train()
     for _ in range(epochs):
         for xb, yb in train_loader:

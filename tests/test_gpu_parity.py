@@ -393,7 +393,7 @@ def test_train_mode_dropout(dev):
     yy = torch.from_numpy(y[:4]).to(dev)
 
     def f():
-        return torch.nn.functional.cross_entropy(_LobModelFn.apply(xs, cfg, *ps)[0], yy)
+        return torch.nn.functional.cross_entropy(_LobModelFn.apply(xs, cfg, None, *ps)[0], yy)
     m.zero_grad()
     f().backward()
     ga = w.grad[0, 3].item()

@@ -441,3 +441,53 @@ def test_fused_weight_gradients_same_step_as_separate_gemms(dev, monkeypatch):
     for k in g0:
         sc = g0[k].abs().max().item() + 1e-12
         assert (g1[k] - g0[k]).abs().max().item() <= 1e-4 * sc + 1e-7, k
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+@pytest.mark.parametrize("kw", [dict(), dict(bidirectional=False, num_layers=2), dict(use_attention=False), dict(use_layer_norm=False)])
+def test_gradient_sink_equals_autograd_accumulation(dev, mixed, kw):
+    """FusedAdamW(model=...) as the model's gradient sink: the backward accumulates every parameter gradient straight
+    into flat_grad (autograd gets None).  Same gradients as the plain autograd path (fp32 atomics: summation order
+    only), over two accumulated micro-batches, after model.zero_grad(set_to_none=True), for the ablation variants and a
+    unidirectional model; and one fused step equals the un-sunk optimizer's."""
+    import copy
+    from lstm_ode_bci_amd import AblationLSTMModel
+    from lstm_ode_bci_amd.training import FusedAdamW, WeightedCrossEntropy
+    torch.manual_seed(5)
+    args = dict(input_size=61, hidden_size=128, num_layers=3, num_classes=2, dropout=0.0, bidirectional=True,
+                use_attention=True, use_layer_norm=True)
+    args.update(kw)
+    m1 = AblationLSTMModel(**args).to(dev).train()
+    m2 = copy.deepcopy(m1)
+    xs = [torch.randn(40, 24, 61, device=dev) for _ in range(2)]
+    ys = [torch.randint(0, 2, (40,), device=dev) for _ in range(2)]
+    crit = WeightedCrossEntropy(torch.tensor([0.8, 1.2])).to(dev)
+    o1 = FusedAdamW(m1.parameters(), lr=3e-4, weight_decay=1e-4, model=m1)          # sink
+    o2 = FusedAdamW(m2.parameters(), lr=3e-4, weight_decay=1e-4)                    # plain autograd accumulation
+    assert m1._lob_grad_sink() is o1 and getattr(m2, "_lob_grad_sink", None) is None
+
+    def run(m, o, drop_grads=False):
+        o.zero_grad()
+        if drop_grads:
+            m.zero_grad(set_to_none=True)
+        for x, y in zip(xs, ys):
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=mixed):
+                loss = crit(m(x), y) / 2
+            loss.backward()
+        return {k: p.grad.clone() for k, p in m.named_parameters()}
+    for drop in (False, True):
+        g1, g2 = run(m1, o1, drop), run(m2, o2, drop)
+        for k in g2:
+            sc = g2[k].abs().max().item() + 1e-12
+            assert (g1[k] - g2[k]).abs().max().item() <= 2e-4 * sc + 1e-7, (k, drop)
+    # every .grad is still a view of the flat buffer, and the fused step agrees
+    for p, off in zip(o1.param_groups[0]["params"], o1._offsets):
+        assert p.grad.data_ptr() == o1.flat_grad.data_ptr() + 4 * off
+    o1.step(clip_grad_norm=1.0)
+    o2.step(clip_grad_norm=1.0)
+    for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert (p1 - p2).abs().max().item() <= 2e-6, k
+    # detaching restores autograd's own accumulation
+    o1.detach_model()
+    g1 = run(m1, o1)
+    assert m1._lob_grad_sink is None and all(torch.isfinite(v).all() for v in g1.values())
