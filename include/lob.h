@@ -76,8 +76,7 @@ const char* lob_build_id(void);
 #define LOB_VAR_REC_F32_HALF 15  /* 1: fp32 recurrent forward may split the gate columns over two workgroups       */
 #define LOB_VAR_H256_BWD     16  /* H=256 BPTT kernel shape: 1 = 64-row pairs sharing one weight stream, 0 = 32-row */
 #define LOB_VAR_DX_KSPLIT    17  /* 1: dX = dP W_ih on the k-split weight-stationary kernel; 0: tiled LDS-DMA NT GEMM          */
-#define LOB_VAR_REC_W8       18  /* mixed inference forward, H=128: eight-wave kernel 0 never / 1 at <= 256 workgroups / 2 always  */
-#define LOB_VAR_COUNT        19
+#define LOB_VAR_COUNT        18
 int lob_debug_set_variant(int which, int value);
 int lob_debug_get_variant(int which);
 

@@ -340,7 +340,6 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_h128_bf16_kernel(
 // kernels of this file.
 int lob_rec_fwd_bf16_s16(void* P, int pg_bf16, const float* Whh, float* Y, void* Csave, int c_bf16, void* Y16, void* Yd,
                          float drop_p, uint64_t seed, int T, int Bp, int D, int save, hipStream_t s);
-int lob_rec_fwd_bf16_w8(const void* P, const float* Whh, float* Y, void* Y16, int T, int Bp, int D, hipStream_t s);
 int lob_rec_bwd_bf16_s16(const void* G, int pg_bf16, const void* Csave, int c_bf16, const float* Whh, const void* dY,
                          int dy_bf16, void* dP, float* dbias, int T, int Bp, int D, hipStream_t s);
 // H = 256: W_hh streamed from L2 (lstm_rec_h256_bf16.hip); bf16 P / saved gates only
@@ -374,16 +373,7 @@ extern "C" int lob_lstm_rec_fwd_bf16(void* P, int pg_bf16, const float* Whh, con
     if ((reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(Whh) | reinterpret_cast<uintptr_t>(Csave) |
          reinterpret_cast<uintptr_t>(Y16) | reinterpret_cast<uintptr_t>(Yd)) & 15) return LOB_E_ALIGN;
     hipStream_t s = (hipStream_t)stream;
-    if (use_s16()) {
-        // inference at small batch (at most one 16-row workgroup per CU): the eight-wave kernel -- the step is latency-
-        // bound there and half the per-wave work per step is what counts (lstm_rec_bf16_w8.hip); LOB_VAR_REC_W8: 0 never,
-        // 1 (default) when the grid is <= 256 workgroups, 2 always
-        const int w8 = lob_variant(LOB_VAR_REC_W8);
-        if (pg_bf16 && !save && !Yd && (Y != nullptr) != (Y16 != nullptr) &&
-            (w8 == 2 || (w8 == 1 && (long)(Bp / 16) * D <= 256)))
-            return lob_rec_fwd_bf16_w8(P, Whh, Y, Y16, T, Bp, D, s);
-        return lob_rec_fwd_bf16_s16(P, pg_bf16, Whh, Y, Csavev, c_bf16, Y16, Yd, drop_p, seed, T, Bp, D, save, s);
-    }
+    if (use_s16()) return lob_rec_fwd_bf16_s16(P, pg_bf16, Whh, Y, Csavev, c_bf16, Y16, Yd, drop_p, seed, T, Bp, D, save, s);
     const dim3 grid(Bp / 32, D), block(256);
     __bf16* y16 = reinterpret_cast<__bf16*>(Y16);
     __bf16* yd = reinterpret_cast<__bf16*>(Yd);

@@ -436,24 +436,3 @@ def test_row_major_weight_stationary_gemm_vs_tiled_twin(dev, M, N, K):
         o_tl = ops.gemm_nt(a, w if M % 256 == 0 else w.float(), mixed=True)
     assert torch.equal(o_ws, o_tl), (o_ws - o_tl).abs().max().item()
     assert torch.equal(o_ws16, o_tl.to(torch.bfloat16))
-
-
-@pytest.mark.parametrize("Bn,Tn,D", [(1, 256, 2), (40, 64, 2), (512, 256, 2), (96, 17, 1)])
-def test_eight_wave_inference_forward_bit_identical_to_four_wave(dev, Bn, Tn, D):
-    """lstm_rec_fwd_h128_bf16_w8_kernel (small-batch inference: the same 16-row tile on eight waves) against the
-    four-wave kernel: same MFMAs in the same k order, same activations -> bit-identical h, fp32 and bf16 outputs."""
-    from lstm_ode_bci_amd import _lib, ops
-    H, K = 128, 256
-    Bp = ops.ceil32(Bn)
-    x = _rand((Tn * Bp, K), dev, 101, dtype=torch.bfloat16)
-    wih = _rand((D * 4 * H, K), dev, 102, 0.06, dtype=torch.bfloat16)
-    bias = _rand((D * 4 * H,), dev, 103, 0.1)
-    whh = _rand((D, 4 * H, H), dev, 104, 0.06)
-    P = ops.gate_gemm_x(x, wih, bias, Tn, Bp, H, D, True, mixed=True)
-    for kw in (dict(want_f32=True, want_bf16=False), dict(want_f32=False, want_bf16=True)):
-        with _lib.variant(REC_W8=2):
-            y8 = ops.lstm_rec_fwd(P, whh, Tn, Bp, H, D, False, mixed=True, **kw)
-        with _lib.variant(REC_W8=0):
-            y4 = ops.lstm_rec_fwd(P, whh, Tn, Bp, H, D, False, mixed=True, **kw)
-        a, b = (y8[0], y4[0]) if kw["want_f32"] else (y8[2], y4[2])
-        assert a is not None and torch.equal(a, b), kw
