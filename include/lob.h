@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LOB_VERSION 200
+#define LOB_VERSION 201
 
 #define LOB_E_ARG   (-1)   /* null pointer / non-positive size                      */
 #define LOB_E_SHAPE (-2)   /* shape not supported by this kernel (see each entry)   */
@@ -76,7 +76,8 @@ const char* lob_build_id(void);
 #define LOB_VAR_REC_F32_HALF 15  /* 1: fp32 recurrent forward may split the gate columns over two workgroups       */
 #define LOB_VAR_H256_BWD     16  /* H=256 BPTT kernel shape: 1 = 64-row pairs sharing one weight stream, 0 = 32-row */
 #define LOB_VAR_DX_KSPLIT    17  /* 1: dX = dP W_ih on the k-split weight-stationary kernel; 0: tiled LDS-DMA NT GEMM          */
-#define LOB_VAR_COUNT        18
+#define LOB_VAR_REC_FEW      18  /* 1: mixed inference forward with fewer than 4 windows skips the padding registers' cell update */
+#define LOB_VAR_COUNT        19
 int lob_debug_set_variant(int which, int value);
 int lob_debug_get_variant(int which);
 
@@ -190,7 +191,9 @@ int lob_lstm_dw_bf16(const void* dP, int ldp, const void* X, int ldx, int nx, co
  * Whh16 / WhhT16 are ignored (may be NULL) at H == 128.                                                  */
 int lob_lstm_rec_fwd_bf16(void* P, int pg_bf16, const float* Whh, const void* Whh16, float* Y, void* Csave, int c_bf16,
                           void* Y16, void* Yd, float drop_p, uint64_t seed,
-                          int T, int Bp, int H, int D, int save, void* stream);
+                          int T, int Bp, int H, int D, int save, int nvalid, void* stream);
+/*   nvalid: how many of the Bp rows carry windows (rows >= nvalid are padding); 0 = unknown / all.  Only a hint: with
+ *   save == 0, bf16 P, H == 128 and nvalid < 4 the padding rows' cell update is skipped and their outputs are zeros.  */
 /*   c_bf16 = 1 (H == 128, 16-row kernels, bf16 saved gates): the cell states saved for BPTT are stored as bf16, in the
  *   element order of one gate of the saved gates ([q pair][lane][8]); BPTT takes the matching flag.  The state carried
  *   through time is fp32 in both kernels; only the saved copy is rounded.                                          */

@@ -102,7 +102,8 @@ def _forward_impl(x, ps, cfg, save):
         # layer's GEMMs read Yd / Y16, dW_hh reads Y16); the last layer keeps fp32 Y for the LayerNorm
         Y, Cs, Y16, Yd = ops.lstm_rec_fwd(P, whh, T, Bp, H, D, save, mixed=mixed,
                                           drop_p=p_lstm if fuse else 0.0, seed=_seed(seed, 10 + layer),
-                                          want_f32=last or not bf16_out, want_bf16=bf16_out and (save or not last))
+                                          want_f32=last or not bf16_out, want_bf16=bf16_out and (save or not last),
+                                          nvalid=B)
         if fuse:
             nxt = Yd
         elif bf16_out and not last:
@@ -217,6 +218,12 @@ def lob_forward(model, x, drops, seed):
         if opt is not None:
             sink = opt.sink_for(params, model.num_directions)
     with ops.on_device(x.device), torch.autocast(device_type="cuda", enabled=False):
+        if not torch.is_grad_enabled():
+            # torch.no_grad() (every inference loop of the reference: 04_lstm_model.py:557, 06_lstm_ode_integration.py:347):
+            # ctx.needs_input_grad still reports the parameters' requires_grad there, so going through the autograd node
+            # would run the SAVING forward kernels (gates and cell states written for a backward that cannot happen)
+            logits, attn, _ = _forward_impl(_f32c(x), [_f32c(p) for p in params], cfg, save=False)
+            return logits, attn
         return _LobModelFn.apply(x, cfg, sink, *params)
 
 

@@ -32,6 +32,7 @@ const VarDef kVars[LOB_VAR_COUNT] = {
     {"LOB_REC_F32_HALF", 1},  // LOB_VAR_REC_F32_HALF
     {"LOB_H256_BWD", 1},      // LOB_VAR_H256_BWD
     {"LOB_DX_KSPLIT", 1},     // LOB_VAR_DX_KSPLIT
+    {"LOB_REC_FEW", 1},       // LOB_VAR_REC_FEW
 };
 std::atomic<int> g_vals[LOB_VAR_COUNT];
 std::atomic<int> g_init{0};

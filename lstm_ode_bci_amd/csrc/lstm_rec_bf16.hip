@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_h128_bf16_kernel(
 // 16-row tiles, two workgroups per CU (lstm_rec_bf16_s16.hip): the default.  LOB_REC_BF16=32 selects the 32-row
 // kernels of this file.
 int lob_rec_fwd_bf16_s16(void* P, int pg_bf16, const float* Whh, float* Y, void* Csave, int c_bf16, void* Y16, void* Yd,
-                         float drop_p, uint64_t seed, int T, int Bp, int D, int save, hipStream_t s);
+                         float drop_p, uint64_t seed, int T, int Bp, int D, int save, int nvalid, hipStream_t s);
 int lob_rec_bwd_bf16_s16(const void* G, int pg_bf16, const void* Csave, int c_bf16, const float* Whh, const void* dY,
                          int dy_bf16, void* dP, float* dbias, int T, int Bp, int D, hipStream_t s);
 // H = 256: W_hh streamed from L2 (lstm_rec_h256_bf16.hip); bf16 P / saved gates only
@@ -354,9 +354,10 @@ static bool use_s16() {
 
 extern "C" int lob_lstm_rec_fwd_bf16(void* P, int pg_bf16, const float* Whh, const void* Whh16, float* Y, void* Csavev,
                                      int c_bf16, void* Y16, void* Yd, float drop_p, uint64_t seed,
-                                     int T, int Bp, int Hh, int D, int save, void* stream) {
+                                     int T, int Bp, int Hh, int D, int save, int nvalid, void* stream) {
     if (!P || !Whh || T <= 0 || Bp <= 0 || (D != 1 && D != 2)) return LOB_E_ARG;
     if (!Y && !Y16) return LOB_E_ARG;
+    if (nvalid < 0 || nvalid > Bp) return LOB_E_ARG;
     if (save && !Csavev) return LOB_E_ARG;
     // bf16 cell-state storage: the 16-row H = 128 kernels only
     if (c_bf16 && (Hh != 128 || !use_s16())) return LOB_E_SHAPE;
@@ -373,7 +374,7 @@ extern "C" int lob_lstm_rec_fwd_bf16(void* P, int pg_bf16, const float* Whh, con
     if ((reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(Whh) | reinterpret_cast<uintptr_t>(Csave) |
          reinterpret_cast<uintptr_t>(Y16) | reinterpret_cast<uintptr_t>(Yd)) & 15) return LOB_E_ALIGN;
     hipStream_t s = (hipStream_t)stream;
-    if (use_s16()) return lob_rec_fwd_bf16_s16(P, pg_bf16, Whh, Y, Csavev, c_bf16, Y16, Yd, drop_p, seed, T, Bp, D, save, s);
+    if (use_s16()) return lob_rec_fwd_bf16_s16(P, pg_bf16, Whh, Y, Csavev, c_bf16, Y16, Yd, drop_p, seed, T, Bp, D, save, nvalid, s);
     const dim3 grid(Bp / 32, D), block(256);
     __bf16* y16 = reinterpret_cast<__bf16*>(Y16);
     __bf16* yd = reinterpret_cast<__bf16*>(Yd);

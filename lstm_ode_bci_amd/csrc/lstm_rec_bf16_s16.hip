@@ -79,11 +79,19 @@ __device__ __forceinline__ void store_frag16(E* p, unsigned off, const f32x4 (&s
 // saved gates: BPTT only ever uses c_t inside tanh(c_t) and as the factor of the forget-gate gradient, next to gate
 // values that are bf16 already -- half the bytes of that stream, forward and backward).  The state carried through
 // time stays fp32 in registers.
-template <bool SAVE, bool YF32, bool Y16, bool DROP, typename PE, typename CE>
+//
+// FEW (inference, nvalid < 4 windows in the whole call -- the single-window serving call of
+// 06_lstm_ode_integration.py:340-360 with one (256, 61) window): a call that small is one 16-row tile per direction on
+// one CU, 768 dependent steps long, and a step is bound by what ONE wave issues: 32 MFMAs, then the gate activations of
+// its 8 elements per lane (80 transcendentals).  The MFMA's D layout puts tile row 4 rq + j in register j, so with
+// nvalid rows only registers j < nvalid hold a window: the cell update of the other registers is skipped (their h
+// rows stay zero in LDS, so padding rows leave as zeros), and a tile without any window only writes zeros.
+template <bool SAVE, bool YF32, bool Y16, bool DROP, typename PE, typename CE, bool FEW = false>
 __global__ __launch_bounds__(256, 2) void lstm_rec_fwd_h128_bf16_s16_kernel(
     PE* __restrict__ P, const float* __restrict__ Whh, float* __restrict__ Y,
     CE* __restrict__ Csave, __bf16* __restrict__ Y16p, __bf16* __restrict__ Yd, float drop_p, uint64_t seed,
-    int T, int Bp) {
+    int T, int Bp, int nvalid) {
+    static_assert(!FEW || (!SAVE && !DROP), "FEW: inference only");
     __shared__ __attribute__((aligned(16))) __bf16 hs[2 * 16 * HB_LD];
     // fp32 h of the step (last layer only), staged so that it leaves as 32-B-per-lane row segments instead of eight
     // 4-byte stores per lane; double-buffered like hs (one barrier per step)
@@ -93,6 +101,17 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_fwd_h128_bf16_s16_kernel(
     const int d = blockIdx.y, D = gridDim.y, NBT = Bp >> 5;
     const int c16 = lane & 15, rq = lane >> 4;
     const int bt = blockIdx.x >> 1, s0 = blockIdx.x & 1;      // 32-row fragment block, 16-row half
+    const int nj = FEW ? nvalid - (bt * 32 + s0 * 16) : 4;   // FEW: registers j < nj hold windows (nvalid < 4)
+    if (FEW && nj <= 0) {                                     // a tile of padding rows: zeros for every step
+        const int row = tid >> 4, c8 = (tid & 15) * 8;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < T; ++t) {
+            const size_t o = ((size_t)t * Bp + bt * 32 + s0 * 16 + row) * (D * H) + d * H + c8;
+            if (YF32) { *reinterpret_cast<f32x4*>(Y + o) = z; *reinterpret_cast<f32x4*>(Y + o + 4) = z; }
+            if (Y16) *reinterpret_cast<f32x4*>(Y16p + o) = z;
+        }
+        return;
+    }
 
     // B fragments: wr[g][cbu][ks] = W_hh[g*128 + 32w + 16cbu + c16][32ks + 8rq .. +7]
     bf16x8 wr[4][2][4];
@@ -108,6 +127,8 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_fwd_h128_bf16_s16_kernel(
             }
     }
     for (int i = tid; i < 2 * 16 * HB_LD; i += 256) hs[i] = (__bf16)0.f;
+    if (FEW && YF32)
+        for (int i = tid; i < 2 * 16 * YF_LD; i += 256) yfs[i] = 0.f;
     float c[2][4];
 #pragma unroll
     for (int cbu = 0; cbu < 2; ++cbu)
@@ -154,6 +175,7 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_fwd_h128_bf16_s16_kernel(
         for (int cbu = 0; cbu < 2; ++cbu)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+                if (FEW && j >= nj) continue;              // wave-uniform: a register of padding rows only
                 const float ig = fast_sigmoid(acc[0][cbu][j]);
                 const float fg = fast_sigmoid(acc[1][cbu][j]);
                 const float gg = fast_tanh(acc[2][cbu][j]);
@@ -615,13 +637,21 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_bwd_h128_bf16_s16_dma_kernel(
 
 // Internal entry points used by lob_lstm_rec_fwd_bf16 / lob_lstm_rec_bwd_bf16 (lstm_rec_bf16.hip).
 int lob_rec_fwd_bf16_s16(void* P, int pg_bf16, const float* Whh, float* Y, void* Csave, int c_bf16, void* Y16, void* Yd,
-                         float drop_p, uint64_t seed, int T, int Bp, int D, int save, hipStream_t s) {
+                         float drop_p, uint64_t seed, int T, int Bp, int D, int save, int nvalid, hipStream_t s) {
     const dim3 grid(Bp / 16, D), block(256);
     __bf16* y16 = reinterpret_cast<__bf16*>(Y16);
     __bf16* yd = reinterpret_cast<__bf16*>(Yd);
     if (c_bf16 && !(pg_bf16 && save)) return LOB_E_SHAPE;          // bf16 c: with bf16 saved gates only
+    if (!save && !yd && pg_bf16 && nvalid > 0 && nvalid < 4 && lob_variant(LOB_VAR_REC_FEW)) {
+#define LOB_FEW(YF, Y6) hipLaunchKernelGGL((lstm_rec_fwd_h128_bf16_s16_kernel<false, YF, Y6, false, __bf16, float, true>), grid, block, \
+        0, s, reinterpret_cast<__bf16*>(P), Whh, Y, (float*)nullptr, y16, yd, 0.f, (uint64_t)0, T, Bp, nvalid)
+        if (Y && y16) LOB_FEW(true, true); else if (Y) LOB_FEW(true, false); else LOB_FEW(false, true);
+#undef LOB_FEW
+        LOB_CHECK_LAUNCH();
+        return 0;
+    }
 #define LOB_FWD(SV, YF, Y6, DR, PE, CE) hipLaunchKernelGGL((lstm_rec_fwd_h128_bf16_s16_kernel<SV, YF, Y6, DR, PE, CE>), grid, block, \
-        0, s, reinterpret_cast<PE*>(P), Whh, Y, reinterpret_cast<CE*>(Csave), y16, yd, drop_p, seed, T, Bp)
+        0, s, reinterpret_cast<PE*>(P), Whh, Y, reinterpret_cast<CE*>(Csave), y16, yd, drop_p, seed, T, Bp, Bp)
 #define LOB_FWD_OUT(SV, PE, CE) do {                                                     \
         if (Y && !y16 && !yd) LOB_FWD(SV, true, false, false, PE, CE);                   \
         else if (Y && y16 && !yd) LOB_FWD(SV, true, true, false, PE, CE);                \

@@ -683,7 +683,10 @@ extern "C" int lob_layernorm_act_f32(const float* in, const float* gamma, const 
     if (drop_p < 0.f || drop_p >= 1.f) return LOB_E_ARG;
     if (remap_T > 0 && (remap_B <= 0 || remap_Bp < remap_B || rows != remap_T * remap_B)) return LOB_E_SHAPE;
     const int waves_per_block = 4;
-    int blocks = (rows + waves_per_block - 1) / waves_per_block;
+    // the walk a wave strides over: rows, or (remap) the 8 x 8 (b, t) tiles INCLUDING their out-of-range corners -- with
+    // one window that is 8 x the rows, and a grid sized from `rows` made every wave loop 8 times (28 us for 256 rows)
+    const int work = remap_T > 0 ? ((remap_B + 7) >> 3) * ((remap_T + 7) >> 3) * 64 : rows;
+    int blocks = (work + waves_per_block - 1) / waves_per_block;
     if (blocks > 256 * 16) blocks = 256 * 16;
     const bool al = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) |
                       reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) == 0;
@@ -693,7 +696,7 @@ extern "C" int lob_layernorm_act_f32(const float* in, const float* gamma, const 
         in, gamma, beta, out, rows, eps, act, remap_T, remap_B, remap_Bp, drop_p, seed); } while (0)
     if (al && width == 128 && ln_lpr16()) {
         // four rows per wave pass: a pass covers 4 rows, RPW = 2 passes in flight
-        blocks = (rows + 31) / 32;
+        blocks = (work + 31) / 32;
         if (blocks > 256 * 16) blocks = 256 * 16;
         if (out_bf16) hipLaunchKernelGGL((layernorm_act_vec_kernel<8, true, 16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                                          in, gamma, beta, out, rows, eps, act, remap_T, remap_B, remap_Bp, drop_p, seed);

@@ -244,10 +244,11 @@ def can_fuse_dropout(H, mixed):
     return bool(mixed) and bf16_rec(H, PG_BF16)
 
 
-def lstm_rec_fwd(P, whh, T, Bp, H, D, save, mixed=False, drop_p=0.0, seed=0, want_f32=True, want_bf16=False):
+def lstm_rec_fwd(P, whh, T, Bp, H, D, save, mixed=False, drop_p=0.0, seed=0, want_f32=True, want_bf16=False, nvalid=0):
     """Runs the persistent recurrent kernel; returns (Y fp32 or None, Csave or None, Y16 or None, Yd or None).
     mixed: h W_hh^T on bf16 MFMA (H == 128), everything else fp32.  With can_fuse_dropout: want_bf16 adds
-    Y16 = bf16(Y); drop_p > 0 adds Yd = bf16(dropout(Y)); want_f32=False skips the fp32 Y."""
+    Y16 = bf16(Y); drop_p > 0 adds Yd = bf16(dropout(Y)); want_f32=False skips the fp32 Y.
+    nvalid: how many of the Bp rows carry windows (0 = all): lets a one-window inference call skip the padding rows."""
     p16 = P.dtype == torch.bfloat16
     _chk(P, "P", P.dtype if p16 else torch.float32); _chk(whh, "whh")
     assert whh.shape == (D, 4 * H, H)
@@ -269,7 +270,7 @@ def lstm_rec_fwd(P, whh, T, Bp, H, D, save, mixed=False, drop_p=0.0, seed=0, wan
             Yd = torch.empty((T * Bp, D * H), device=dev, dtype=torch.bfloat16)
         rc = _lib.lib().lob_lstm_rec_fwd_bf16(_ptr(P), int(p16), _ptr(whh), _ptr(whh16), _ptr(Y), _ptr(Cs), int(c16), _ptr(Y16),
                                               _ptr(Yd), float(drop_p), C.c_uint64(seed), T, Bp, H, D, 1 if save else 0,
-                                              _stream())
+                                              int(nvalid), _stream())
     else:
         assert drop_p == 0 and not p16 and not want_bf16
         Y = torch.empty((T * Bp, D * H), device=dev, dtype=torch.float32)

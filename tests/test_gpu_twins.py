@@ -436,3 +436,58 @@ def test_row_major_weight_stationary_gemm_vs_tiled_twin(dev, M, N, K):
         o_tl = ops.gemm_nt(a, w if M % 256 == 0 else w.float(), mixed=True)
     assert torch.equal(o_ws, o_tl), (o_ws - o_tl).abs().max().item()
     assert torch.equal(o_ws16, o_tl.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("nwin", [1, 2, 3])
+@pytest.mark.parametrize("outs", ["f32", "bf16", "both"])
+def test_few_window_inference_kernel_vs_full_tile_twin(dev, nwin, outs):
+    """The single-window serving call (06_lstm_ode_integration.py:340-360 with one (256, 61) window): the FEW variant of
+    the mixed recurrent forward skips the cell update of the MFMA output registers that only hold padding rows.  The
+    rows that carry windows must equal the full-tile kernel's (same instructions on the same values), the skipped
+    padding rows must come out as zeros."""
+    from lstm_ode_bci_amd import _lib, ops
+    H, D, Bp = 128, 2, 32
+    P = _rand((D * T * Bp * 4 * H,), dev, 120 + nwin, 0.8).to(torch.bfloat16)
+    whh = _rand((D, 4 * H, H), dev, 121, 0.08)
+    kw = dict(want_f32=outs in ("f32", "both"), want_bf16=outs in ("bf16", "both"))
+    with _lib.variant(REC_FEW=1):
+        Yf, _, Y16f, _ = ops.lstm_rec_fwd(P, whh, T, Bp, H, D, False, mixed=True, nvalid=nwin, **kw)
+    with _lib.variant(REC_FEW=0):
+        Yt, _, Y16t, _ = ops.lstm_rec_fwd(P, whh, T, Bp, H, D, False, mixed=True, nvalid=nwin, **kw)
+    for few, twin in ((Yf, Yt), (Y16f, Y16t)):
+        if few is None:
+            assert twin is None
+            continue
+        few, twin = few.float().reshape(T, Bp, D * H), twin.float().reshape(T, Bp, D * H)
+        assert torch.isfinite(few).all()
+        err = (few[:, :nwin] - twin[:, :nwin]).abs().max().item()
+        assert err <= 2e-6 if few is Yf else err <= 8e-3, err
+        # padding rows: tile row 4 rq + j lives in output register j, so rows with (row % 4) >= nwin are skipped and
+        # leave as zeros (rows 4, 8, 12 share register 0 with window 0 and are computed as before); so does the
+        # second tile, which holds no window at all
+        r = torch.arange(Bp, device=dev)
+        skipped = (r >= 16) | ((r % 4) >= nwin)
+        assert float(few[:, skipped].abs().max()) == 0.0
+        assert float(twin[:, skipped].abs().max()) > 0.0        # (the full-tile kernel computes them)
+        assert torch.equal(few[:, ~skipped], twin[:, ~skipped]) or err <= 2e-6
+
+
+@pytest.mark.parametrize("B1", [1, 3, 40])
+def test_no_grad_forward_does_not_save_and_matches_grad_mode(dev, B1):
+    """torch.no_grad() inference (04_lstm_model.py:557, 06_lstm_ode_integration.py:347) must not run the saving
+    forward kernels: same logits as the grad-mode forward, no autograd node, and (mixed, B < 4) the few-window
+    kernel is what runs."""
+    from lstm_ode_bci_amd import EnhancedLSTMModel
+    sd = syn.make_state_dict(61, 128, 3, 2, True)
+    m = EnhancedLSTMModel(61, 128, 3, 2, 0.4, True)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m = m.to(dev).eval()
+    x = _rand((B1, T, 61), dev, 7)
+    for mixed in (False, True):
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=mixed):
+            lg, ag = m(x, return_attention=True)
+            with torch.no_grad():
+                ln, an = m(x, return_attention=True)
+        assert lg.requires_grad and not ln.requires_grad and ln.grad_fn is None
+        tol = 3e-3 if mixed else 1e-5
+        assert (lg - ln).abs().max().item() <= tol and (ag - an).abs().max().item() <= tol
