@@ -40,22 +40,30 @@ struct WSArgs {
     int ldc, out_bf16;           // EPI = 1 (row-major C): leading dimension in elements, bf16 or fp32 C
 };
 
-// EPI = 0: the gate GEMM -- 64 columns per wave, 512 per workgroup (one direction), bf16 fragment-order P, bias.
+// EPI = 0: the gate GEMM -- bf16 fragment-order P, bias.  K <= 256: 64 columns per wave (512 per workgroup), 64-row tiles.
+//          K = 512 (layers 1.. at H = 256, the reference's checkpoint size, 04_lstm_model.py:877): the B fragments of 64
+//          columns would be the whole 256-register budget, so a wave keeps 32 columns (128 VGPRs), a workgroup 256, and
+//          the tiles are 32 rows (32 KB per ring slot as at K = 256).  Every MFMA then needs its own 1-KB A fragment from
+//          LDS (the 64-column shape shares one between two), i.e. LDS reads run at the MFMA rate -- still 1.7 x faster
+//          than re-staging the weight tile per 256 rows.  HID = hidden size: only the fragment-order address
+//          ([d][t][bt][w HID/32][gate 4][q pair 2][lane 64][8], include/lob.h) depends on it.
 // EPI = 1 (bf16 C) / 2 (fp32 C): a plain row-major C[M, N] = A W^T (no bias) for narrow contractions -- the attention pooling's
 //          dV = dPreU W1 (K = 128, N = 256; 04_lstm_model.py:118 in the backward of 04:482-512): 32 columns per wave,
 //          256 per workgroup, `D` = number of 256-column groups.  The MFMA runs with its operands SWAPPED (the weights as
 //          the A operand), so a lane holds 4 consecutive columns of one row per accumulator quad: 8-B (bf16) / 16-B
 //          (fp32) stores -- and, as in the fragment epilogue, exactly 8 store instructions per wave and tile.
-template <int K, int EPI>
+template <int K, int EPI, int HID = 128>
 __global__ __launch_bounds__(512, 2) void gate_gemm_ws_kernel(WSArgs g) {
-    constexpr int MT = 64;                          // rows per tile
-    constexpr int NCB = EPI == 0 ? 2 : 1;           // 32-column blocks per wave
+    constexpr int MT = K == 512 ? 32 : 64;          // rows per tile
+    constexpr int MI = MT / 32;                     // 32-row blocks per tile
+    constexpr int NCB = (EPI == 0 && K <= 256) ? 2 : 1;   // 32-column blocks per wave
     constexpr int WGN = 8 * 32 * NCB;               // columns per workgroup
-    constexpr int NSLOT = K == 256 ? 4 : 6, LA = NSLOT - 1;
+    constexpr int NSLOT = K == 128 ? 6 : 4, LA = NSLOT - 1;
     constexpr int ROWB = 2 * K, SLOTB = MT * ROWB;  // bytes per LDS row / slot
     constexpr int RPI = 1024 / ROWB;                // rows per DMA instruction
     constexpr int NDMA = MT / RPI / 8;              // DMA instructions per wave per tile
-    constexpr int NST = 8;                          // fragment stores per wave per tile
+    constexpr int NST = EPI == 0 ? MI * NCB * 2 : 8;   // stores per wave per tile
+    static_assert(EPI == 0 || K <= 256, "row-major epilogue: K in {128, 256}");
     constexpr int VM_STEADY = LA * NST + (LA - 1) * NDMA, VM_PRO = (LA - 1) * NDMA;
     constexpr int KS = K / 16;                      // MFMA k-steps
     static_assert(VM_STEADY < 64 && NDMA >= 1, "vmcnt is a 6-bit counter");
@@ -122,9 +130,8 @@ __global__ __launch_bounds__(512, 2) void gate_gemm_ws_kernel(WSArgs g) {
 #pragma unroll
     for (int s = 0; s < 8; ++s) aoff[s] = (unsigned)(r31 * ROWB + (((2 * s + hi) ^ (r31 & 15)) * 16));
 
-    f32x16 acc[2][NCB];
+    f32x16 acc[MI][NCB];
     const int NBT = EPI == 0 ? g.Bp >> 5 : 1;
-    const int gate = wv >> 1, w4 = 2 * (wv & 1);
 
     for (int q = 0; q < total; ++q) {
         if (q < LA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_PRO) : "memory");
@@ -134,7 +141,7 @@ __global__ __launch_bounds__(512, 2) void gate_gemm_ws_kernel(WSArgs g) {
 
         const unsigned sb = ring_b + (unsigned)((q % NSLOT) * SLOTB);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
@@ -143,6 +150,24 @@ __global__ __launch_bounds__(512, 2) void gate_gemm_ws_kernel(WSArgs g) {
         // front, which would drain the ring); LDS operations return in order: each wait names the registers it frees
 #define LOB_RD(dstv, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dstv) : "v"(ADDR), "n"(OFF) : "memory")
         bf16x8 a0, a1, n0, n1;
+        if constexpr (MI == 1) {
+            // one 32-row block: one fragment per k-step, TWO k-steps ahead (a0 = step s, a1 = s + 1, n0 = s + 2)
+            LOB_RD(a0, sb + aoff[0], 0);
+            LOB_RD(a1, sb + aoff[1], 0);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                if (s + 2 < KS) {
+                    LOB_RD(n0, sb + aoff[(s + 2) & 7], ((s + 2) >> 3) * 256);
+                    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a0));
+                } else if (s + 1 < KS) {
+                    asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(a0));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0));
+                }
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wreg[0][s], acc[0][0], 0, 0, 0);
+                a0 = a1; a1 = n0;
+            }
+        } else {
         LOB_RD(a0, sb + aoff[0], 0);
         LOB_RD(a1, sb + aoff[0], 32 * ROWB);
 #pragma unroll
@@ -165,9 +190,10 @@ __global__ __launch_bounds__(512, 2) void gate_gemm_ws_kernel(WSArgs g) {
             }
             a0 = n0; a1 = n1;
         }
+        }
 #undef LOB_RD
 
-        // ---- epilogue: + bias, bf16, fragment order [d][t][bt][w 4][gate 4][q pair 2][lane 64][8]
+        // ---- epilogue: + bias, bf16, fragment order [d][t][bt][w HID/32][gate 4][q pair 2][lane 64][8]
         const int m0 = ((pair + npair * q) * 8 + xcd) * MT;
         if constexpr (EPI >= 1) {
             // row-major C: lane = row m0 + 32 i + r31; accumulator quad qd = columns ncol0 + 8 qd + 4 hi .. + 3
@@ -193,14 +219,17 @@ __global__ __launch_bounds__(512, 2) void gate_gemm_ws_kernel(WSArgs g) {
             continue;
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < MI; ++i) {
             const int mrow = m0 + 32 * i;
             const bool ok = mrow < g.M;
             const int mr = ok ? mrow : 0;
             const int t = mr / g.Bp, bt = (mr - t * g.Bp) >> 5;
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
-                const size_t fo = ((((size_t)(d * g.T + t) * NBT + bt) * 4 + (w4 + cb)) * 4 + gate) * 1024;
+                // column block ncol0 + 32 cb of the [D][gate 4][HID] gate axis
+                const int nc = ncol0 + 32 * cb;
+                const int dd = nc / (4 * HID), gate = (nc % (4 * HID)) / HID, wq = (nc % HID) >> 5;
+                const size_t fo = ((((size_t)(dd * g.T + t) * NBT + bt) * (HID / 32) + wq) * 4 + gate) * 1024;
                 __bf16* dst = g.P + fo + lane * 8;
 #pragma unroll
                 for (int pq = 0; pq < 2; ++pq) {
@@ -220,18 +249,27 @@ __global__ __launch_bounds__(512, 2) void gate_gemm_ws_kernel(WSArgs g) {
 }  // namespace
 
 // Internal entry point used by lob_gate_gemm_x_bf16 (gemm_bf16.hip).  Preconditions checked by the caller: X, W bf16,
-// P bf16 fragment order, H == 128, K in {128, 256}, ldx % 8 == 0, 16-B aligned bases, Bp % 32 == 0.
-int lob_gate_gemm_ws(const void* X, int ldx, const void* Wih, const float* bias, void* P, int T, int Bp, int D, int K,
+// P bf16 fragment order, (H, K) in {(128, 128), (128, 256), (256, 256), (256, 512)}, ldx % 8 == 0, 16-B aligned bases,
+// Bp % 32 == 0.
+int lob_gate_gemm_ws(const void* X, int ldx, const void* Wih, const float* bias, void* P, int T, int Bp, int H, int D, int K,
                      hipStream_t s) {
     const int M = T * Bp;
-    const int ntile = (M + 63) / 64;
-    int npx = (ntile + 7) / 8;                       // pairs per XCD, one workgroup per CU at most
-    const int cap = 32 / D;
+    const int mt = K == 512 ? 32 : 64;
+    const int wgn = K == 512 ? 256 : 512;            // gate columns per workgroup
+    const int ncg = D * 4 * H / wgn;                 // column groups: 1 per direction at H = 128; 4 (K = 256) / 8 (K = 512) at H = 256
+    const int ntile = (M + mt - 1) / mt;
+    int npx = (ntile + 7) / 8;                       // row walkers per XCD, one workgroup per CU at most
+    const int cap = 32 / ncg;
     if (npx > cap) npx = cap;
-    WSArgs g{(const __bf16*)X, (const __bf16*)Wih, bias, (__bf16*)P, ldx, M, T, Bp, D, 0, 0};
-    const dim3 grid((unsigned)(8 * D * npx)), block(512);
-    if (K == 256) hipLaunchKernelGGL((gate_gemm_ws_kernel<256, 0>), grid, block, 0, s, g);
-    else          hipLaunchKernelGGL((gate_gemm_ws_kernel<128, 0>), grid, block, 0, s, g);
+    WSArgs g{(const __bf16*)X, (const __bf16*)Wih, bias, (__bf16*)P, ldx, M, T, Bp, ncg, 0, 0};
+    const dim3 grid((unsigned)(8 * ncg * npx)), block(512);
+    if (H == 256) {
+        if (K == 512) hipLaunchKernelGGL((gate_gemm_ws_kernel<512, 0, 256>), grid, block, 0, s, g);
+        else          hipLaunchKernelGGL((gate_gemm_ws_kernel<256, 0, 256>), grid, block, 0, s, g);
+    } else {
+        if (K == 256) hipLaunchKernelGGL((gate_gemm_ws_kernel<256, 0>), grid, block, 0, s, g);
+        else          hipLaunchKernelGGL((gate_gemm_ws_kernel<128, 0>), grid, block, 0, s, g);
+    }
     LOB_CHECK_LAUNCH();
     return 0;
 }

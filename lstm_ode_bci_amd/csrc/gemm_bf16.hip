@@ -1078,7 +1078,7 @@ extern "C" int lob_gemm_nt_bf16(const void* A, int a_bf16, int lda, const void* 
     return 0;
 }
 
-int lob_gate_gemm_ws(const void* X, int ldx, const void* Wih, const float* bias, void* P, int T, int Bp, int D, int K,
+int lob_gate_gemm_ws(const void* X, int ldx, const void* Wih, const float* bias, void* P, int T, int Bp, int H, int D, int K,
                      hipStream_t s);       // gate_gemm_ws.hip
 
 extern "C" int lob_gate_gemm_x_bf16(const void* X, int x_bf16, int ldx, const void* Wih, int w_bf16, const float* bias,
@@ -1090,9 +1090,10 @@ extern "C" int lob_gate_gemm_x_bf16(const void* X, int x_bf16, int ldx, const vo
     NTArgs g{X, reinterpret_cast<const float*>(Wih), bias, reinterpret_cast<float*>(P), ldx, K, N, M, N, K, LOB_ACT_NONE, 0,
              T, Bp, H, D, p_bf16, 0.f, 0, 0};
     if (w_bf16) {
-        // H = 128, bf16 P: the weight-stationary kernel (gate_gemm_ws.hip) -- only the activations stream
-        if (x_bf16 && p_bf16 && H == 128 && (K == 128 || K == 256) && lob_variant(LOB_VAR_GATE_WS) != 0)
-            return lob_gate_gemm_ws(X, ldx, Wih, bias, P, T, Bp, D, K, (hipStream_t)stream);
+        // bf16 P: the weight-stationary kernel (gate_gemm_ws.hip) -- only the activations stream
+        if (x_bf16 && p_bf16 && ((H == 128 && (K == 128 || K == 256)) || (H == 256 && (K == 256 || K == 512))) &&
+            lob_variant(LOB_VAR_GATE_WS) != 0)
+            return lob_gate_gemm_ws(X, ldx, Wih, bias, P, T, Bp, H, D, K, (hipStream_t)stream);
         if (!x_bf16 || (K % DTK) || K / DTK < DS || N > 2048 || (N % 128) || (M % 256)) return LOB_E_SHAPE;
         launch_nt_dma<1>(g, (hipStream_t)stream);
         LOB_CHECK_LAUNCH();

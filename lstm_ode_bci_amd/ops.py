@@ -196,8 +196,8 @@ def dma_ok(K, N, M):
 
 def gate_ws_ok(K, H):
     """Shapes of the weight-stationary gate GEMM (csrc/gate_gemm_ws.hip): bf16 x bf16 -> bf16 fragment-order P at
-    H == 128, any number of rows."""
-    return PG_BF16 and H == 128 and K in (128, 256)
+    H == 128 (K = 128 / 256) and H == 256 (K = 256 / 512), any number of rows."""
+    return PG_BF16 and ((H == 128 and K in (128, 256)) or (H == 256 and K in (256, 512)))
 
 
 #: mixed mode, H == 128: store the fragment-order pre-activations / saved gates as bf16 (half the HBM

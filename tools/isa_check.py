@@ -101,12 +101,14 @@ def _check_ws_kernel(srcname, cases, path=None):
 
 def check_gate_ws(path=None):
     """gate_gemm_ws.hip (mixed path) and gate_gemm_ws_split.hip (fp32 path): one hand-counted ring wait per row tile."""
-    return (_check_ws_kernel("gate_gemm_ws.hip", [("gate_gemm_ws_kernelILi256ELi0E", 4, 8, 64),
-                                                  ("gate_gemm_ws_kernelILi128ELi0E", 2, 8, 32),
-                                                  ("gate_gemm_ws_kernelILi256ELi1E", 4, 8, 32),
-                                                  ("gate_gemm_ws_kernelILi128ELi1E", 2, 8, 16),
-                                                  ("gate_gemm_ws_kernelILi256ELi2E", 4, 8, 32),
-                                                  ("gate_gemm_ws_kernelILi128ELi2E", 2, 8, 16)], path) +
+    return (_check_ws_kernel("gate_gemm_ws.hip", [("gate_gemm_ws_kernelILi256ELi0ELi128E", 4, 8, 64),
+                                                  ("gate_gemm_ws_kernelILi128ELi0ELi128E", 2, 8, 32),
+                                                  ("gate_gemm_ws_kernelILi256ELi0ELi256E", 4, 8, 64),
+                                                  ("gate_gemm_ws_kernelILi512ELi0ELi256E", 4, 2, 32),
+                                                  ("gate_gemm_ws_kernelILi256ELi1ELi128E", 4, 8, 32),
+                                                  ("gate_gemm_ws_kernelILi128ELi1ELi128E", 2, 8, 16),
+                                                  ("gate_gemm_ws_kernelILi256ELi2ELi128E", 4, 8, 32),
+                                                  ("gate_gemm_ws_kernelILi128ELi2ELi128E", 2, 8, 16)], path) +
             _check_ws_kernel("gate_gemm_ws_split.hip", [("gate_gemm_ws_split_kernelILi256E", 4, 4, 48),
                                                         ("gate_gemm_ws_split_kernelILi128E", 2, 4, 24)], path))
 
