@@ -203,7 +203,10 @@ int lob_lstm_rec_fwd_bf16(void* P, int pg_bf16, const float* Whh, const void* Wh
  *   Yd (or Y16 without dropout) and dW_hh reads Y16, so layers below the last never write fp32 Y.  */
 int lob_lstm_rec_bwd_bf16(const void* G, int pg_bf16, const void* Csave, int c_bf16, const float* Whh, const void* WhhT16,
                           const void* dY, int dy_bf16,
-                          void* dP, float* dbias, int T, int Bp, int H, int D, void* stream);
+                          void* dP, float* dbias, float* dbias2, int T, int Bp, int H, int D, void* stream);
+/*   dbias2 (may be NULL; needs dbias): a second [D*4H] destination that receives the same atomic adds -- b_ih and b_hh
+ *   have the same gradient (04_lstm_model.py:181-188 keeps both), and an optimizer that owns one flat gradient buffer
+ *   hands the two parameters' slices over directly instead of adding a temporary into each afterwards.             */
 /*   dy_bf16 = 1 (H == 128, 16-row kernels): dY is stored as bf16 -- in the mixed path the gradient carried from layer
  *   to layer (dX of the layer above, written by lob_gemm_nt_bf16 with LOB_OUT_BF16, or the LayerNorm backward's dx)
  *   is a bf16 stream like dP; it is widened to fp32 on load and everything carried through time stays fp32.      */

@@ -31,7 +31,7 @@ _SIGS = {
                               C.c_void_p], C.c_int),
     "lob_lstm_rec_fwd_bf16": ([_f32p, C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_int, _f32p, _f32p, C.c_float, C.c_uint64, C.c_int,
                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p], C.c_int),
-    "lob_lstm_rec_bwd_bf16": ([_f32p, C.c_int, _f32p, C.c_int, _f32p, _f32p, _f32p, C.c_int, _f32p, _f32p, C.c_int, C.c_int,
+    "lob_lstm_rec_bwd_bf16": ([_f32p, C.c_int, _f32p, C.c_int, _f32p, _f32p, _f32p, C.c_int, _f32p, _f32p, _f32p, C.c_int, C.c_int,
                                C.c_int, C.c_int, C.c_void_p], C.c_int),
     "lob_colsum_bf16": ([_f32p, C.c_int, C.c_int, C.c_int, _f32p, C.c_void_p], C.c_int),
     "lob_gemm_nt_bf16": ([_f32p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, _f32p, _f32p, C.c_int, C.c_int, C.c_int,

@@ -178,10 +178,17 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad, sink=None):
         if layer + 1 < L and p_lstm > 0 and not lay["fused_drop"]:
             dY = ops.dropout(dY, p_lstm, _seed(seed, 10 + layer))
         base = 4 + layer * 4 * D
-        # b_ih and b_hh have the same gradient: with a sink BPTT adds into a temporary that is then added to both
-        # parameters' slices (the slices hold earlier micro-batches: BPTT cannot add into one and copy to the other)
-        dP, dbias = ops.lstm_rec_bwd(lay["G"], lay["C"], lay["whh"], dY, T, Bp, H, D, dp_bf16=mixed,
-                                     dbias=zeros((D * 4 * H,)))
+        # b_ih and b_hh have the same gradient.  With a sink the bf16 BPTT kernels add it into BOTH parameters' slices
+        # themselves (two destinations); the fp32 kernels add into a temporary that is then added to both slices (the
+        # slices hold earlier micro-batches: BPTT cannot add into one and copy to the other)
+        two_dst = need_w and sink is not None and mixed and ops.bf16_rec(H, lay["G"].dtype == torch.bfloat16)
+        if two_dst:
+            dP, dbias = ops.lstm_rec_bwd(lay["G"], lay["C"], lay["whh"], dY, T, Bp, H, D, dp_bf16=True,
+                                         dbias=tgt.span(base + 2, 4, D, (D * 4 * H,)),
+                                         dbias2=tgt.span(base + 3, 4, D, (D * 4 * H,)))
+        else:
+            dP, dbias = ops.lstm_rec_bwd(lay["G"], lay["C"], lay["whh"], dY, T, Bp, H, D, dp_bf16=mixed,
+                                         dbias=zeros((D * 4 * H,)))
         inp, Y, wih = lay["inp"], lay["Y"], lay["wih"]
         fused_dw = need_w and ops.can_fuse_dw(dP, inp, Y, T, Bp, H, D)
         if fused_dw:     # one contiguous target over both directions (the sink lays the two directions out side by side)
@@ -190,7 +197,7 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad, sink=None):
         elif need_w:
             dwih = tgt.span(base, 4, D, wih.shape)
             ops.gemm_tn(dP, inp, dwih, mixed=mixed)
-        if need_w and sink is not None:
+        if need_w and sink is not None and not two_dst:
             tgt.span(base + 2, 4, D, dbias.shape).add_(dbias)
             tgt.span(base + 3, 4, D, dbias.shape).add_(dbias)
         dbias2 = dbias.clone() if (need_w and sink is None) else None   # b_ih and b_hh: equal gradients, distinct tensors

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_h128_bf16_kernel(
 template <typename PE>
 __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_h128_bf16_kernel(
     const PE* __restrict__ G, const float* __restrict__ Csave, const float* __restrict__ Whh,
-    const float* __restrict__ dY, __bf16* __restrict__ dP, float* __restrict__ dbias, int T, int Bp) {
+    const float* __restrict__ dY, __bf16* __restrict__ dP, float* __restrict__ dbias, float* __restrict__ dbias2, int T, int Bp) {
     __shared__ __attribute__((aligned(16))) __bf16 dgs[32 * DGB_LD];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -329,7 +329,11 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_h128_bf16_kernel(
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float v = dbsum[g] + __shfl_xor(dbsum[g], 32, 64);
-            if (hi == 0) atomicAdd(dbias + (size_t)d * 4 * H + g * H + 32 * w + l31, v);
+            if (hi == 0) {
+                const size_t bi = (size_t)d * 4 * H + g * H + 32 * w + l31;
+                atomicAdd(dbias + bi, v);
+                if (dbias2) atomicAdd(dbias2 + bi, v);
+            }
         }
     }
 }
@@ -341,12 +345,12 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_h128_bf16_kernel(
 int lob_rec_fwd_bf16_s16(void* P, int pg_bf16, const float* Whh, float* Y, void* Csave, int c_bf16, void* Y16, void* Yd,
                          float drop_p, uint64_t seed, int T, int Bp, int D, int save, int nvalid, hipStream_t s);
 int lob_rec_bwd_bf16_s16(const void* G, int pg_bf16, const void* Csave, int c_bf16, const float* Whh, const void* dY,
-                         int dy_bf16, void* dP, float* dbias, int T, int Bp, int D, hipStream_t s);
+                         int dy_bf16, void* dP, float* dbias, float* dbias2, int T, int Bp, int D, hipStream_t s);
 // H = 256: W_hh streamed from L2 (lstm_rec_h256_bf16.hip); bf16 P / saved gates only
 int lob_rec_fwd_h256_bf16(void* P, const void* Whh16, float* Y, float* Csave, void* Y16, void* Yd, float drop_p,
                           uint64_t seed, int T, int Bp, int D, int save, hipStream_t s);
 int lob_rec_bwd_h256_bf16(const void* G, const float* Csave, const void* WhhT16, const float* dY, void* dP,
-                          float* dbias, int T, int Bp, int D, hipStream_t s);
+                          float* dbias, float* dbias2, int T, int Bp, int D, hipStream_t s);
 static bool use_s16() {
     const bool v = lob_variant(LOB_VAR_REC_BF16_ROWS) != 32;
     return v;
@@ -397,7 +401,7 @@ extern "C" int lob_lstm_rec_fwd_bf16(void* P, int pg_bf16, const float* Whh, con
 }
 
 extern "C" int lob_lstm_rec_bwd_bf16(const void* G, int pg_bf16, const void* Csavev, int c_bf16, const float* Whh,
-                                     const void* WhhT16, const void* dYv, int dy_bf16, void* dP, float* dbias, int T, int Bp,
+                                     const void* WhhT16, const void* dYv, int dy_bf16, void* dP, float* dbias, float* dbias2, int T, int Bp,
                                      int Hh, int D, void* stream) {
     if (!G || !Csavev || !Whh || !dYv || !dP || T <= 0 || Bp <= 0 || (D != 1 && D != 2)) return LOB_E_ARG;
     // bf16 dY / bf16 cell state: the 16-row H = 128 kernels only
@@ -409,18 +413,18 @@ extern "C" int lob_lstm_rec_bwd_bf16(const void* G, int pg_bf16, const void* Csa
         if (!WhhT16) return LOB_E_ARG;
         if ((reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(Csave) | reinterpret_cast<uintptr_t>(WhhT16) |
              reinterpret_cast<uintptr_t>(dP)) & 15) return LOB_E_ALIGN;
-        return lob_rec_bwd_h256_bf16(G, Csave, WhhT16, dY, dP, dbias, T, Bp, D, (hipStream_t)stream);
+        return lob_rec_bwd_h256_bf16(G, Csave, WhhT16, dY, dP, dbias, dbias2, T, Bp, D, (hipStream_t)stream);
     }
     if (Hh != 128 || (Bp % 32)) return LOB_E_SHAPE;
     if ((reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(Csave) |
          reinterpret_cast<uintptr_t>(dP)) & 15) return LOB_E_ALIGN;
-    if (use_s16()) return lob_rec_bwd_bf16_s16(G, pg_bf16, Csavev, c_bf16, Whh, dYv, dy_bf16, dP, dbias, T, Bp, D, (hipStream_t)stream);
+    if (use_s16()) return lob_rec_bwd_bf16_s16(G, pg_bf16, Csavev, c_bf16, Whh, dYv, dy_bf16, dP, dbias, dbias2, T, Bp, D, (hipStream_t)stream);
     if (pg_bf16)
         hipLaunchKernelGGL((lstm_rec_bwd_h128_bf16_kernel<__bf16>), dim3(Bp / 32, D), dim3(256), 0, (hipStream_t)stream,
-                           reinterpret_cast<const __bf16*>(G), Csave, Whh, dY, reinterpret_cast<__bf16*>(dP), dbias, T, Bp);
+                           reinterpret_cast<const __bf16*>(G), Csave, Whh, dY, reinterpret_cast<__bf16*>(dP), dbias, dbias2, T, Bp);
     else
         hipLaunchKernelGGL((lstm_rec_bwd_h128_bf16_kernel<float>), dim3(Bp / 32, D), dim3(256), 0, (hipStream_t)stream,
-                           reinterpret_cast<const float*>(G), Csave, Whh, dY, reinterpret_cast<__bf16*>(dP), dbias, T, Bp);
+                           reinterpret_cast<const float*>(G), Csave, Whh, dY, reinterpret_cast<__bf16*>(dP), dbias, dbias2, T, Bp);
     LOB_CHECK_LAUNCH();
     return 0;
 }

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_fwd_h128_bf16_s16_kernel(
 template <typename PE, typename DE, typename CE>
 __global__ __launch_bounds__(256, 2) void lstm_rec_bwd_h128_bf16_s16_kernel(
     const PE* __restrict__ G, const CE* __restrict__ Csave, const float* __restrict__ Whh,
-    const DE* __restrict__ dY, __bf16* __restrict__ dP, float* __restrict__ dbias, int T, int Bp) {
+    const DE* __restrict__ dY, __bf16* __restrict__ dP, float* __restrict__ dbias, float* __restrict__ dbias2, int T, int Bp) {
     __shared__ __attribute__((aligned(16))) __bf16 dgs[16 * DGB_LD];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -370,7 +370,11 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_bwd_h128_bf16_s16_kernel(
                 float v = dbsum[g][cbu];
                 v += __shfl_xor(v, 16, 64);
                 v += __shfl_xor(v, 32, 64);
-                if (rq == 0) atomicAdd(dbias + (size_t)d * 4 * H + g * H + 32 * w + 16 * cbu + c16, v);
+                if (rq == 0) {
+                    const size_t bi = (size_t)d * 4 * H + g * H + 32 * w + 16 * cbu + c16;
+                    atomicAdd(dbias + bi, v);
+                    if (dbias2) atomicAdd(dbias2 + bi, v);          // b_ih and b_hh: the same gradient, two destinations
+                }
             }
     }
 }
@@ -402,7 +406,7 @@ template <bool C16> constexpr int RING_SLOT = 4 * RING_WAVE<C16>;          // 20
 template <int D, bool DY16, bool C16>
 __global__ __launch_bounds__(256, 2) void lstm_rec_bwd_h128_bf16_s16_dma_kernel(
     const __bf16* __restrict__ G, const void* __restrict__ Csavev, const float* __restrict__ Whh,
-    const void* __restrict__ dYv, __bf16* __restrict__ dP, float* __restrict__ dbias, int T, int Bp) {
+    const void* __restrict__ dYv, __bf16* __restrict__ dP, float* __restrict__ dbias, float* __restrict__ dbias2, int T, int Bp) {
     constexpr int NCD = C16 ? 1 : 2;                         // DMA instructions for c per step
     constexpr int VM_FIRST = 8 + 4 + NCD, VM_LOOP = VM_FIRST + 4;     // see the wait before the loop
     constexpr int CB = C16 ? 2 : 4;                          // bytes per stored c element
@@ -628,7 +632,11 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_bwd_h128_bf16_s16_dma_kernel(
                 float v = dbs[(2 * g + cbu) * 256 + tid];
                 v += __shfl_xor(v, 16, 64);
                 v += __shfl_xor(v, 32, 64);
-                if (rq == 0) atomicAdd(dbias + (size_t)d * 4 * H + g * H + 32 * w + 16 * cbu + c16, v);
+                if (rq == 0) {
+                    const size_t bi = (size_t)d * 4 * H + g * H + 32 * w + 16 * cbu + c16;
+                    atomicAdd(dbias + bi, v);
+                    if (dbias2) atomicAdd(dbias2 + bi, v);          // b_ih and b_hh: the same gradient, two destinations
+                }
             }
     }
 }
@@ -669,7 +677,7 @@ int lob_rec_fwd_bf16_s16(void* P, int pg_bf16, const float* Whh, float* Y, void*
 }
 
 int lob_rec_bwd_bf16_s16(const void* G, int pg_bf16, const void* Csave, int c_bf16, const float* Whh, const void* dY,
-                         int dy_bf16, void* dP, float* dbias, int T, int Bp, int D, hipStream_t s) {
+                         int dy_bf16, void* dP, float* dbias, float* dbias2, int T, int Bp, int D, hipStream_t s) {
     const dim3 grid(Bp / 16, D), block(256);
     // LOB_VAR_REC_BWD_DMA = 0 selects the register-prefetch kernel (also the only one for fp32 saved gates)
     const bool dma = lob_variant(LOB_VAR_REC_BWD_DMA) != 0;
@@ -678,7 +686,7 @@ int lob_rec_bwd_bf16_s16(const void* G, int pg_bf16, const void* Csave, int c_bf
     if ((dy_bf16 || c_bf16) && !pg_bf16) return LOB_E_SHAPE;       // bf16 dY / c only with bf16 saved gates
     if (pg_bf16 && dma) {
 #define LOB_BWD_DMA(DD, Y16, C16) hipLaunchKernelGGL((lstm_rec_bwd_h128_bf16_s16_dma_kernel<DD, Y16, C16>), grid, block, 0, s, \
-                                                     g16, Csave, Whh, dY, dp16, dbias, T, Bp)
+                                                     g16, Csave, Whh, dY, dp16, dbias, dbias2, T, Bp)
 #define LOB_BWD_DMA_D(DD) do {                                                               \
         if (dy_bf16 && c_bf16) LOB_BWD_DMA(DD, true, true);                                  \
         else if (dy_bf16)      LOB_BWD_DMA(DD, true, false);                                 \
@@ -690,7 +698,7 @@ int lob_rec_bwd_bf16_s16(const void* G, int pg_bf16, const void* Csave, int c_bf
     }
     else if (pg_bf16) {
 #define LOB_BWD_REG(DE, CE) hipLaunchKernelGGL((lstm_rec_bwd_h128_bf16_s16_kernel<__bf16, DE, CE>), grid, block, 0, s, g16, \
-                            reinterpret_cast<const CE*>(Csave), Whh, reinterpret_cast<const DE*>(dY), dp16, dbias, T, Bp)
+                            reinterpret_cast<const CE*>(Csave), Whh, reinterpret_cast<const DE*>(dY), dp16, dbias, dbias2, T, Bp)
         if (dy_bf16 && c_bf16) LOB_BWD_REG(__bf16, __bf16);
         else if (dy_bf16)      LOB_BWD_REG(__bf16, float);
         else if (c_bf16)       LOB_BWD_REG(float, __bf16);
@@ -700,7 +708,7 @@ int lob_rec_bwd_bf16_s16(const void* G, int pg_bf16, const void* Csave, int c_bf
     else
         hipLaunchKernelGGL((lstm_rec_bwd_h128_bf16_s16_kernel<float, float, float>), grid, block, 0, s,
                            reinterpret_cast<const float*>(G), reinterpret_cast<const float*>(Csave), Whh,
-                           reinterpret_cast<const float*>(dY), dp16, dbias, T, Bp);
+                           reinterpret_cast<const float*>(dY), dp16, dbias, dbias2, T, Bp);
     LOB_CHECK_LAUNCH();
     return 0;
 }

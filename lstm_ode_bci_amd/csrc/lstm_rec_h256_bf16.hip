@@ -169,7 +169,7 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h256_bf16_kernel(
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512, 2) void lstm_rec_bwd_h256_bf16_kernel(
     const __bf16* __restrict__ G, const float* __restrict__ Csave, const __bf16* __restrict__ WTb,
-    const float* __restrict__ dY, __bf16* __restrict__ dP, float* __restrict__ dbias, int T, int Bp) {
+    const float* __restrict__ dY, __bf16* __restrict__ dP, float* __restrict__ dbias, float* __restrict__ dbias2, int T, int Bp) {
     __shared__ __attribute__((aligned(16))) __bf16 dgs[32 * DGB_LD];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -273,7 +273,11 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_bwd_h256_bf16_kernel(
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float v = dbsum[g] + __shfl_xor(dbsum[g], 32, 64);
-            if (hi == 0) atomicAdd(dbias + (size_t)d * 4 * HH + g * HH + 32 * w + l31, v);
+            if (hi == 0) {
+                const size_t bi = (size_t)d * 4 * HH + g * HH + 32 * w + l31;
+                atomicAdd(dbias + bi, v);
+                if (dbias2) atomicAdd(dbias2 + bi, v);
+            }
         }
     }
 }
@@ -303,10 +307,10 @@ int lob_rec_fwd_h256_bf16(void* P, const void* Whh16, float* Y, float* Csave, vo
 }
 
 int lob_rec_bwd_h256_bf16(const void* G, const float* Csave, const void* WhhT16, const float* dY, void* dP,
-                          float* dbias, int T, int Bp, int D, hipStream_t s) {
+                          float* dbias, float* dbias2, int T, int Bp, int D, hipStream_t s) {
     hipLaunchKernelGGL(lstm_rec_bwd_h256_bf16_kernel, dim3(Bp / 32, D), dim3(512), 0, s,
                        reinterpret_cast<const __bf16*>(G), Csave, reinterpret_cast<const __bf16*>(WhhT16), dY,
-                       reinterpret_cast<__bf16*>(dP), dbias, T, Bp);
+                       reinterpret_cast<__bf16*>(dP), dbias, dbias2, T, Bp);
     LOB_CHECK_LAUNCH();
     return 0;
 }

@@ -370,8 +370,9 @@ def ode_rk4(base_rates, n_points, t0, t1, substeps, *, probs=None, alpha=0.0, y0
 # ---------------------------------------------------------------------------------------------
 # backward-side wrappers
 # ---------------------------------------------------------------------------------------------
-def lstm_rec_bwd(G, Cs, whh, dY, T, Bp, H, D, dp_bf16=False, dbias=None):
-    """BPTT through one layer; returns (dP[T*Bp, D*4H] row-major fp32|bf16, dbias[D*4H]); dbias: zeroed destination."""
+def lstm_rec_bwd(G, Cs, whh, dY, T, Bp, H, D, dp_bf16=False, dbias=None, dbias2=None):
+    """BPTT through one layer; returns (dP[T*Bp, D*4H] row-major fp32|bf16, dbias[D*4H]); dbias: zeroed destination.
+    dbias2 (mixed kernels only, see ``rec_bwd_two_bias_ok``): a second destination that receives the same adds."""
     g16 = G.dtype == torch.bfloat16
     dy16 = dY.dtype == torch.bfloat16
     c16 = Cs.dtype == torch.bfloat16
@@ -384,13 +385,15 @@ def lstm_rec_bwd(G, Cs, whh, dY, T, Bp, H, D, dp_bf16=False, dbias=None):
     fused_bias = uses_frag(H)
     if dbias is None:
         dbias = torch.zeros((D * 4 * H,), device=G.device, dtype=torch.float32)
-    _chk(dbias, "dbias")
+    _chk(dbias, "dbias"); _chk(dbias2, "dbias2")
+    if dbias2 is not None and not (dp_bf16 and bf16_rec(H, g16)):
+        raise _lib.LobError("lstm_rec_bwd: a second bias-gradient destination is taken by the bf16 BPTT kernels only")
     if dp_bf16 and bf16_rec(H, g16):
         whht16 = None
         if H == 256:       # [D, ks 64, hi 2, j 8, w 8, l31 32] -> [D, w, ks, hi, l31, j]  (fragment order, lob.h)
             whht16 = (whh.to(torch.bfloat16).reshape(D, 64, 2, 8, 8, 32).permute(0, 4, 1, 2, 5, 3).contiguous())
         rc = _lib.lib().lob_lstm_rec_bwd_bf16(_ptr(G), int(g16), _ptr(Cs), int(c16), _ptr(whh), _ptr(whht16), _ptr(dY),
-                                              int(dy16), _ptr(dP), _ptr(dbias), T, Bp, H, D, _stream())
+                                              int(dy16), _ptr(dP), _ptr(dbias), _ptr(dbias2), T, Bp, H, D, _stream())
     else:
         rc = _lib.lib().lob_lstm_rec_bwd_f32(_ptr(G), _ptr(Cs), _ptr(whh), _ptr(dY), _ptr(dP), int(dp_bf16),
                                              _ptr(dbias) if fused_bias else _ptr(None), T, Bp, H, D, _stream())

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Small-batch latency of the forward / coupled path (serving-style calls): ms per call and windows/s."""
+"""Small-batch latency of the forward / coupled path (serving-style calls): ms per call (best and median of five
+batches of --iters back-to-back calls, after a 30-ms warm-up) and windows/s."""
 import os, sys, time
 import numpy as np
 import torch
@@ -30,13 +31,21 @@ for B in [int(b) for b in args.batches.split(",")]:
                 def fn():
                     with torch.autocast("cuda", dtype=torch.bfloat16):
                         return m(x)
-            for _ in range(3):
+            # warm-up: the first calls of a new shape / precision load code objects and grow the caching allocator, and an
+            # idle GPU ramps its clocks over tens of milliseconds -- run until 30 ms of work have passed
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < 0.03:
                 fn()
-            torch.cuda.synchronize()
-            t = time.perf_counter()
+                torch.cuda.synchronize()
             n = args.iters
-            for _ in range(n):
-                fn()
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t) / n
-        print(f"B={B:4d} {name:24s} {dt * 1e3:8.3f} ms/call  {B / dt:10.0f} windows/s", flush=True)
+            rates = []
+            for _ in range(5):                 # five batches of n calls: min and median of the per-call time
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                torch.cuda.synchronize()
+                rates.append((time.perf_counter() - t) / n)
+            rates.sort()
+            dt, med = rates[0], rates[2]
+        print(f"B={B:4d} {name:24s} {dt * 1e3:8.3f} ms/call (median {med * 1e3:6.3f})  {B / dt:10.0f} windows/s", flush=True)
