@@ -81,6 +81,14 @@ def _forward_impl(x, ps, cfg, save):
         sv["x2d"], sv["pre"], sv["a"], sv["xb"] = x2d, pre, a, xb
         sv["layers"] = []
     inp = a
+    # mixed path: the last layer hands its output to the LayerNorm as bf16 only (ops.LN_X_BF16) -- no fp32 Y is written
+    # or read.  When saving for a backward, only if that backward will carry bf16 gradients through this LayerNorm
+    # (bf16 dV from the attention backward, bf16 dx: the conditions of backward_impl, restated on the forward's facts)
+    a0w_p = ps[len(ps) - 10]
+    ln_x16 = bool(mixed and ops.LN_X_BF16 and ops.can_fuse_dropout(H, mixed) and ops.ln_x_bf16_ok(W))
+    if ln_x16 and save:
+        ln_x16 = bool(a0w_p is not None and ops.dy_bf16_ok(H, mixed) and
+                      ops.dma_ok(a0w_p.shape[0], W, T * Bp) and ps[len(ps) - 12] is not None)
     for layer in range(L):
         for _ in range(4 * D):
             next(it)
@@ -102,14 +110,16 @@ def _forward_impl(x, ps, cfg, save):
         # layer's GEMMs read Yd / Y16, dW_hh reads Y16); the last layer keeps fp32 Y for the LayerNorm
         Y, Cs, Y16, Yd = ops.lstm_rec_fwd(P, whh, T, Bp, H, D, save, mixed=mixed,
                                           drop_p=p_lstm if fuse else 0.0, seed=_seed(seed, 10 + layer),
-                                          want_f32=last or not bf16_out, want_bf16=bf16_out and (save or not last),
-                                          nvalid=B)
+                                          want_f32=(last and not ln_x16) or not bf16_out,
+                                          want_bf16=bf16_out and (save or not last or ln_x16), nvalid=B)
         if fuse:
             nxt = Yd
         elif bf16_out and not last:
             nxt = Y16
         elif drop_here:
             nxt = ops.dropout(Y, p_lstm, _seed(seed, 10 + layer))
+        elif last and ln_x16:
+            nxt = Y16
         else:
             nxt = Y
         if save:

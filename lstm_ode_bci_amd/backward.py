@@ -169,8 +169,12 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad, sink=None):
             return None, None
         return tgt.param(i, ps[i].shape), tgt.param(i + 1, ps[i + 1].shape)
     dg_t, db_t = affine(i_ln)
-    dY, g[i_ln], g[i_ln + 1] = ops.layernorm_act_bwd(sv["ylast"], ps[i_ln], ps[i_ln + 1], dV, pool=pool_ctx, dg=dg_t, db=db_t,
-                                                     dx_bf16=carry16 and width_ok(sv["ylast"].shape[1]))
+    ylast = sv["ylast"]
+    dx16 = carry16 and width_ok(ylast.shape[1])
+    if ylast.dtype == torch.bfloat16 and not (dx16 and dV.dtype == torch.bfloat16):
+        ylast = ylast.float()        # a storage switch was flipped between forward and backward: widen, stay correct
+    dY, g[i_ln], g[i_ln + 1] = ops.layernorm_act_bwd(ylast, ps[i_ln], ps[i_ln + 1], dV, pool=pool_ctx, dg=dg_t, db=db_t,
+                                                     dx_bf16=dx16)
 
     # ---- LSTM stack, last layer first (04:211)
     for layer in reversed(range(L)):

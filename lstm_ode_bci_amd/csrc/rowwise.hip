@@ -298,9 +298,10 @@ __device__ __forceinline__ float row_sum(float v) {
     return v;
 }
 
-template <int VPL, bool OUT_BF16, int LPR = 64>
+// XE: storage type of the input rows (LOB_X_BF16: the last LSTM layer's output handed over as bf16 only)
+template <int VPL, bool OUT_BF16, int LPR = 64, typename XE = float>
 __global__ __launch_bounds__(256) void layernorm_act_vec_kernel(
-    const float* __restrict__ in, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const XE* __restrict__ in, const float* __restrict__ gamma, const float* __restrict__ beta,
     void* __restrict__ outv, int rows, float eps, int act,
     int remap_T, int remap_B, int remap_Bp, float drop_p, uint64_t seed) {
     constexpr int width = LPR * VPL, GPW = 64 / LPR;       // GPW rows per wave pass
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(256) void layernorm_act_vec_kernel(
             const int g = g0 + r * GPW + sub;
             rowv[r] = g; orowv[r] = g;
             ok[r] = g < count && (remap_T <= 0 || tiled_row(g, remap_T, remap_B, remap_Bp, rowv[r], orowv[r]));
-            if (ok[r]) ldv<VPL>(in + (size_t)rowv[r] * width + sl * VPL, vv[r]);
+            if (ok[r]) ldv_t<VPL, XE>(in + (size_t)rowv[r] * width + sl * VPL, vv[r]);
         }
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
@@ -371,9 +372,9 @@ __device__ __forceinline__ float red_sum(const float (&r)[N][W], int c) {
 
 // DYE / DXE: storage type of the incoming gradient dy / the outgoing dx (mixed path: the gradient carried between the
 // LSTM layers and into / out of the LayerNorms is a bf16 stream; LOB_DY_BF16 / LOB_OUT_BF16)
-template <int VPL, int LPR = 64, typename DYE = float, typename DXE = float>
+template <int VPL, int LPR = 64, typename DYE = float, typename DXE = float, typename XE = float>
 __global__ __launch_bounds__(256) void layernorm_act_bwd_vec_kernel(
-    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const XE* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     const DYE* __restrict__ dy, DXE* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
     int rows, float eps, int act, int remap_T, int remap_B, int remap_Bp, float drop_p, uint64_t seed,
     const float* __restrict__ pool_attn, const float* __restrict__ pool_dctx, int pool_T, int pool_B, int pool_Bp,
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(256) void layernorm_act_bwd_vec_kernel(
             rowv[r] = g; orowv[r] = g;
             ok[r] = g < count && (remap_T <= 0 || tiled_row(g, remap_T, remap_B, remap_Bp, rowv[r], orowv[r]));
             if (ok[r]) {
-                ldv<VPL>(x + (size_t)rowv[r] * width + sl * VPL, vv[r]);
+                ldv_t<VPL, XE>(x + (size_t)rowv[r] * width + sl * VPL, vv[r]);
                 ldv_t<VPL, DYE>(dy + (size_t)orowv[r] * width + sl * VPL, gov[r]);
             }
         }
@@ -678,10 +679,25 @@ extern "C" int lob_layernorm_act_f32(const float* in, const float* gamma, const 
                                      int remap_T, int remap_B, int remap_Bp,
                                      float drop_p, uint64_t seed, void* stream) {
     const bool ident = (act & LOB_LN_IDENTITY) != 0;
+    const bool x16 = (act & LOB_X_BF16) != 0;
+    act &= ~LOB_X_BF16;
     if (!in || !out || rows <= 0 || width <= 0 || (!ident && (!gamma || !beta))) return LOB_E_ARG;
     if (width > 64 * LN_MAX_PER_LANE) return LOB_E_SHAPE;
     if (drop_p < 0.f || drop_p >= 1.f) return LOB_E_ARG;
     if (remap_T > 0 && (remap_B <= 0 || remap_Bp < remap_B || rows != remap_T * remap_B)) return LOB_E_SHAPE;
+    if (x16) {       // bf16 input rows: the post-LSTM LayerNorm of the mixed path (width 256), vectorised kernel only
+        if (width != 256 || ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) |
+                              reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15)) return LOB_E_SHAPE;
+        int nb = (rows + 3) / 4;
+        if (nb > 256 * 16) nb = 256 * 16;
+        const __bf16* inb = reinterpret_cast<const __bf16*>(in);
+        if (out_bf16) hipLaunchKernelGGL((layernorm_act_vec_kernel<4, true, 64, __bf16>), dim3(nb), dim3(256), 0, (hipStream_t)stream,
+                                         inb, gamma, beta, out, rows, eps, act, remap_T, remap_B, remap_Bp, drop_p, seed);
+        else hipLaunchKernelGGL((layernorm_act_vec_kernel<4, false, 64, __bf16>), dim3(nb), dim3(256), 0, (hipStream_t)stream,
+                                inb, gamma, beta, out, rows, eps, act, remap_T, remap_B, remap_Bp, drop_p, seed);
+        LOB_CHECK_LAUNCH();
+        return 0;
+    }
     const int waves_per_block = 4;
     // the walk a wave strides over: rows, or (remap) the 8 x 8 (b, t) tiles INCLUDING their out-of-range corners -- with
     // one window that is 8 x the rows, and a grid sized from `rows` made every wave loop 8 times (28 us for 256 rows)
@@ -772,8 +788,9 @@ extern "C" int lob_layernorm_act_bwd_f32(const float* x, const float* gamma, con
                                          uint64_t seed, const float* pool_attn, const float* pool_dctx,
                                          int pool_T, int pool_B, int pool_Bp, float* dx_colsum, void* stream) {
     const bool ident = (act & LOB_LN_IDENTITY) != 0;
-    const bool dy16 = (act & LOB_DY_BF16) != 0, dx16 = (act & LOB_OUT_BF16) != 0;
-    act &= ~(LOB_DY_BF16 | LOB_OUT_BF16);
+    const bool dy16 = (act & LOB_DY_BF16) != 0, dx16 = (act & LOB_OUT_BF16) != 0, x16 = (act & LOB_X_BF16) != 0;
+    act &= ~(LOB_DY_BF16 | LOB_OUT_BF16 | LOB_X_BF16);
+    if (x16 && !(dy16 && dx16 && width == 256)) return LOB_E_SHAPE;   // bf16 x: with bf16 dy / dx at width 256 only
     if (!x || !dy || !dx || rows <= 0 || width <= 0) return LOB_E_ARG;
     if (!ident && (!gamma || !beta || !dgamma || !dbeta)) return LOB_E_ARG;
     if (width > 64 * LN_MAX_PER_LANE) return LOB_E_SHAPE;
@@ -794,7 +811,12 @@ extern "C" int lob_layernorm_act_bwd_f32(const float* x, const float* gamma, con
                        remap_B, remap_Bp, drop_p, seed, pool_attn, pool_dctx, pool_T, pool_B, pool_Bp, dx_colsum)
         if (width == 256) {
             if (blocks > 256 * 8) blocks = 256 * 8;
-            if (dy16 && dx16)       LOB_LNB_T(4, 64, __bf16, __bf16, dyb, dxb);
+            if (x16)
+                hipLaunchKernelGGL((layernorm_act_bwd_vec_kernel<4, 64, __bf16, __bf16, __bf16>), dim3(blocks), dim3(256), 0,
+                                   (hipStream_t)stream, reinterpret_cast<const __bf16*>(x), gamma, beta, dyb, dxb, dgamma, dbeta,
+                                   rows, eps, act, remap_T, remap_B, remap_Bp, drop_p, seed, pool_attn, pool_dctx, pool_T, pool_B,
+                                   pool_Bp, dx_colsum);
+            else if (dy16 && dx16)  LOB_LNB_T(4, 64, __bf16, __bf16, dyb, dxb);
             else if (dx16)          LOB_LNB_T(4, 64, float, __bf16, dy, dxb);
             else                    LOB_LNB_T(4, 64, __bf16, float, dyb, dx);
         } else if (width == 128) {

@@ -13,7 +13,7 @@ from . import _lib
 
 ACT_NONE, ACT_TANH, ACT_GELU = 0, 1, 2
 LN_IDENTITY = 0x200          # LOB_LN_IDENTITY: OR into `act` of the LayerNorm entry points
-OUT_BF16, DY_BF16 = 0x400, 0x800      # LOB_OUT_BF16 / LOB_DY_BF16 (include/lob.h)
+OUT_BF16, DY_BF16, X_BF16 = 0x400, 0x800, 0x1000      # LOB_OUT_BF16 / LOB_DY_BF16 / LOB_X_BF16 (include/lob.h)
 
 #: mixed mode, H == 128: carry the gradient between the LSTM layers (dX of the layer above = dY of the layer below), out
 #: of the post-LSTM LayerNorm and into the input-projection LayerNorm as bf16 -- like dP, it is only consumed after
@@ -284,10 +284,15 @@ def layernorm_act(x, gamma, beta, act=ACT_NONE, eps=1e-5, remap=None, drop_p=0.0
                   out_bf16=False):
     """LN(+act, +dropout) over the last axis of x[rows, width]; remap=(T, B, Bp) relays rows
     (b,t) -> t*Bp + b (out must then have T*Bp rows; pad rows are left untouched)."""
-    _chk(x, "x"); _chk(gamma, "gamma"); _chk(beta, "beta")
+    x16 = x.dtype == torch.bfloat16
+    _chk(x, "x", torch.bfloat16 if x16 else torch.float32); _chk(gamma, "gamma"); _chk(beta, "beta")
     if gamma is None:            # nn.Identity in place of the LayerNorm (09_sensitivity_analysis.py:190, 209)
         act = act | LN_IDENTITY
     rows, width = x.shape
+    if x16:
+        if not ln_x_bf16_ok(width) or remap is not None:
+            raise _lib.LobError("layernorm_act: bf16 input rows are read at width 256 (no relayout) only")
+        act = act | X_BF16
     out_bf16 = bool(out_bf16) and width in (128, 256, 512)
     odt = torch.bfloat16 if out_bf16 else torch.float32
     if remap is None:
@@ -438,8 +443,14 @@ def layernorm_act_bwd(x, gamma, beta, dy, act=ACT_NONE, eps=1e-5, remap=None, dr
     (widths 128/256/512): += column sums of dx (see ``can_fuse_colsum``).  dy may be bf16 and dx_bf16 stores dx as
     bf16 (widths 128 / 256: the mixed path's gradient carries, ``DY_BF16_CARRY``)."""
     dy16 = dy.dtype == torch.bfloat16
-    _chk(x, "x"); _chk(gamma, "gamma"); _chk(beta, "beta"); _chk(dy, "dy", torch.bfloat16 if dy16 else torch.float32)
+    x16 = x.dtype == torch.bfloat16
+    _chk(x, "x", torch.bfloat16 if x16 else torch.float32); _chk(gamma, "gamma"); _chk(beta, "beta")
+    _chk(dy, "dy", torch.bfloat16 if dy16 else torch.float32)
     rows, width = x.shape
+    if x16:
+        if not (ln_x_bf16_ok(width) and dy16 and dx_bf16):
+            raise _lib.LobError("layernorm_act_bwd: bf16 input rows need width 256 and bf16 dy / dx")
+        act = act | X_BF16
     rT, rB, rBp = (0, 0, 0) if remap is None else remap
     dx = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16 if dx_bf16 else torch.float32)
     if dy16:
@@ -459,6 +470,15 @@ def layernorm_act_bwd(x, gamma, beta, dy, act=ACT_NONE, eps=1e-5, remap=None, dr
                                               _ptr(pa), _ptr(pd), pT, pB, pBp, _ptr(dx_colsum), _stream())
     _lib.check(rc, "lob_layernorm_act_bwd_f32")
     return dx, dg, db
+
+
+#: mixed path: the last LSTM layer hands its output to the LayerNorm as bf16 only (no fp32 copy of Y is written or read).
+LN_X_BF16 = True
+
+
+def ln_x_bf16_ok(width):
+    """Width at which the LayerNorm kernels read bf16 input rows (the post-LSTM LayerNorm at H = 128, D = 2)."""
+    return width == 256
 
 
 def can_fuse_colsum(width):

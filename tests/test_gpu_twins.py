@@ -541,3 +541,28 @@ def test_no_grad_forward_does_not_save_and_matches_grad_mode(dev, B1):
         assert lg.requires_grad and not ln.requires_grad and ln.grad_fn is None
         tol = 3e-3 if mixed else 1e-5
         assert (lg - ln).abs().max().item() <= tol and (ag - an).abs().max().item() <= tol
+
+
+def test_layernorm_bf16_input_rows_equal_the_widened_rows(dev):
+    """LOB_X_BF16 (the last LSTM layer hands its output to the post-LSTM LayerNorm, 04_lstm_model.py:212, as bf16 only):
+    reading bf16 rows must give exactly what the fp32-input kernels give on the same values widened -- forward (bf16 and
+    fp32 out) and backward (bf16 dy / dx, fused pooling term), at rows = 1,048,576 and at a ragged row count."""
+    from lstm_ode_bci_amd import ops
+    W = 256
+    for rows, Tn, Bn in ((T * B, T, B), (3 * 96, 3, 96)):
+        x16 = _rand((rows, W), dev, 71, 0.5, dtype=torch.bfloat16)
+        gm, bt = 1 + _rand((W,), dev, 72, 0.1), _rand((W,), dev, 73, 0.1)
+        for ob in (True, False):
+            a = ops.layernorm_act(x16, gm, bt, out_bf16=ob)
+            b = ops.layernorm_act(x16.float(), gm, bt, out_bf16=ob)
+            assert a.dtype == b.dtype and torch.equal(a, b)
+        dy = _rand((rows, W), dev, 74, 1e-3, dtype=torch.bfloat16)
+        attn = torch.softmax(_rand((Bn, Tn), dev, 75), 1)
+        dctx = _rand((Bn, W), dev, 76, 1e-3)
+        pool = (attn, dctx, Tn, Bn, Bn)
+        dxa, dga, dba = ops.layernorm_act_bwd(x16, gm, bt, dy, pool=pool, dx_bf16=True)
+        dxb, dgb, dbb = ops.layernorm_act_bwd(x16.float(), gm, bt, dy, pool=pool, dx_bf16=True)
+        assert dxa.dtype == torch.bfloat16 and torch.equal(dxa, dxb)
+        # dgamma / dbeta: fp32 atomics, order not fixed
+        assert (dga - dgb).abs().max().item() <= 1e-4 * dgb.abs().max().item()
+        assert (dba - dbb).abs().max().item() <= 1e-4 * dbb.abs().max().item()
