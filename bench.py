@@ -426,6 +426,8 @@ def extra_legs(dev, forecast_steps):
          dict(mode="train", precision="mixed", B=4096, H=256), 5, 2),
         ("configs[4] per-rank shard: forward, B=8192, fp32", dict(mode="fwd", precision="fp32", B=8192, H=128), 4, 2),
         ("configs[4] per-rank shard: forward, B=8192, mixed", dict(mode="fwd", precision="mixed", B=8192, H=128), 5, 2),
+        ("H=256 mixed forward, B=4096 (a real checkpoint under the reference's inference autocast, 06:349)",
+         dict(mode="fwd", precision="mixed", B=4096, H=256), 5, 2),
     ]
     out = {}
     for name, kw, steps, warmup in specs:

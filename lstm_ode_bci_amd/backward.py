@@ -89,7 +89,7 @@ class _Targets:
 
 def width_ok(w):
     """Widths at which the LayerNorm backward reads / writes bf16 gradient streams."""
-    return w in (128, 256)
+    return w in (128, 256, 512)
 
 
 def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad, sink=None):

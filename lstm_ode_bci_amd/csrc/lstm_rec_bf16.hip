@@ -347,10 +347,10 @@ int lob_rec_fwd_bf16_s16(void* P, int pg_bf16, const float* Whh, float* Y, void*
 int lob_rec_bwd_bf16_s16(const void* G, int pg_bf16, const void* Csave, int c_bf16, const float* Whh, const void* dY,
                          int dy_bf16, void* dP, float* dbias, float* dbias2, int T, int Bp, int D, hipStream_t s);
 // H = 256: W_hh streamed from L2 (lstm_rec_h256_bf16.hip); bf16 P / saved gates only
-int lob_rec_fwd_h256_bf16(void* P, const void* Whh16, float* Y, float* Csave, void* Y16, void* Yd, float drop_p,
+int lob_rec_fwd_h256_bf16(void* P, const void* Whh16, float* Y, void* Csave, int c_bf16, void* Y16, void* Yd, float drop_p,
                           uint64_t seed, int T, int Bp, int D, int save, hipStream_t s);
-int lob_rec_bwd_h256_bf16(const void* G, const float* Csave, const void* WhhT16, const float* dY, void* dP,
-                          float* dbias, float* dbias2, int T, int Bp, int D, hipStream_t s);
+int lob_rec_bwd_h256_bf16(const void* G, const void* Csave, int c_bf16, const void* WhhT16, const void* dY, int dy_bf16,
+                          void* dP, float* dbias, float* dbias2, int T, int Bp, int D, hipStream_t s);
 static bool use_s16() {
     const bool v = lob_variant(LOB_VAR_REC_BF16_ROWS) != 32;
     return v;
@@ -363,8 +363,8 @@ extern "C" int lob_lstm_rec_fwd_bf16(void* P, int pg_bf16, const float* Whh, con
     if (!Y && !Y16) return LOB_E_ARG;
     if (nvalid < 0 || nvalid > Bp) return LOB_E_ARG;
     if (save && !Csavev) return LOB_E_ARG;
-    // bf16 cell-state storage: the 16-row H = 128 kernels only
-    if (c_bf16 && (Hh != 128 || !use_s16())) return LOB_E_SHAPE;
+    // bf16 cell-state storage: the 16-row H = 128 kernels and the H = 256 kernels
+    if (c_bf16 && !((Hh == 128 && use_s16()) || Hh == 256)) return LOB_E_SHAPE;
     float* Csave = reinterpret_cast<float*>(Csavev);
     if (Yd && (drop_p <= 0.f || drop_p >= 1.f)) return LOB_E_ARG;
     if (Hh == 256) {
@@ -372,7 +372,7 @@ extern "C" int lob_lstm_rec_fwd_bf16(void* P, int pg_bf16, const float* Whh, con
         if (!Whh16) return LOB_E_ARG;
         if ((reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(Whh16) | reinterpret_cast<uintptr_t>(Csave) |
              reinterpret_cast<uintptr_t>(Y16) | reinterpret_cast<uintptr_t>(Yd)) & 15) return LOB_E_ALIGN;
-        return lob_rec_fwd_h256_bf16(P, Whh16, Y, Csave, Y16, Yd, drop_p, seed, T, Bp, D, save, (hipStream_t)stream);
+        return lob_rec_fwd_h256_bf16(P, Whh16, Y, Csavev, c_bf16, Y16, Yd, drop_p, seed, T, Bp, D, save, (hipStream_t)stream);
     }
     if (Hh != 128 || (Bp % 32)) return LOB_E_SHAPE;
     if ((reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(Whh) | reinterpret_cast<uintptr_t>(Csave) |
@@ -404,8 +404,8 @@ extern "C" int lob_lstm_rec_bwd_bf16(const void* G, int pg_bf16, const void* Csa
                                      const void* WhhT16, const void* dYv, int dy_bf16, void* dP, float* dbias, float* dbias2, int T, int Bp,
                                      int Hh, int D, void* stream) {
     if (!G || !Csavev || !Whh || !dYv || !dP || T <= 0 || Bp <= 0 || (D != 1 && D != 2)) return LOB_E_ARG;
-    // bf16 dY / bf16 cell state: the 16-row H = 128 kernels only
-    if ((dy_bf16 || c_bf16) && (Hh != 128 || !use_s16())) return LOB_E_SHAPE;
+    // bf16 dY / bf16 cell state: the 16-row H = 128 kernels and the H = 256 kernel
+    if ((dy_bf16 || c_bf16) && !((Hh == 128 && use_s16()) || Hh == 256)) return LOB_E_SHAPE;
     const float* Csave = reinterpret_cast<const float*>(Csavev);
     const float* dY = reinterpret_cast<const float*>(dYv);
     if (Hh == 256) {
@@ -413,7 +413,7 @@ extern "C" int lob_lstm_rec_bwd_bf16(const void* G, int pg_bf16, const void* Csa
         if (!WhhT16) return LOB_E_ARG;
         if ((reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(Csave) | reinterpret_cast<uintptr_t>(WhhT16) |
              reinterpret_cast<uintptr_t>(dP)) & 15) return LOB_E_ALIGN;
-        return lob_rec_bwd_h256_bf16(G, Csave, WhhT16, dY, dP, dbias, dbias2, T, Bp, D, (hipStream_t)stream);
+        return lob_rec_bwd_h256_bf16(G, Csavev, c_bf16, WhhT16, dYv, dy_bf16, dP, dbias, dbias2, T, Bp, D, (hipStream_t)stream);
     }
     if (Hh != 128 || (Bp % 32)) return LOB_E_SHAPE;
     if ((reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(Csave) |

@@ -34,9 +34,12 @@ __device__ __forceinline__ void load_raw(const __bf16* p, unsigned off8, Raw& r)
         for (int pq = 0; pq < 2; ++pq) r.v[2 * g + pq] = *reinterpret_cast<const bf16x8*>((p + g * 1024 + pq * 512) + off8);
 }
 
-template <bool SAVE, bool YF32, bool Y16, bool DROP>
+// CE: storage type of the saved cell states (fp32 [q 4][lane 64][4], or bf16 in the element order of one saved gate,
+// [q pair 2][lane 64][8]: ops.C_BF16, as in the H = 128 kernels -- BPTT only uses c_t inside tanh and as a factor next
+// to bf16 gate values; the state carried through time stays fp32 in registers)
+template <bool SAVE, bool YF32, bool Y16, bool DROP, typename CE = float>
 __global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h256_bf16_kernel(
-    __bf16* __restrict__ P, const __bf16* __restrict__ Wb, float* __restrict__ Y, float* __restrict__ Csave,
+    __bf16* __restrict__ P, const __bf16* __restrict__ Wb, float* __restrict__ Y, CE* __restrict__ Csave,
     __bf16* __restrict__ Y16p, __bf16* __restrict__ Yd, float drop_p, uint64_t seed, int T, int Bp) {
     __shared__ __attribute__((aligned(16))) __bf16 hs[2 * 32 * HB_LD];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h256_bf16_kernel(
 
     const size_t pstep = (size_t)NBT * NW * 4096, cstep = (size_t)NBT * NW * 1024;
     __bf16* pblk = P + (((size_t)d * T * NBT + bt) * NW + w) * 4096;
-    float* cblk = SAVE ? Csave + (((size_t)d * T * NBT + bt) * NW + w) * 1024 : nullptr;
+    CE* cblk = SAVE ? Csave + (((size_t)d * T * NBT + bt) * NW + w) * 1024 : nullptr;
     const unsigned off8 = lane * 8, off4 = lane * 4;
     const int DH = D * HH;
     const unsigned y_off = (unsigned)(4 * hi * DH + l31);
@@ -129,11 +132,21 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h256_bf16_kernel(
                     for (int e = 0; e < 8; ++e) v[e] = (__bf16)acc[g][8 * pq + e];
                     *reinterpret_cast<bf16x8*>((gp + g * 1024 + pq * 512) + off8) = v;
                 }
-            float* cp = cblk + (size_t)t * cstep;
+            CE* cp = cblk + (size_t)t * cstep;
+            if constexpr (sizeof(CE) == 4) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 v = {c[4 * q + 0], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]};
-                *reinterpret_cast<f32x4*>((cp + q * 256) + off4) = v;
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v = {c[4 * q + 0], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]};
+                    *reinterpret_cast<f32x4*>((cp + q * 256) + off4) = v;
+                }
+            } else {
+#pragma unroll
+                for (int pq = 0; pq < 2; ++pq) {
+                    bf16x8 v;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (__bf16)c[8 * pq + e];
+                    *reinterpret_cast<bf16x8*>((cp + pq * 512) + off8) = v;
+                }
             }
         }
         __syncthreads();
@@ -167,9 +180,12 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h256_bf16_kernel(
 // fragments W_hh^T[unit][n = 16 ks + 8 hi .. +7] (ks < 64) are streamed from the pre-transposed bf16 copy, 8 per
 // group, one group ahead.  The bf16 dgates tile (32 x 1024) is the MFMA A operand and the dP image.
 // ------------------------------------------------------------------------------------------
+// CE / DE: storage types of the saved cell states and of the incoming gradient dY (fp32, or bf16: ops.C_BF16 /
+// ops.DY_BF16_CARRY -- the gradient carried from layer to layer is a bf16 stream like dP)
+template <typename CE, typename DE>
 __global__ __launch_bounds__(512, 2) void lstm_rec_bwd_h256_bf16_kernel(
-    const __bf16* __restrict__ G, const float* __restrict__ Csave, const __bf16* __restrict__ WTb,
-    const float* __restrict__ dY, __bf16* __restrict__ dP, float* __restrict__ dbias, float* __restrict__ dbias2, int T, int Bp) {
+    const __bf16* __restrict__ G, const CE* __restrict__ Csave, const __bf16* __restrict__ WTb,
+    const DE* __restrict__ dY, __bf16* __restrict__ dP, float* __restrict__ dbias, float* __restrict__ dbias2, int T, int Bp) {
     __shared__ __attribute__((aligned(16))) __bf16 dgs[32 * DGB_LD];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -178,10 +194,10 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_bwd_h256_bf16_kernel(
 
     const size_t gstep = (size_t)NBT * NW * 4096, cstep = (size_t)NBT * NW * 1024;
     const __bf16* gwave = G + (((size_t)d * T * NBT + bt) * NW + w) * 4096;
-    const float* cwave = Csave + (((size_t)d * T * NBT + bt) * NW + w) * 1024;
+    const CE* cwave = Csave + (((size_t)d * T * NBT + bt) * NW + w) * 1024;
     const unsigned off8 = lane * 8, off4 = lane * 4;
     const int DH = D * HH, D4H = D * 4 * HH;
-    const float* dywave = dY + (size_t)(bt * 32) * DH + d * HH + 32 * w;
+    const DE* dywave = dY + (size_t)(bt * 32) * DH + d * HH + 32 * w;
     const unsigned dy_off = (unsigned)(4 * hi * DH + l31);
     // B fragments in fragment order [D][wave][ks 64][lane 64][8]: element = W_hh[n = 16 ks + 8 (lane >> 5) + j][32w + (lane & 31)]
     const __bf16* wtwave = WTb + ((size_t)d * NW + w) * (64 * 64 * 8);
@@ -196,11 +212,20 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_bwd_h256_bf16_kernel(
 
     auto load_c = [&](int t, f32x16& dst) {
         if (t >= 0 && t < T) {
-            const float* cq = cwave + (size_t)t * cstep;
+            const CE* cq = cwave + (size_t)t * cstep;
+            if constexpr (sizeof(CE) == 4) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>((cq + q * 256) + off4);
-                dst[4 * q] = v[0]; dst[4 * q + 1] = v[1]; dst[4 * q + 2] = v[2]; dst[4 * q + 3] = v[3];
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>((cq + q * 256) + off4);
+                    dst[4 * q] = v[0]; dst[4 * q + 1] = v[1]; dst[4 * q + 2] = v[2]; dst[4 * q + 3] = v[3];
+                }
+            } else {
+#pragma unroll
+                for (int pq = 0; pq < 2; ++pq) {
+                    const bf16x8 v = *reinterpret_cast<const bf16x8*>((cq + pq * 512) + off8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) dst[8 * pq + e] = (float)v[e];
+                }
             }
         } else {
 #pragma unroll
@@ -211,9 +236,9 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_bwd_h256_bf16_kernel(
     auto load_step = [&](int t) {
         load_raw(gwave + (size_t)t * gstep, off8, graw);
         load_c(t + dt, cp);
-        const float* dp = dywave + (size_t)t * Bp * DH;
+        const DE* dp = dywave + (size_t)t * Bp * DH;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dy[r] = (dp + ((r & 3) + 8 * (r >> 2)) * DH)[dy_off];
+        for (int r = 0; r < 16; ++r) dy[r] = (float)(dp + ((r & 3) + 8 * (r >> 2)) * DH)[dy_off];
     };
     bf16x8 wb[2][4];              // group q = k-steps 4q .. 4q+3 (64 k-steps of 16 gate rows in 16 groups), one group ahead
                                   // (three ahead as in the forward kernel spills here: 4.7 ms; this is HBM-bound anyway)
@@ -285,32 +310,37 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_bwd_h256_bf16_kernel(
 }  // namespace
 
 // Internal entry points used by lob_lstm_rec_fwd_bf16 / lob_lstm_rec_bwd_bf16 (lstm_rec_bf16.hip) at H = 256.
-int lob_rec_fwd_h256_bf16(void* P, const void* Whh16, float* Y, float* Csave, void* Y16, void* Yd, float drop_p,
+int lob_rec_fwd_h256_bf16(void* P, const void* Whh16, float* Y, void* Csave, int c_bf16, void* Y16, void* Yd, float drop_p,
                           uint64_t seed, int T, int Bp, int D, int save, hipStream_t s) {
     const dim3 grid(Bp / 32, D), block(512);
     __bf16* y16 = reinterpret_cast<__bf16*>(Y16);
     __bf16* yd = reinterpret_cast<__bf16*>(Yd);
-#define LOB_FWD(SV, YF, Y6, DR) hipLaunchKernelGGL((lstm_rec_fwd_h256_bf16_kernel<SV, YF, Y6, DR>), grid, block, 0, s, \
-        reinterpret_cast<__bf16*>(P), reinterpret_cast<const __bf16*>(Whh16), Y, Csave, y16, yd, drop_p, seed, T, Bp)
-#define LOB_FWD_OUT(SV) do {                                                     \
-        if (Y && !y16 && !yd) LOB_FWD(SV, true, false, false);                   \
-        else if (Y && y16 && !yd) LOB_FWD(SV, true, true, false);                \
-        else if (Y && !y16 && yd) LOB_FWD(SV, true, false, true);                \
-        else if (Y && y16 && yd) LOB_FWD(SV, true, true, true);                  \
-        else if (!Y && y16 && !yd) LOB_FWD(SV, false, true, false);              \
-        else LOB_FWD(SV, false, true, true); } while (0)
-    if (save) LOB_FWD_OUT(true); else LOB_FWD_OUT(false);
+    if (c_bf16 && !save) return LOB_E_SHAPE;
+#define LOB_FWD(SV, YF, Y6, DR, CE) hipLaunchKernelGGL((lstm_rec_fwd_h256_bf16_kernel<SV, YF, Y6, DR, CE>), grid, block, 0, s, \
+        reinterpret_cast<__bf16*>(P), reinterpret_cast<const __bf16*>(Whh16), Y, reinterpret_cast<CE*>(Csave), y16, yd, drop_p, seed, T, Bp)
+#define LOB_FWD_OUT(SV, CE) do {                                                     \
+        if (Y && !y16 && !yd) LOB_FWD(SV, true, false, false, CE);                   \
+        else if (Y && y16 && !yd) LOB_FWD(SV, true, true, false, CE);                \
+        else if (Y && !y16 && yd) LOB_FWD(SV, true, false, true, CE);                \
+        else if (Y && y16 && yd) LOB_FWD(SV, true, true, true, CE);                  \
+        else if (!Y && y16 && !yd) LOB_FWD(SV, false, true, false, CE);              \
+        else LOB_FWD(SV, false, true, true, CE); } while (0)
+    if (save && c_bf16) LOB_FWD_OUT(true, __bf16); else if (save) LOB_FWD_OUT(true, float); else LOB_FWD_OUT(false, float);
 #undef LOB_FWD_OUT
 #undef LOB_FWD
     LOB_CHECK_LAUNCH();
     return 0;
 }
 
-int lob_rec_bwd_h256_bf16(const void* G, const float* Csave, const void* WhhT16, const float* dY, void* dP,
-                          float* dbias, float* dbias2, int T, int Bp, int D, hipStream_t s) {
-    hipLaunchKernelGGL(lstm_rec_bwd_h256_bf16_kernel, dim3(Bp / 32, D), dim3(512), 0, s,
-                       reinterpret_cast<const __bf16*>(G), Csave, reinterpret_cast<const __bf16*>(WhhT16), dY,
-                       reinterpret_cast<__bf16*>(dP), dbias, dbias2, T, Bp);
+int lob_rec_bwd_h256_bf16(const void* G, const void* Csave, int c_bf16, const void* WhhT16, const void* dY, int dy_bf16,
+                          void* dP, float* dbias, float* dbias2, int T, int Bp, int D, hipStream_t s) {
+#define LOB_BWD(CE, DE) hipLaunchKernelGGL((lstm_rec_bwd_h256_bf16_kernel<CE, DE>), dim3(Bp / 32, D), dim3(512), 0, s,      \
+                       reinterpret_cast<const __bf16*>(G), reinterpret_cast<const CE*>(Csave),                               \
+                       reinterpret_cast<const __bf16*>(WhhT16), reinterpret_cast<const DE*>(dY),                            \
+                       reinterpret_cast<__bf16*>(dP), dbias, dbias2, T, Bp)
+    if (c_bf16) { if (dy_bf16) LOB_BWD(__bf16, __bf16); else LOB_BWD(__bf16, float); }
+    else        { if (dy_bf16) LOB_BWD(float, __bf16);  else LOB_BWD(float, float); }
+#undef LOB_BWD
     LOB_CHECK_LAUNCH();
     return 0;
 }

@@ -798,8 +798,8 @@ extern "C" int lob_layernorm_act_bwd_f32(const float* x, const float* gamma, con
     if (remap_T > 0 && (remap_B <= 0 || remap_Bp < remap_B || rows != remap_T * remap_B)) return LOB_E_SHAPE;
     int blocks = (rows + 3) / 4;
     if (dy16 || dx16) {
-        // bf16 gradient streams: the two shapes of the mixed path (post-LSTM LayerNorm, width 256: dx bf16, dy fp32 or
-        // bf16; input-projection LayerNorm, width 128: dy bf16, dx fp32), vectorised kernels only
+        // bf16 gradient streams: the shapes of the mixed path (post-LSTM LayerNorm, width 256 / 512 at H = 128 / 256: dx bf16,
+        // dy fp32 or bf16; input-projection LayerNorm, width 128 / 256: dy bf16, dx fp32), vectorised kernels only
         const bool al16b = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx) |
                              reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) == 0;
         if (!al16b) return LOB_E_ALIGN;
@@ -825,6 +825,11 @@ extern "C" int lob_layernorm_act_bwd_f32(const float* x, const float* gamma, con
             if (dy16 && dx16)       LOB_LNB_T(8, 16, __bf16, __bf16, dyb, dxb);
             else if (dx16)          LOB_LNB_T(8, 16, float, __bf16, dy, dxb);
             else                    LOB_LNB_T(8, 16, __bf16, float, dyb, dx);
+        } else if (width == 512) {       // post-LSTM LayerNorm at H = 256
+            if (blocks > 256 * 8) blocks = 256 * 8;
+            if (dy16 && dx16)       LOB_LNB_T(8, 64, __bf16, __bf16, dyb, dxb);
+            else if (dx16)          LOB_LNB_T(8, 64, float, __bf16, dy, dxb);
+            else                    LOB_LNB_T(8, 64, __bf16, float, dyb, dx);
         } else {
             return LOB_E_SHAPE;
         }

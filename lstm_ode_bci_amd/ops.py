@@ -25,14 +25,20 @@ DY_BF16_CARRY = True
 C_BF16 = True
 
 
+def _rec16(H):
+    """Hidden sizes whose bf16 recurrent kernels take bf16 cell states / a bf16 dY: the 16-row H == 128 kernels and the
+    H == 256 kernels."""
+    return (H == 128 and _lib.get_variant("REC_BF16_ROWS") != 32) or H == 256
+
+
 def c_bf16_ok(H, mixed, p16):
-    """bf16 storage of the saved cell states: the 16-row H == 128 bf16 kernels with bf16 saved gates."""
-    return bool(mixed) and C_BF16 and bool(p16) and H == 128 and _lib.get_variant("REC_BF16_ROWS") != 32
+    """bf16 storage of the saved cell states (with bf16 saved gates)."""
+    return bool(mixed) and C_BF16 and bool(p16) and _rec16(H)
 
 
 def dy_bf16_ok(H, mixed):
-    """The 16-row bf16 BPTT kernels (H == 128) read a bf16 dY."""
-    return bool(mixed) and DY_BF16_CARRY and PG_BF16 and H == 128 and _lib.get_variant("REC_BF16_ROWS") != 32
+    """The bf16 BPTT kernels read a bf16 dY."""
+    return bool(mixed) and DY_BF16_CARRY and PG_BF16 and _rec16(H)
 
 
 def _stream():
@@ -384,8 +390,8 @@ def lstm_rec_bwd(G, Cs, whh, dY, T, Bp, H, D, dp_bf16=False, dbias=None, dbias2=
     _chk(G, "G", G.dtype if g16 else torch.float32); _chk(Cs, "Csave", torch.bfloat16 if c16 else torch.float32)
     _chk(whh, "whh"); _chk(dY, "dY", torch.bfloat16 if dy16 else torch.float32)
     assert dY.shape == (T * Bp, D * H) and (not g16 or (dp_bf16 and bf16_rec(H, g16)))
-    if (dy16 or c16) and not (dp_bf16 and bf16_rec(H, g16) and H == 128):
-        raise _lib.LobError("lstm_rec_bwd: bf16 dY / cell states are read by the H = 128 bf16 BPTT kernels only")
+    if (dy16 or c16) and not (dp_bf16 and bf16_rec(H, g16) and _rec16(H)):
+        raise _lib.LobError("lstm_rec_bwd: bf16 dY / cell states are read by the bf16 BPTT kernels (H = 128 / 256) only")
     dP = torch.empty((T * Bp, D * 4 * H), device=G.device, dtype=torch.bfloat16 if dp_bf16 else torch.float32)
     fused_bias = uses_frag(H)
     if dbias is None:

@@ -238,8 +238,9 @@ def test_h256_full_size_kernels_vs_twins(dev):
     NBT = Bp // 32
     Gr = (G.view(D, T, NBT, 8, 4, 2, 2, 32, 2, 4)             # d t bt w g pq hi c ehi elo (include/lob.h, H = 256)
           .permute(1, 2, 5, 8, 6, 9, 0, 4, 3, 7).reshape(T, Bp, D, 4, H))   # row = 16 pq + 8 ehi + 4 hi + elo, unit = 32 w + c
-    Cr = (Cs.view(D, T, NBT, 8, 4, 2, 32, 4)                  # d t bt w q hi c e
-          .permute(1, 2, 4, 5, 7, 0, 3, 6).reshape(T, Bp, D, H))           # row = 8 q + 4 hi + e
+    assert Cs.dtype == torch.bfloat16          # default: bf16 saved cell states, in the element order of one saved gate
+    Cr = (Cs.view(D, T, NBT, 8, 2, 2, 32, 2, 4)               # d t bt w pq hi c ehi elo
+          .permute(1, 2, 4, 7, 5, 8, 0, 3, 6).reshape(T, Bp, D, H))
     dPr = dP1.view(T, Bp, D, 4, H)
     for d in range(D):
         w64 = whh[d].to(torch.bfloat16).double()                           # (4H, H)
@@ -260,6 +261,22 @@ def test_h256_full_size_kernels_vs_twins(dev):
             scale = dg4.abs().max().item()
             assert (got - dg4).abs().max().item() <= 1e-2 * scale, (d, t)
             dhrec = dg4.to(torch.bfloat16).double().reshape(16, 4 * H) @ w64
+    # storage types: a bf16 dY carries the same values as its widened copy -> bit-identical dP; fp32 cell states give
+    # the same forward and a dP that differs by the rounding of c only
+    dY16 = dY.to(torch.bfloat16)
+    dPa, _ = ops.lstm_rec_bwd(G, Cs, whh, dY16, T, Bp, H, D, dp_bf16=True)
+    dPb, _ = ops.lstm_rec_bwd(G, Cs, whh, dY16.float(), T, Bp, H, D, dp_bf16=True)
+    assert torch.equal(dPa, dPb)
+    ops.C_BF16 = False
+    try:
+        G32 = P.clone()
+        Y_b, Cs32, Y16_b, _ = ops.lstm_rec_fwd(G32, whh, T, Bp, H, D, True, mixed=True, want_f32=True, want_bf16=True)
+    finally:
+        ops.C_BF16 = True
+    assert Cs32.dtype == torch.float32 and torch.equal(G32, G) and torch.equal(Y16_b, Y16) and torch.equal(Y_b, Y)
+    dPc, _ = ops.lstm_rec_bwd(G, Cs32, whh, dY, T, Bp, H, D, dp_bf16=True)
+    ref = dPc.float()
+    assert (dP1.float() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
 
 
 def test_full_size_mixed_fwd_bwd_properties(dev):
