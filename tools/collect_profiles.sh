@@ -26,5 +26,13 @@ timeout -k 10 400 python3 bench.py --steps 10 --warmup 3 > $O/b_default.json 2> 
 timeout -k 10 200 python3 bench.py --steps 10 --warmup 3 --batch 1024 --no-cpu-baseline --mode train > $O/b_train_b1024.json 2> /dev/null
 timeout -k 10 200 python3 bench.py --steps 6 --warmup 2 --batch 8192 --no-cpu-baseline --mode train > $O/b_train_b8192.json 2> /dev/null
 timeout -k 10 200 python3 bench.py --steps 6 --warmup 2 --mode train --precision fp32 --no-cpu-baseline > $O/b_train_fp32.json 2> /dev/null
+timeout -k 10 200 python3 bench.py --steps 10 --warmup 3 --mode fwd --precision fp32 --no-extra --no-cpu-baseline > $O/b_fwd_fp32.json 2> /dev/null
+timeout -k 10 200 python3 bench.py --steps 10 --warmup 3 --mode fwd --precision mixed --no-extra --no-cpu-baseline > $O/b_fwd_mixed.json 2> /dev/null
+timeout -k 10 200 python3 bench.py --steps 10 --warmup 3 --mode coupled --precision fp32 --no-extra --no-cpu-baseline > $O/b_coupled_fp32.json 2> /dev/null
+timeout -k 10 200 python3 bench.py --steps 6 --warmup 2 --hidden 256 --no-extra --no-cpu-baseline > $O/b_train_h256.json 2> /dev/null
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_h256 -o run -- python3 $R/bench.py --hidden 256 --steps 5 --warmup 2 $B > $O/stats_h256.log 2>&1
+find $O/stats_h256 -name "*kernel_trace.csv" -delete
+cd $R
 python3 tools/latency_probe.py > $O/latency_probe.txt 2>&1
 echo done > $O/done.txt
