@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_h128_bf16_kernel(
             const float fg = fast_sigmoid(acc[1][r]);
             const float gg = fast_tanh(acc[2][r]);
             const float og = fast_sigmoid(acc[3][r]);
-            c[r] = fg * c[r] + ig * gg;
+            c[r] = __builtin_fmaf(fg, c[r], ig * gg);
             const float h = og * fast_tanh(c[r]);
             const int row = (r & 3) + 8 * (r >> 2);
             hnext[row * HB_LD] = (__bf16)h;

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_fwd_h128_bf16_s16_kernel(
                 const float fg = fast_sigmoid(acc[1][cbu][j]);
                 const float gg = fast_tanh(acc[2][cbu][j]);
                 const float og = fast_sigmoid(acc[3][cbu][j]);
-                c[cbu][j] = fg * c[cbu][j] + ig * gg;
+                c[cbu][j] = __builtin_fmaf(fg, c[cbu][j], ig * gg);
                 const float h = og * fast_tanh(c[cbu][j]);
                 hnext[j * HB_LD + 16 * cbu] = (__bf16)h;
                 if (YF32) ynext[j * YF_LD + 16 * cbu] = h;

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_h128_kernel(
             const float fg = fast_sigmoid(acc[1][r]);
             const float gg = fast_tanh(acc[2][r]);
             const float og = fast_sigmoid(acc[3][r]);
-            c[r] = fg * c[r] + ig * gg;
+            c[r] = __builtin_fmaf(fg, c[r], ig * gg);
             const float h = og * fast_tanh(c[r]);
             const int row = (r & 3) + 8 * (r >> 2);          // + 4*hi folded into the lane offsets
             hnext[row * HS_LD] = h;
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_generic_kernel(
             }
             const float ig = fast_sigmoid(z[0]), fg = fast_sigmoid(z[1]);
             const float gg = fast_tanh(z[2]), og = fast_sigmoid(z[3]);
-            const float cn = fg * cst[idx] + ig * gg;
+            const float cn = __builtin_fmaf(fg, cst[idx], ig * gg);
             const float h = og * fast_tanh(cn);
             cst[idx] = cn;
             hnew[idx] = h;

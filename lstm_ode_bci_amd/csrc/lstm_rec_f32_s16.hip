@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_h128_s16_kernel(
                 const float fg = fast_sigmoid(acc[1][cbu][j]);
                 const float gg = fast_tanh(acc[2][cbu][j]);
                 const float og = fast_sigmoid(acc[3][cbu][j]);
-                c[s][cbu][j] = fg * c[s][cbu][j] + ig * gg;
+                c[s][cbu][j] = __builtin_fmaf(fg, c[s][cbu][j], ig * gg);
                 const float h = og * fast_tanh(c[s][cbu][j]);
                 hsub_next[(4 * rq + j) * HLD + 32 * w + 16 * cbu + c16] = h;
                 (yrow + (size_t)j * DH + 16 * cbu)[y_off] = h;

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h128_split_kernel(
             const float zg = pz[2][j] + (ahh[2][j] * R_HH + asm_[2][j] * R_SM);
             const float zo = pz[3][j] + (ahh[3][j] * R_HH + asm_[3][j] * R_SM);
             const float ig = fast_sigmoid(zi), fg = fast_sigmoid(zf), gg = fast_tanh(zg), og = fast_sigmoid(zo);
-            c[j] = fg * c[j] + ig * gg;
+            c[j] = __builtin_fmaf(fg, c[j], ig * gg);
             const float h = og * fast_tanh(c[j]);
             _Float16 hh, hl;
             split2(h, hh, hl);

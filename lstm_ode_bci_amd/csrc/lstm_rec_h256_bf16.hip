@@ -37,11 +37,17 @@ __device__ __forceinline__ void load_raw(const __bf16* p, unsigned off8, Raw& r)
 // CE: storage type of the saved cell states (fp32 [q 4][lane 64][4], or bf16 in the element order of one saved gate,
 // [q pair 2][lane 64][8]: ops.C_BF16, as in the H = 128 kernels -- BPTT only uses c_t inside tanh and as a factor next
 // to bf16 gate values; the state carried through time stays fp32 in registers)
-template <bool SAVE, bool YF32, bool Y16, bool DROP, typename CE = float>
+// NQL: how many of the 16 k-step groups of a wave's W_hh fragments stay in LDS for the whole launch (a wave's
+// private 4 KB per group): the free LDS next to the h tiles holds 3 of them (96 KB), i.e. 3/16 of the per-step weight
+// stream never leaves the CU again.  The other groups are streamed as before, three ahead; with 13 streamed groups
+// the cyclic order needs a FIFTH ring buffer (positions 0..11 use buffer pos % 4, position 12 buffer 4: any four
+// consecutive positions of ..., 11, 12, 0, 1, ... then sit in different buffers).  Same MFMAs in the same order.
+template <bool SAVE, bool YF32, bool Y16, bool DROP, typename CE = float, int NQL = 0>
 __global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h256_bf16_kernel(
     __bf16* __restrict__ P, const __bf16* __restrict__ Wb, float* __restrict__ Y, CE* __restrict__ Csave,
     __bf16* __restrict__ Y16p, __bf16* __restrict__ Yd, float drop_p, uint64_t seed, int T, int Bp) {
     __shared__ __attribute__((aligned(16))) __bf16 hs[2 * 32 * HB_LD];
+    __shared__ __attribute__((aligned(16))) __bf16 wl[NQL > 0 ? NW * NQL * 4 * 512 : 8];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bt = blockIdx.x, d = blockIdx.y, D = gridDim.y, NBT = gridDim.x;
@@ -71,15 +77,26 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h256_bf16_kernel(
     // W stream: group q = k-step q x 4 gates = 4 fragments; buffer q & 3; THREE groups in flight ahead of the one
     // being consumed (cyclic: the weights are the same every step, so the tail of a step prefetches the head of the
     // next).  The stream is latency-bound: what counts is bytes in flight per CU (12 KB per wave here).
-    bf16x8 wb[4][4];
+    constexpr int NSQ = 16 - NQL;                      // streamed groups per step
+    constexpr int NRB = (NSQ % 4 == 0) ? 4 : 5;        // ring buffers (see above)
+    static_assert(NSQ % 4 == 0 || NSQ % 4 == 1, "ring assignment: pos % 4, last position in a fifth buffer");
+    bf16x8 wb[NRB][4];
     auto load_w = [&](int q, bf16x8 (&dst)[4]) {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             dst[g] = *reinterpret_cast<const bf16x8*>((wwave + (q * 4 + g) * 512) + w_off);
     };
-    load_w(0, wb[0]);
-    load_w(1, wb[1]);
-    load_w(2, wb[2]);
+    // streamed position p (0 .. NSQ-1) = group NQL + p, ring buffer rb(p)
+    auto rb = [](int p) { return (NSQ % 4 == 1 && p == NSQ - 1) ? 4 : (p & 3); };
+    __bf16* wlw = wl + (size_t)w * (NQL * 4 * 512) + lane * 8;      // this wave's stationary fragments
+    if constexpr (NQL > 0) {
+#pragma unroll
+        for (int f = 0; f < NQL * 4; ++f)
+            *reinterpret_cast<bf16x8*>(wlw + f * 512) = *reinterpret_cast<const bf16x8*>((wwave + f * 512) + w_off);
+    }
+    load_w(NQL + 0, wb[rb(0)]);
+    load_w(NQL + 1, wb[rb(1)]);
+    load_w(NQL + 2, wb[rb(2)]);
     __syncthreads();
 
     int cur = 0;
@@ -99,11 +116,19 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h256_bf16_kernel(
         asm volatile("" : "+v"(w_off));
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            load_w((q + 3) & 15, wb[(q + 3) & 3]);
+            if (q < NQL) {                              // stationary group: B fragments from this wave's LDS block
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(hrow + 16 * q);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    acc[g] = mfma_bf16(a, *reinterpret_cast<const bf16x8*>(wlw + (q * 4 + g) * 512), acc[g]);
+                continue;
+            }
+            const int p = q - NQL, pn = (p + 3) % NSQ;  // three streamed groups ahead, cyclic over the steps
+            load_w(NQL + pn, wb[rb(pn)]);
             __builtin_amdgcn_sched_barrier(0);          // pin the order: issue the prefetch, then consume group q
             const bf16x8 a = *reinterpret_cast<const bf16x8*>(hrow + 16 * q);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g] = mfma_bf16(a, wb[q & 3][g], acc[g]);
+            for (int g = 0; g < 4; ++g) acc[g] = mfma_bf16(a, wb[rb(p)][g], acc[g]);
             __builtin_amdgcn_sched_barrier(0);
         }
         __bf16* hnext = hs + (cur ^ 1) * 32 * HB_LD + 32 * w + l31 + 4 * hi * HB_LD;
@@ -114,7 +139,7 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h256_bf16_kernel(
             const float fg = fast_sigmoid(acc[1][r]);
             const float gg = fast_tanh(acc[2][r]);
             const float og = fast_sigmoid(acc[3][r]);
-            c[r] = fg * c[r] + ig * gg;
+            c[r] = __builtin_fmaf(fg, c[r], ig * gg);
             const float h = og * fast_tanh(c[r]);
             const int row = (r & 3) + 8 * (r >> 2);
             hnext[row * HB_LD] = (__bf16)h;
@@ -182,11 +207,15 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h256_bf16_kernel(
 // ------------------------------------------------------------------------------------------
 // CE / DE: storage types of the saved cell states and of the incoming gradient dY (fp32, or bf16: ops.C_BF16 /
 // ops.DY_BF16_CARRY -- the gradient carried from layer to layer is a bf16 stream like dP)
-template <typename CE, typename DE>
+// NGL: how many of the 16 groups (of four k-steps) of a wave's W_hh^T fragments stay in LDS for the whole launch: 2
+// (64 KB next to the 66-KB dgates tile), 1/8 of the per-step weight stream; the other 14 are streamed one group ahead.
+template <typename CE, typename DE, int NGL = 0>
 __global__ __launch_bounds__(512, 2) void lstm_rec_bwd_h256_bf16_kernel(
     const __bf16* __restrict__ G, const CE* __restrict__ Csave, const __bf16* __restrict__ WTb,
     const DE* __restrict__ dY, __bf16* __restrict__ dP, float* __restrict__ dbias, float* __restrict__ dbias2, int T, int Bp) {
     __shared__ __attribute__((aligned(16))) __bf16 dgs[32 * DGB_LD];
+    __shared__ __attribute__((aligned(16))) __bf16 wl[NGL > 0 ? NW * NGL * 4 * 512 : 8];
+    static_assert(((16 - NGL) & 1) == 0, "two ring buffers: an even number of streamed groups");
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bt = blockIdx.x, d = blockIdx.y, D = gridDim.y, NBT = gridDim.x;
@@ -246,9 +275,15 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_bwd_h256_bf16_kernel(
 #pragma unroll
         for (int j = 0; j < 4; ++j) dst[j] = *reinterpret_cast<const bf16x8*>((wtwave + (4 * q + j) * 512) + wt_off);
     };
+    __bf16* wlw = wl + (size_t)w * (NGL * 4 * 512) + lane * 8;      // this wave's stationary fragments
+    if constexpr (NGL > 0) {
+#pragma unroll
+        for (int f = 0; f < NGL * 4; ++f)
+            *reinterpret_cast<bf16x8*>(wlw + f * 512) = *reinterpret_cast<const bf16x8*>((wtwave + f * 512) + wt_off);
+    }
     load_c(t_first, ct);
     load_step(t_first);
-    load_w(0, wb[0]);
+    load_w(NGL, wb[NGL & 1]);
 
     for (int step = 0; step < T; ++step) {
         const int t = t_first + dt * step;
@@ -277,7 +312,15 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_bwd_h256_bf16_kernel(
         asm volatile("" : "+v"(wt_off));           // see the forward kernel: keeps the W stream inside the time loop
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            load_w((q + 1) & 15, wb[(q + 1) & 1]);
+            if (q < NGL) {                              // stationary group: B fragments from this wave's LDS block
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    dhrec = mfma_bf16(*reinterpret_cast<const bf16x8*>(arow + 16 * (4 * q + j)),
+                                      *reinterpret_cast<const bf16x8*>(wlw + (4 * q + j) * 512), dhrec);
+                continue;
+            }
+            const int qn = q + 1 < 16 ? q + 1 : NGL;    // next streamed group (cyclic over the steps)
+            load_w(qn, wb[qn & 1]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -316,8 +359,14 @@ int lob_rec_fwd_h256_bf16(void* P, const void* Whh16, float* Y, void* Csave, int
     __bf16* y16 = reinterpret_cast<__bf16*>(Y16);
     __bf16* yd = reinterpret_cast<__bf16*>(Yd);
     if (c_bf16 && !save) return LOB_E_SHAPE;
-#define LOB_FWD(SV, YF, Y6, DR, CE) hipLaunchKernelGGL((lstm_rec_fwd_h256_bf16_kernel<SV, YF, Y6, DR, CE>), grid, block, 0, s, \
-        reinterpret_cast<__bf16*>(P), reinterpret_cast<const __bf16*>(Whh16), Y, reinterpret_cast<CE*>(Csave), y16, yd, drop_p, seed, T, Bp)
+    const bool ldsw = lob_variant(LOB_VAR_H256_LDSW) != 0;      // 0: every weight fragment streamed (the twin)
+#define LOB_FWD(SV, YF, Y6, DR, CE) do {                                                                                      \
+        if (ldsw) hipLaunchKernelGGL((lstm_rec_fwd_h256_bf16_kernel<SV, YF, Y6, DR, CE, 3>), grid, block, 0, s,              \
+            reinterpret_cast<__bf16*>(P), reinterpret_cast<const __bf16*>(Whh16), Y, reinterpret_cast<CE*>(Csave), y16, yd,  \
+            drop_p, seed, T, Bp);                                                                                            \
+        else hipLaunchKernelGGL((lstm_rec_fwd_h256_bf16_kernel<SV, YF, Y6, DR, CE, 0>), grid, block, 0, s,                   \
+            reinterpret_cast<__bf16*>(P), reinterpret_cast<const __bf16*>(Whh16), Y, reinterpret_cast<CE*>(Csave), y16, yd,  \
+            drop_p, seed, T, Bp); } while (0)
 #define LOB_FWD_OUT(SV, CE) do {                                                     \
         if (Y && !y16 && !yd) LOB_FWD(SV, true, false, false, CE);                   \
         else if (Y && y16 && !yd) LOB_FWD(SV, true, true, false, CE);                \
@@ -334,10 +383,16 @@ int lob_rec_fwd_h256_bf16(void* P, const void* Whh16, float* Y, void* Csave, int
 
 int lob_rec_bwd_h256_bf16(const void* G, const void* Csave, int c_bf16, const void* WhhT16, const void* dY, int dy_bf16,
                           void* dP, float* dbias, float* dbias2, int T, int Bp, int D, hipStream_t s) {
-#define LOB_BWD(CE, DE) hipLaunchKernelGGL((lstm_rec_bwd_h256_bf16_kernel<CE, DE>), dim3(Bp / 32, D), dim3(512), 0, s,      \
+    const bool ldsw = lob_variant(LOB_VAR_H256_LDSW) != 0;      // 0: every weight fragment streamed (the twin)
+#define LOB_BWD(CE, DE) do {                                                                                                \
+        if (ldsw) hipLaunchKernelGGL((lstm_rec_bwd_h256_bf16_kernel<CE, DE, 2>), dim3(Bp / 32, D), dim3(512), 0, s,        \
                        reinterpret_cast<const __bf16*>(G), reinterpret_cast<const CE*>(Csave),                               \
                        reinterpret_cast<const __bf16*>(WhhT16), reinterpret_cast<const DE*>(dY),                            \
-                       reinterpret_cast<__bf16*>(dP), dbias, dbias2, T, Bp)
+                       reinterpret_cast<__bf16*>(dP), dbias, dbias2, T, Bp);                                                 \
+        else hipLaunchKernelGGL((lstm_rec_bwd_h256_bf16_kernel<CE, DE, 0>), dim3(Bp / 32, D), dim3(512), 0, s,              \
+                       reinterpret_cast<const __bf16*>(G), reinterpret_cast<const CE*>(Csave),                               \
+                       reinterpret_cast<const __bf16*>(WhhT16), reinterpret_cast<const DE*>(dY),                            \
+                       reinterpret_cast<__bf16*>(dP), dbias, dbias2, T, Bp); } while (0)
     if (c_bf16) { if (dy_bf16) LOB_BWD(__bf16, __bf16); else LOB_BWD(__bf16, float); }
     else        { if (dy_bf16) LOB_BWD(float, __bf16);  else LOB_BWD(float, float); }
 #undef LOB_BWD

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(HH * 2, (HH > 128) ? 2 : 1) void lstm_rec_fwd_strea
             const float fg = fast_sigmoid(acc[1][r]);
             const float gg = fast_tanh(acc[2][r]);
             const float og = fast_sigmoid(acc[3][r]);
-            c[r] = fg * c[r] + ig * gg;
+            c[r] = __builtin_fmaf(fg, c[r], ig * gg);
             const float h = og * fast_tanh(c[r]);
             const int row = (r & 3) + 8 * (r >> 2);
             hnext[row * HLD] = h;

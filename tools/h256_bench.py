@@ -54,3 +54,12 @@ Y, Cs, Y16, _ = ops.lstm_rec_fwd(G.copy_(P), whh, T, Bp, H, D, True, mixed=True,
 dY = rnd((rows, D * H), 1e-3)
 ms = timeit(lambda: ops.lstm_rec_bwd(G, Cs, whh, dY, T, Bp, H, D, dp_bf16=True))
 report("rec BPTT", ms, 2.0 * rows * D * 4 * H * H, rows * D * (4 * H * 2 * 2 + H * 4 + H * 4))
+
+# LDS-resident weight fragments (LOB_VAR_H256_LDSW) against every fragment streamed
+for v in (1, 0):
+    with _lib.variant(H256_LDSW=v):
+        ms_f = timeit(lambda: ops.lstm_rec_fwd(G.copy_(P), whh, T, Bp, H, D, True, mixed=True, want_f32=False, want_bf16=True)) - timeit(lambda: G.copy_(P))
+        ms_i = timeit(lambda: ops.lstm_rec_fwd(P, whh, T, Bp, H, D, False, mixed=True, want_f32=False, want_bf16=True))
+        Y, Cs, Y16, _ = ops.lstm_rec_fwd(G.copy_(P), whh, T, Bp, H, D, True, mixed=True, want_f32=False, want_bf16=True)
+        ms_b = timeit(lambda: ops.lstm_rec_bwd(G, Cs, whh, dY.to(torch.bfloat16), T, Bp, H, D, dp_bf16=True))
+    print(f"H256_LDSW={v}: rec fwd save {ms_f:.3f} ms, inference {ms_i:.3f} ms, BPTT (bf16 dY) {ms_b:.3f} ms", flush=True)
