@@ -77,7 +77,7 @@ const char* lob_build_id(void);
 #define LOB_VAR_FUSED_DW     13  /* read by the Python host: 1 = dW_ih and dW_hh from one pass (lob_lstm_dw_bf16)  */
 #define LOB_VAR_F32_SPLIT    14  /* 1: fp32 gate GEMMs as three-way bf16 splits on bf16 MFMA; 0: exact-fp32 MFMA   */
 #define LOB_VAR_REC_F32_HALF 15  /* 1: fp32 recurrent forward may split the gate columns over two workgroups       */
-#define LOB_VAR_H256_LDSW    16  /* H=256 recurrent kernels: 1 = part of a wave's W_hh fragments stays in LDS; 0 = all streamed   */
+#define LOB_VAR_H256_LDSW    16  /* H=256 recurrent kernels: 0 = all W_hh fragments streamed; 1 = part of them resident in LDS      */
 #define LOB_VAR_DX_KSPLIT    17  /* 1: dX = dP W_ih on the k-split weight-stationary kernel; 0: tiled LDS-DMA NT GEMM          */
 #define LOB_VAR_REC_FEW      18  /* 1: mixed inference forward with fewer than 4 windows skips the padding registers' cell update */
 #define LOB_VAR_COUNT        19

@@ -12,6 +12,7 @@
 // gradient carries, the bf16 dgates tile that is both MFMA operand and dP image, fused dropout copy -- is as in
 // lstm_rec_bf16.hip.
 #include "lob_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -207,15 +208,18 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h256_bf16_kernel(
 // ------------------------------------------------------------------------------------------
 // CE / DE: storage types of the saved cell states and of the incoming gradient dY (fp32, or bf16: ops.C_BF16 /
 // ops.DY_BF16_CARRY -- the gradient carried from layer to layer is a bf16 stream like dP)
-// NGL: how many of the 16 groups (of four k-steps) of a wave's W_hh^T fragments stay in LDS for the whole launch: 2
-// (64 KB next to the 66-KB dgates tile), 1/8 of the per-step weight stream; the other 14 are streamed one group ahead.
-template <typename CE, typename DE, int NGL = 0>
+// NGL: how many of the 16 groups (of four k-steps) of a wave's W_hh^T fragments stay in LDS for the whole launch (a
+// wave's private 4 KB per group; up to 2 fit next to the 66-KB dgates tile).  NAH: how many streamed groups are in
+// flight ahead of the one being consumed (ring of NAH + 1 register buffers; the streamed-group count must be a multiple
+// of it so that the cyclic order over the steps keeps one buffer per position).
+template <typename CE, typename DE, int NGL = 0, int NAH = 1>
 __global__ __launch_bounds__(512, 2) void lstm_rec_bwd_h256_bf16_kernel(
     const __bf16* __restrict__ G, const CE* __restrict__ Csave, const __bf16* __restrict__ WTb,
     const DE* __restrict__ dY, __bf16* __restrict__ dP, float* __restrict__ dbias, float* __restrict__ dbias2, int T, int Bp) {
     __shared__ __attribute__((aligned(16))) __bf16 dgs[32 * DGB_LD];
     __shared__ __attribute__((aligned(16))) __bf16 wl[NGL > 0 ? NW * NGL * 4 * 512 : 8];
-    static_assert(((16 - NGL) & 1) == 0, "two ring buffers: an even number of streamed groups");
+    constexpr int NSG = 16 - NGL, NRB = NAH + 1;       // streamed groups per step, ring buffers
+    static_assert(NSG % NRB == 0, "ring: the streamed-group count must be a multiple of the buffer count");
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bt = blockIdx.x, d = blockIdx.y, D = gridDim.y, NBT = gridDim.x;
@@ -233,13 +237,22 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_bwd_h256_bf16_kernel(
     unsigned wt_off = (unsigned)(lane * 8);
 
     const int t_first = d ? 0 : T - 1, dt = d ? 1 : -1;
-    f32x16 ct, cp, dhrec;
+    // cell states of this step / of the step before it in the direction's time: kept as loaded (bf16: 8 registers each
+    // instead of 16) and widened where the cell update reads them -- the MFMA phase needs every register it can get
+    struct CRaw16 { bf16x8 v[2]; };
+    typedef typename std::conditional<sizeof(CE) == 2, CRaw16, f32x16>::type CS;
+    CS ct, cp;
+    auto cval = [](const CS& cs, int r) -> float {
+        if constexpr (sizeof(CE) == 2) return (float)cs.v[r >> 3][r & 7];
+        else return cs[r];
+    };
+    f32x16 dhrec;
     float dy[16], dcarry[16];
     float dbsum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dcarry[r] = 0.f; dhrec[r] = 0.f; }
 
-    auto load_c = [&](int t, f32x16& dst) {
+    auto load_c = [&](int t, CS& dst) {
         if (t >= 0 && t < T) {
             const CE* cq = cwave + (size_t)t * cstep;
             if constexpr (sizeof(CE) == 4) {
@@ -250,15 +263,18 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_bwd_h256_bf16_kernel(
                 }
             } else {
 #pragma unroll
-                for (int pq = 0; pq < 2; ++pq) {
-                    const bf16x8 v = *reinterpret_cast<const bf16x8*>((cq + pq * 512) + off8);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) dst[8 * pq + e] = (float)v[e];
-                }
+                for (int pq = 0; pq < 2; ++pq) dst.v[pq] = *reinterpret_cast<const bf16x8*>((cq + pq * 512) + off8);
             }
         } else {
+            if constexpr (sizeof(CE) == 4) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dst[r] = 0.f;
+                for (int r = 0; r < 16; ++r) dst[r] = 0.f;
+            } else {
+#pragma unroll
+                for (int pq = 0; pq < 2; ++pq)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) dst.v[pq][e] = (__bf16)0.f;
+            }
         }
     };
     Raw graw;
@@ -269,8 +285,8 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_bwd_h256_bf16_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) dy[r] = (float)(dp + ((r & 3) + 8 * (r >> 2)) * DH)[dy_off];
     };
-    bf16x8 wb[2][4];              // group q = k-steps 4q .. 4q+3 (64 k-steps of 16 gate rows in 16 groups), one group ahead
-                                  // (three ahead as in the forward kernel spills here: 4.7 ms; this is HBM-bound anyway)
+    bf16x8 wb[NRB][4];            // group q = k-steps 4q .. 4q+3 (64 k-steps of 16 gate rows in 16 groups); streamed position
+                                  // p = q - NGL lives in buffer p % NRB
     auto load_w = [&](int q, bf16x8 (&dst)[4]) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) dst[j] = *reinterpret_cast<const bf16x8*>((wtwave + (4 * q + j) * 512) + wt_off);
@@ -283,7 +299,8 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_bwd_h256_bf16_kernel(
     }
     load_c(t_first, ct);
     load_step(t_first);
-    load_w(NGL, wb[NGL & 1]);
+#pragma unroll
+    for (int a = 0; a < NAH; ++a) load_w(NGL + a, wb[a % NRB]);
 
     for (int step = 0; step < T; ++step) {
         const int t = t_first + dt * step;
@@ -294,11 +311,11 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_bwd_h256_bf16_kernel(
             const float ig = (float)graw.v[0 + g8][e8], fg = (float)graw.v[2 + g8][e8];
             const float gg = (float)graw.v[4 + g8][e8], og = (float)graw.v[6 + g8][e8];
             const float dh = dy[r] + dhrec[r];
-            const float tc = fast_tanh(ct[r]);
+            const float tc = fast_tanh(cval(ct, r));
             const float dc = dcarry[r] + dh * og * (1.f - tc * tc);
             dcarry[r] = dc * fg;
             __bf16* p = dgw + ((r & 3) + 8 * (r >> 2)) * DGB_LD;
-            const float v0 = dc * gg * ig * (1.f - ig), v1 = dc * cp[r] * fg * (1.f - fg);
+            const float v0 = dc * gg * ig * (1.f - ig), v1 = dc * cval(cp, r) * fg * (1.f - fg);
             const float v2 = dc * ig * (1.f - gg * gg), v3 = dh * tc * og * (1.f - og);
             p[0 * HH] = (__bf16)v0; p[1 * HH] = (__bf16)v1; p[2 * HH] = (__bf16)v2; p[3 * HH] = (__bf16)v3;
             dbsum[0] += v0; dbsum[1] += v1; dbsum[2] += v2; dbsum[3] += v3;
@@ -319,12 +336,12 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_bwd_h256_bf16_kernel(
                                       *reinterpret_cast<const bf16x8*>(wlw + (4 * q + j) * 512), dhrec);
                 continue;
             }
-            const int qn = q + 1 < 16 ? q + 1 : NGL;    // next streamed group (cyclic over the steps)
-            load_w(qn, wb[qn & 1]);
+            const int p = q - NGL, pn = (p + NAH) % NSG;     // NAH streamed groups ahead, cyclic over the steps
+            load_w(NGL + pn, wb[pn % NRB]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                dhrec = mfma_bf16(*reinterpret_cast<const bf16x8*>(arow + 16 * (4 * q + j)), wb[q & 1][j], dhrec);
+                dhrec = mfma_bf16(*reinterpret_cast<const bf16x8*>(arow + 16 * (4 * q + j)), wb[p % NRB][j], dhrec);
             __builtin_amdgcn_sched_barrier(0);
         }
         // ---- the bf16 tile IS the dP image: 32 rows x 2 KB; 128 lanes x 16 B per row, 4 rows per pass
@@ -383,19 +400,19 @@ int lob_rec_fwd_h256_bf16(void* P, const void* Whh16, float* Y, void* Csave, int
 
 int lob_rec_bwd_h256_bf16(const void* G, const void* Csave, int c_bf16, const void* WhhT16, const void* dY, int dy_bf16,
                           void* dP, float* dbias, float* dbias2, int T, int Bp, int D, hipStream_t s) {
-    const bool ldsw = lob_variant(LOB_VAR_H256_LDSW) != 0;      // 0: every weight fragment streamed (the twin)
-#define LOB_BWD(CE, DE) do {                                                                                                \
-        if (ldsw) hipLaunchKernelGGL((lstm_rec_bwd_h256_bf16_kernel<CE, DE, 2>), dim3(Bp / 32, D), dim3(512), 0, s,        \
-                       reinterpret_cast<const __bf16*>(G), reinterpret_cast<const CE*>(Csave),                               \
+    // LOB_VAR_H256_LDSW: 0 = every weight fragment streamed (the twin); 1 = two groups resident in LDS.  One streamed
+    // group ahead in both: a deeper ring (one resident group, two streamed groups ahead: fits without spills once the
+    // cell states are kept as loaded) measured 3.48 ms against 3.38 -- BPTT is not bound by the weights in flight
+    const int mode = lob_variant(LOB_VAR_H256_LDSW);
+#define LOB_BWD_L(CE, DE, NGL, NAH) hipLaunchKernelGGL((lstm_rec_bwd_h256_bf16_kernel<CE, DE, NGL, NAH>), dim3(Bp / 32, D),  \
+                       dim3(512), 0, s, reinterpret_cast<const __bf16*>(G), reinterpret_cast<const CE*>(Csave),              \
                        reinterpret_cast<const __bf16*>(WhhT16), reinterpret_cast<const DE*>(dY),                            \
-                       reinterpret_cast<__bf16*>(dP), dbias, dbias2, T, Bp);                                                 \
-        else hipLaunchKernelGGL((lstm_rec_bwd_h256_bf16_kernel<CE, DE, 0>), dim3(Bp / 32, D), dim3(512), 0, s,              \
-                       reinterpret_cast<const __bf16*>(G), reinterpret_cast<const CE*>(Csave),                               \
-                       reinterpret_cast<const __bf16*>(WhhT16), reinterpret_cast<const DE*>(dY),                            \
-                       reinterpret_cast<__bf16*>(dP), dbias, dbias2, T, Bp); } while (0)
-    if (c_bf16) { if (dy_bf16) LOB_BWD(__bf16, __bf16); else LOB_BWD(__bf16, float); }
-    else        { if (dy_bf16) LOB_BWD(float, __bf16);  else LOB_BWD(float, float); }
+                       reinterpret_cast<__bf16*>(dP), dbias, dbias2, T, Bp)
+#define LOB_BWD(CE, DE, DEEP) do { if (mode == 0) LOB_BWD_L(CE, DE, 0, 1); else LOB_BWD_L(CE, DE, 2, 1); } while (0)
+    if (c_bf16) { if (dy_bf16) LOB_BWD(__bf16, __bf16, true); else LOB_BWD(__bf16, float, true); }
+    else        { if (dy_bf16) LOB_BWD(float, __bf16, false);  else LOB_BWD(float, float, false); }
 #undef LOB_BWD
+#undef LOB_BWD_L
     LOB_CHECK_LAUNCH();
     return 0;
 }

@@ -61,5 +61,6 @@ for v in (1, 0):
         ms_f = timeit(lambda: ops.lstm_rec_fwd(G.copy_(P), whh, T, Bp, H, D, True, mixed=True, want_f32=False, want_bf16=True)) - timeit(lambda: G.copy_(P))
         ms_i = timeit(lambda: ops.lstm_rec_fwd(P, whh, T, Bp, H, D, False, mixed=True, want_f32=False, want_bf16=True))
         Y, Cs, Y16, _ = ops.lstm_rec_fwd(G.copy_(P), whh, T, Bp, H, D, True, mixed=True, want_f32=False, want_bf16=True)
-        ms_b = timeit(lambda: ops.lstm_rec_bwd(G, Cs, whh, dY.to(torch.bfloat16), T, Bp, H, D, dp_bf16=True))
+        dY16 = dY.to(torch.bfloat16)
+        ms_b = timeit(lambda: ops.lstm_rec_bwd(G, Cs, whh, dY16, T, Bp, H, D, dp_bf16=True))
     print(f"H256_LDSW={v}: rec fwd save {ms_f:.3f} ms, inference {ms_i:.3f} ms, BPTT (bf16 dY) {ms_b:.3f} ms", flush=True)
