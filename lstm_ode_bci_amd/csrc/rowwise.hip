@@ -550,20 +550,29 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 
+// F: width factor -- W = 256 F columns of V, W2 = 128 F columns of U (F = 1: H = 128, F = 2: H = 256, both bidirectional):
+// a lane holds 4 F consecutive columns of V and 2 F of U
+template <int F>
 __global__ __launch_bounds__(256) void attn_pool_fwd_vec_kernel(
     const __bf16* __restrict__ V, const float* __restrict__ U, const float* __restrict__ w2,
     const float* __restrict__ b2, float* __restrict__ ctx, float* __restrict__ attn, int T, int Bp) {
-    constexpr int W = 256, W2 = 128;
+    constexpr int W = 256 * F, W2 = 128 * F, NV = 4 * F, NU = 2 * F;
+    typedef __bf16 bvec __attribute__((ext_vector_type(NV)));
     extern __shared__ __attribute__((aligned(16))) float sc[];   // [T] scores -> weights, then [4][W] partial contexts
     __shared__ float red[8];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float bias2 = b2 ? b2[0] : 0.f;
-    const float2 wv = *reinterpret_cast<const float2*>(w2 + 2 * lane);
+    float wv[NU];
+    ldv<NU>(w2 + NU * lane, wv);
     const size_t rs = (size_t)Bp;
 #pragma unroll 4
     for (int t = wave; t < T; t += 4) {
-        const float2 u = *reinterpret_cast<const float2*>(U + ((size_t)t * rs + b) * W2 + 2 * lane);
-        const float s = wave_sum(fmaf(u.x, wv.x, u.y * wv.y));
+        float u[NU];
+        ldv<NU>(U + ((size_t)t * rs + b) * W2 + NU * lane, u);
+        float s = u[0] * wv[0];
+#pragma unroll
+        for (int i = 1; i < NU; ++i) s = fmaf(u[i], wv[i], s);
+        s = wave_sum(s);
         if (lane == 0) sc[t] = s + bias2;
     }
     __syncthreads();
@@ -581,28 +590,34 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_vec_kernel(
     const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
     for (int t = tid; t < T; t += 256) { const float a = sc[t] * inv; sc[t] = a; attn[(size_t)b * T + t] = a; }
     __syncthreads();
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = 0.f;
 #pragma unroll 4
     for (int t = wave; t < T; t += 4) {
-        const bf16x4_t v = *reinterpret_cast<const bf16x4_t*>(V + ((size_t)t * rs + b) * W + 4 * lane);
+        const bvec v = *reinterpret_cast<const bvec*>(V + ((size_t)t * rs + b) * W + NV * lane);
         const float a = sc[t];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = fmaf(a, (float)v[i], acc[i]);
+        for (int i = 0; i < NV; ++i) acc[i] = fmaf(a, (float)v[i], acc[i]);
     }
     float* part = sc + ((T + 3) & ~3);              // [4][W]
 #pragma unroll
-    for (int i = 0; i < 4; ++i) part[wave * W + 4 * lane + i] = acc[i];
+    for (int i = 0; i < NV; ++i) part[wave * W + NV * lane + i] = acc[i];
     __syncthreads();
-    ctx[(size_t)b * W + tid] = part[tid] + part[W + tid] + part[2 * W + tid] + part[3 * W + tid];
+#pragma unroll
+    for (int c = tid; c < W; c += 256) ctx[(size_t)b * W + c] = part[c] + part[W + c] + part[2 * W + c] + part[3 * W + c];
 }
 
 // Backward, fused form (dV is NOT materialised: the a[t] dctx term goes into the LayerNorm backward): writes dPreU
 // (bf16) and accumulates dw2.
+template <int F>
 __global__ __launch_bounds__(256) void attn_pool_bwd_vec_kernel(
     const __bf16* __restrict__ V, const float* __restrict__ U, const float* __restrict__ attn,
     const float* __restrict__ dctx, const float* __restrict__ w2, __bf16* __restrict__ dPreU,
     float* __restrict__ dw2, float* __restrict__ du_colsum, int T, int Bp) {
-    constexpr int W = 256, W2 = 128;
+    constexpr int W = 256 * F, W2 = 128 * F, NV = 4 * F, NU = 2 * F;
+    typedef __bf16 bvec __attribute__((ext_vector_type(NV)));
+    typedef __bf16 buvec __attribute__((ext_vector_type(NU)));
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* a = sm;                         // [T]
     float* ds = sm + T;                    // [T]  (da, then ds)
@@ -611,12 +626,14 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_vec_kernel(
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t rs = (size_t)Bp;
     for (int t = tid; t < T; t += 256) a[t] = attn[(size_t)b * T + t];
-    const f32x4 dc = *reinterpret_cast<const f32x4*>(dctx + (size_t)b * W + 4 * lane);
+    float dc[NV];
+    ldv<NV>(dctx + (size_t)b * W + NV * lane, dc);
 #pragma unroll 4
     for (int t = wave; t < T; t += 4) {
-        const bf16x4_t v = *reinterpret_cast<const bf16x4_t*>(V + ((size_t)t * rs + b) * W + 4 * lane);
+        const bvec v = *reinterpret_cast<const bvec*>(V + ((size_t)t * rs + b) * W + NV * lane);
         float s = dc[0] * (float)v[0];
-        s = fmaf(dc[1], (float)v[1], s); s = fmaf(dc[2], (float)v[2], s); s = fmaf(dc[3], (float)v[3], s);
+#pragma unroll
+        for (int i = 1; i < NV; ++i) s = fmaf(dc[i], (float)v[i], s);
         s = wave_sum(s);
         if (lane == 0) ds[t] = s;
     }
@@ -630,28 +647,34 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_vec_kernel(
     __syncthreads();
     for (int t = tid; t < T; t += 256) ds[t] = a[t] * (ds[t] - dot);
     __syncthreads();
-    const float2 wv = *reinterpret_cast<const float2*>(w2 + 2 * lane);
-    float acc0 = 0.f, acc1 = 0.f, cs0 = 0.f, cs1 = 0.f;
+    float wv[NU], acc[NU], cs[NU];
+    ldv<NU>(w2 + NU * lane, wv);
+#pragma unroll
+    for (int i = 0; i < NU; ++i) { acc[i] = 0.f; cs[i] = 0.f; }
 #pragma unroll 4
     for (int t = wave; t < T; t += 4) {
-        const size_t ro = ((size_t)t * rs + b) * W2 + 2 * lane;
-        const float2 u = *reinterpret_cast<const float2*>(U + ro);
+        const size_t ro = ((size_t)t * rs + b) * W2 + NU * lane;
+        float u[NU];
+        ldv<NU>(U + ro, u);
         const float d = ds[t];
-        acc0 = fmaf(d, u.x, acc0);
-        acc1 = fmaf(d, u.y, acc1);
-        const float o0 = d * wv.x * (1.f - u.x * u.x), o1 = d * wv.y * (1.f - u.y * u.y);
-        cs0 += o0; cs1 += o1;
-        bf16x2_t o = {(__bf16)o0, (__bf16)o1};
-        *reinterpret_cast<bf16x2_t*>(dPreU + ro) = o;
+        buvec o;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            acc[i] = fmaf(d, u[i], acc[i]);
+            const float oi = d * wv[i] * (1.f - u[i] * u[i]);
+            cs[i] += oi;
+            o[i] = (__bf16)oi;
+        }
+        *reinterpret_cast<buvec*>(dPreU + ro) = o;
     }
-    part[wave * W2 + 2 * lane] = acc0;
-    part[wave * W2 + 2 * lane + 1] = acc1;
+#pragma unroll
+    for (int i = 0; i < NU; ++i) part[wave * W2 + NU * lane + i] = acc[i];
     __syncthreads();
     if (tid < W2) atomicAdd(dw2 + tid, part[tid] + part[W2 + tid] + part[2 * W2 + tid] + part[3 * W2 + tid]);
     if (du_colsum) {      // column sums of dPreU = the gradient of the score MLP's first bias (04:118)
         __syncthreads();
-        part[wave * W2 + 2 * lane] = cs0;
-        part[wave * W2 + 2 * lane + 1] = cs1;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) part[wave * W2 + NU * lane + i] = cs[i];
         __syncthreads();
         if (tid < W2) atomicAdd(du_colsum + tid, part[tid] + part[W2 + tid] + part[2 * W2 + tid] + part[3 * W2 + tid]);
     }
@@ -739,10 +762,13 @@ extern "C" int lob_attn_pool_fwd_f32(const void* V, int v_bf16, const float* U, 
     if (U && (!w2 || W2 <= 0)) return LOB_E_ARG;
     if ((size_t)T * sizeof(float) > 60 * 1024) return LOB_E_SHAPE;
     const bool al8 = ((reinterpret_cast<uintptr_t>(V) | reinterpret_cast<uintptr_t>(U) | reinterpret_cast<uintptr_t>(w2)) & 7) == 0;
-    if (v_bf16 && U && W == 256 && W2 == 128 && al8) {
-        const size_t smem = ((size_t)((T + 3) & ~3) + 4 * 256) * sizeof(float);
-        hipLaunchKernelGGL(attn_pool_fwd_vec_kernel, dim3(B), dim3(256), smem, (hipStream_t)stream,
-                           reinterpret_cast<const __bf16*>(V), U, w2, b2, ctx, attn, T, Bp);
+    const bool al16v = ((reinterpret_cast<uintptr_t>(V) | reinterpret_cast<uintptr_t>(U) | reinterpret_cast<uintptr_t>(w2)) & 15) == 0;
+    if (v_bf16 && U && ((W == 256 && W2 == 128 && al8) || (W == 512 && W2 == 256 && al16v))) {
+        const size_t smem = ((size_t)((T + 3) & ~3) + 4 * W) * sizeof(float);
+        if (W == 256) hipLaunchKernelGGL(attn_pool_fwd_vec_kernel<1>, dim3(B), dim3(256), smem, (hipStream_t)stream,
+                                         reinterpret_cast<const __bf16*>(V), U, w2, b2, ctx, attn, T, Bp);
+        else          hipLaunchKernelGGL(attn_pool_fwd_vec_kernel<2>, dim3(B), dim3(256), smem, (hipStream_t)stream,
+                                         reinterpret_cast<const __bf16*>(V), U, w2, b2, ctx, attn, T, Bp);
         LOB_CHECK_LAUNCH();
         return 0;
     }
@@ -873,11 +899,13 @@ extern "C" int lob_attn_pool_bwd_f32(const void* V, int v_bf16, const float* U, 
     if (T <= 0 || B <= 0 || Bp < B || W <= 0) return LOB_E_ARG;
     const size_t smem = ((size_t)2 * T + W) * sizeof(float);
     if (smem > 60 * 1024) return LOB_E_SHAPE;
-    if (v_bf16 && du_bf16 && U && !dV && W == 256 && W2 == 128 &&
+    if (v_bf16 && du_bf16 && U && !dV && ((W == 256 && W2 == 128) || (W == 512 && W2 == 256)) &&
         ((reinterpret_cast<uintptr_t>(V) | reinterpret_cast<uintptr_t>(U) | reinterpret_cast<uintptr_t>(w2) |
-          reinterpret_cast<uintptr_t>(dctx)) & 15) == 0 && (reinterpret_cast<uintptr_t>(dPreU) & 3) == 0) {
-        const size_t sm2 = ((size_t)2 * T + 4 * 128) * sizeof(float);
-        hipLaunchKernelGGL(attn_pool_bwd_vec_kernel, dim3(B), dim3(256), sm2, (hipStream_t)stream,
+          reinterpret_cast<uintptr_t>(dctx)) & 15) == 0 && (reinterpret_cast<uintptr_t>(dPreU) & 7) == 0) {
+        const size_t sm2 = ((size_t)2 * T + 4 * W2) * sizeof(float);
+        if (W == 256) hipLaunchKernelGGL(attn_pool_bwd_vec_kernel<1>, dim3(B), dim3(256), sm2, (hipStream_t)stream,
+                           reinterpret_cast<const __bf16*>(V), U, attn, dctx, w2, reinterpret_cast<__bf16*>(dPreU), dw2, du_colsum, T, Bp);
+        else          hipLaunchKernelGGL(attn_pool_bwd_vec_kernel<2>, dim3(B), dim3(256), sm2, (hipStream_t)stream,
                            reinterpret_cast<const __bf16*>(V), U, attn, dctx, w2, reinterpret_cast<__bf16*>(dPreU), dw2, du_colsum, T, Bp);
         LOB_CHECK_LAUNCH();
         return 0;

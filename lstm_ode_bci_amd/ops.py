@@ -518,8 +518,8 @@ def attn_pool_bwd(v, u, attn, dctx, w2, T, B, Bp, want_dv=True, du_bf16=False, d
 
 def attn_bwd_fuses_colsum(v, u, want_dv, du_bf16):
     """Shapes for which lob_attn_pool_bwd_f32 can accumulate the column sums of dPreU itself."""
-    return (v.dtype == torch.bfloat16 and du_bf16 and not want_dv and u is not None and v.shape[1] == 256
-            and u.shape[1] == 128)
+    return (v.dtype == torch.bfloat16 and du_bf16 and not want_dv and u is not None and
+            (v.shape[1], u.shape[1]) in ((256, 128), (512, 256)))
 
 
 # ---------------------------------------------------------------------------------------------
