@@ -8,6 +8,8 @@ kernel launch over all windows.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -15,7 +17,7 @@ from . import ops
 from .synthetic import RATE_KEYS
 
 
-_COPY_THREADS = 8
+_COPY_THREADS = max(4, min(16, (os.cpu_count() or 8)))
 _pool = None
 
 
@@ -183,20 +185,20 @@ class LSTMODEIntegration:
                 ev = torch.cuda.Event()
                 ev.record(copy_stream)
             return ev, m
-        nxt = upload(0)
+        ev, m = upload(0)
+        prev_ev = None
         for k in range(len(starts)):
-            ev, m = nxt
             main.wait_event(ev)
             b = k & 1
+            yield dbuf[b][:m]            # the consumer enqueues chunk k's kernels BEFORE the host stages chunk k+1
+            done[b] = torch.cuda.Event()
+            done[b].record(main)
             if k + 1 < len(starts):
-                if k >= 1:
+                if prev_ev is not None:
                     # staging buffer (k+1)&1 was last read by the copy of chunk k-1: make sure that copy has finished
                     prev_ev.synchronize()
                 prev_ev = ev
-                nxt = upload(k + 1)
-            yield dbuf[b][:m]
-            done[b] = torch.cuda.Event()
-            done[b].record(main)
+                ev, m = upload(k + 1)    # host-side staging + H2D of chunk k+1 overlap chunk k's kernels
 
     def predict_batch(self, X_batch, forecast_steps=20, batch_size=512, show_progress=True, use_amp=None,
                       respect_batch_size=False):
