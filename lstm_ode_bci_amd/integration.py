@@ -205,8 +205,78 @@ class LSTMODEIntegration:
         """(trajectories (N,steps,3) f64, probs (N,2) f32, predictions (N,) int64) as numpy
         (06:308-406).  ``show_progress`` is accepted and ignored (no per-sample loop to show).  ``use_amp`` mirrors
         the reference's flag of 06:340 (see the class attribute); ``respect_batch_size`` makes ``batch_size`` an
-        upper bound on the windows per device pass."""
-        traj, probs, pred = self.predict_batch_device(X_batch, forecast_steps, batch_size, use_amp=use_amp,
-                                                      respect_batch_size=respect_batch_size)
+        upper bound on the windows per device pass.
+
+        Host arrays in, host arrays out: per device chunk the LSTM pass, the ODE kernel and the download of that chunk's
+        results are queued back to back; the download runs on a side stream into page-locked staging buffers while the
+        NEXT chunk is in the LSTM kernels, and the host moves the previous chunk's staged results into the returned
+        arrays meanwhile (the trajectories are the larger message: 7.2 KB per window at 300 points)."""
+        n = len(X_batch)
+        if n == 0 or (torch.is_tensor(X_batch) and X_batch.is_cuda):
+            traj, probs, pred = self.predict_batch_device(X_batch, forecast_steps, batch_size, use_amp=use_amp,
+                                                          respect_batch_size=respect_batch_size)
+            self.ode_model.params = self.base_params.copy()
+            return traj.cpu().numpy(), probs.cpu().numpy(), pred.cpu().numpy()
+        chunk = self._chunk(batch_size, respect_batch_size)
+        self.lstm_model.eval()
+        dev = self._device()
+        steps = int(forecast_steps)
+        traj = np.empty((n, steps, 3), dtype=np.float64)
+        probs = np.empty((n, 2), dtype=np.float32)
+        pred = np.empty((n,), dtype=np.int64)
+        nb = min(chunk, n)
+        key = (nb, steps, str(dev))
+        if getattr(self, "_d2h_key", None) != key:
+            self._d2h_key = key
+            self._d2h_stream = torch.cuda.Stream(device=dev)
+            self._d2h_stage = [(torch.empty((nb, steps, 3), dtype=torch.float64).pin_memory(),
+                                torch.empty((nb, 2), dtype=torch.float32).pin_memory(),
+                                torch.empty((nb,), dtype=torch.int64).pin_memory()) for _ in range(2)]
+        side, stage = self._d2h_stream, self._d2h_stage
+        pool = _copy_pool()
+
+        def drain(p):
+            """Chunk p's results: page-locked staging -> the returned arrays (sliced over the copy threads)."""
+            i0, m, b, ev, _keep = p
+            ev.synchronize()
+            st, sp, sd = (t.numpy() for t in stage[b])
+            step = max(1, (m + _COPY_THREADS - 1) // _COPY_THREADS)
+            list(pool.map(lambda s0: np.copyto(traj[i0 + s0:i0 + min(m, s0 + step)], st[s0:min(m, s0 + step)]),
+                          range(0, m, step)))
+            probs[i0:i0 + m] = sp[:m]
+            pred[i0:i0 + m] = sd[:m]
+
+        self._amp_now = self.use_amp if use_amp is None else bool(use_amp)
+        try:
+            with torch.no_grad(), ops.on_device(dev):
+                main = torch.cuda.current_stream(dev)
+                pending, i0, k = None, 0, 0
+                for Xc in self._device_chunks(X_batch, n, chunk, dev):
+                    m = Xc.shape[0]
+                    probs_d, _ = self._probs_device(Xc)
+                    traj_d, _, pred_d = ops.ode_rk4(self._base_rates(), steps, 0.0, float(steps), self._substeps(),
+                                                    probs=probs_d, alpha=self.coupling_strength, want_traj=True,
+                                                    want_pred=True)
+                    ready = torch.cuda.Event()
+                    ready.record(main)
+                    b = k & 1               # staging set b was drained when chunk k-1 was queued
+                    with torch.cuda.stream(side):
+                        side.wait_event(ready)
+                        stage[b][0][:m].copy_(traj_d, non_blocking=True)
+                        stage[b][1][:m].copy_(probs_d, non_blocking=True)
+                        stage[b][2][:m].copy_(pred_d, non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(side)
+                    if pending is not None:
+                        drain(pending)      # the host copy of chunk k-1 runs while the GPU is in chunk k
+                    # the device results stay referenced until their download has been waited for (they were
+                    # allocated on the compute stream and are read on the side stream)
+                    pending = (i0, m, b, ev, (traj_d, probs_d, pred_d))
+                    i0 += m
+                    k += 1
+                if pending is not None:
+                    drain(pending)
+        finally:
+            self._amp_now = False
         self.ode_model.params = self.base_params.copy()
-        return traj.cpu().numpy(), probs.cpu().numpy(), pred.cpu().numpy()
+        return traj, probs, pred
