@@ -50,3 +50,22 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "no_such_liblob.so"))
     with pytest.raises(_lib.LobError, match="not built|not found"):
         _lib.lib()
+
+
+def test_python_constants_match_the_header():
+    """The flag bits OR-ed into `act` and the variant indices are restated in Python (ops.py, _lib.py): they must be the
+    header's values, every LOB_VAR_* must have a Python name, and the library must know as many variants as the header."""
+    from lstm_ode_bci_amd import _lib, ops
+    text = open(os.path.join(ROOT, "include", "lob.h")).read()
+    defs = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"#define\s+(LOB_\w+)\s+(0x[0-9a-fA-F]+|\d+)\b", text)}
+    assert ops.OUT_BF16 == defs["LOB_OUT_BF16"] and ops.DY_BF16 == defs["LOB_DY_BF16"] and ops.X_BF16 == defs["LOB_X_BF16"]
+    assert ops.LN_IDENTITY == defs["LOB_LN_IDENTITY"]
+    flags = [defs[k] for k in ("LOB_OUT_BF16", "LOB_DY_BF16", "LOB_X_BF16", "LOB_LN_IDENTITY")]
+    assert len(set(flags)) == 4 and all(f & 0xff == 0 for f in flags)          # distinct, clear of the activation code
+    header_vars = {k[len("LOB_VAR_"):]: v for k, v in defs.items() if k.startswith("LOB_VAR_") and k != "LOB_VAR_COUNT"}
+    assert header_vars == _lib.VAR, (sorted(header_vars.items()), sorted(_lib.VAR.items()))
+    assert sorted(header_vars.values()) == list(range(defs["LOB_VAR_COUNT"]))
+    L = _lib.lib()
+    assert L.lob_debug_get_variant(defs["LOB_VAR_COUNT"] - 1) >= 0
+    assert L.lob_debug_set_variant(defs["LOB_VAR_COUNT"], 1) < 0                # out of range: argument error
+    assert L.lob_version() == defs["LOB_VERSION"]
