@@ -283,8 +283,9 @@ __device__ __forceinline__ bool tiled_row(int g, int T, int B, int Bp, int& row,
 }
 __device__ __forceinline__ int tiled_count(int T, int B) { return ((B + 7) >> 3) * ((T + 7) >> 3) * 64; }
 
-// LPR = lanes per row: 64 (one row per wave pass) or 16 (four rows per pass, VPL = 8: width 128 then moves 32 B per
-// lane in and 16 B of bf16 out, instead of 8 B / 4 B with 64 lanes on the row).
+// LPR = lanes per row: 64 (one row per wave pass), 16 (four rows per pass, VPL = 8: width 128 then moves 32 B per
+// lane in and 16 B of bf16 out, instead of 8 B / 4 B with 64 lanes on the row) or 32 (two rows per pass, VPL = 8:
+// width 256 with bf16 rows in and out -- 16 B per lane and stream instead of 8).
 template <int LPR>
 __device__ __forceinline__ float row_sum(float v) {
     if (LPR == 64) return wave_sum(v);
@@ -295,6 +296,7 @@ __device__ __forceinline__ float row_sum(float v) {
     LOB_DPP_ADD(0x141);      // row_half_mirror
     LOB_DPP_ADD(0x140);      // row_mirror: every lane of the 16-lane row now holds the row's sum
 #undef LOB_DPP_ADD
+    if (LPR == 32) v += __shfl_xor(v, 16, 64);      // two 16-lane halves of a 32-lane row
     return v;
 }
 
@@ -711,9 +713,17 @@ extern "C" int lob_layernorm_act_f32(const float* in, const float* gamma, const 
     if (x16) {       // bf16 input rows: the post-LSTM LayerNorm of the mixed path (width 256), vectorised kernel only
         if (width != 256 || ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) |
                               reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15)) return LOB_E_SHAPE;
+        const __bf16* inb = reinterpret_cast<const __bf16*>(in);
+        if (out_bf16 && ln_lpr16()) {      // bf16 in and out: 32 lanes per row, 16 B per lane and stream
+            int nb = (rows + 15) / 16;     // RPW 2 x GPW 2 rows per wave pass, 4 waves
+            if (nb > 256 * 16) nb = 256 * 16;
+            hipLaunchKernelGGL((layernorm_act_vec_kernel<8, true, 32, __bf16>), dim3(nb), dim3(256), 0, (hipStream_t)stream,
+                               inb, gamma, beta, out, rows, eps, act, remap_T, remap_B, remap_Bp, drop_p, seed);
+            LOB_CHECK_LAUNCH();
+            return 0;
+        }
         int nb = (rows + 3) / 4;
         if (nb > 256 * 16) nb = 256 * 16;
-        const __bf16* inb = reinterpret_cast<const __bf16*>(in);
         if (out_bf16) hipLaunchKernelGGL((layernorm_act_vec_kernel<4, true, 64, __bf16>), dim3(nb), dim3(256), 0, (hipStream_t)stream,
                                          inb, gamma, beta, out, rows, eps, act, remap_T, remap_B, remap_Bp, drop_p, seed);
         else hipLaunchKernelGGL((layernorm_act_vec_kernel<4, false, 64, __bf16>), dim3(nb), dim3(256), 0, (hipStream_t)stream,
@@ -837,7 +847,14 @@ extern "C" int lob_layernorm_act_bwd_f32(const float* x, const float* gamma, con
                        remap_B, remap_Bp, drop_p, seed, pool_attn, pool_dctx, pool_T, pool_B, pool_Bp, dx_colsum)
         if (width == 256) {
             if (blocks > 256 * 8) blocks = 256 * 8;
-            if (x16)
+            if (x16 && ln_lpr16()) {     // all three streams bf16: 32 lanes per row, 16 B per lane and stream
+                blocks = (rows + 31) / 32;
+                if (blocks > 256 * 8) blocks = 256 * 8;
+                hipLaunchKernelGGL((layernorm_act_bwd_vec_kernel<8, 32, __bf16, __bf16, __bf16>), dim3(blocks), dim3(256), 0,
+                                   (hipStream_t)stream, reinterpret_cast<const __bf16*>(x), gamma, beta, dyb, dxb, dgamma, dbeta,
+                                   rows, eps, act, remap_T, remap_B, remap_Bp, drop_p, seed, pool_attn, pool_dctx, pool_T, pool_B,
+                                   pool_Bp, dx_colsum);
+            } else if (x16)
                 hipLaunchKernelGGL((layernorm_act_bwd_vec_kernel<4, 64, __bf16, __bf16, __bf16>), dim3(blocks), dim3(256), 0,
                                    (hipStream_t)stream, reinterpret_cast<const __bf16*>(x), gamma, beta, dyb, dxb, dgamma, dbeta,
                                    rows, eps, act, remap_T, remap_B, remap_Bp, drop_p, seed, pool_attn, pool_dctx, pool_T, pool_B,

@@ -575,7 +575,7 @@ def test_layernorm_bf16_input_rows_equal_the_widened_rows(dev):
     """LOB_X_BF16 (the last LSTM layer hands its output to the post-LSTM LayerNorm, 04_lstm_model.py:212, as bf16 only):
     reading bf16 rows must give exactly what the fp32-input kernels give on the same values widened -- forward (bf16 and
     fp32 out) and backward (bf16 dy / dx, fused pooling term), at rows = 1,048,576 and at a ragged row count."""
-    from lstm_ode_bci_amd import ops
+    from lstm_ode_bci_amd import _lib, ops
     W = 256
     for rows, Tn, Bn in ((T * B, T, B), (3 * 96, 3, 96)):
         x16 = _rand((rows, W), dev, 71, 0.5, dtype=torch.bfloat16)
@@ -583,14 +583,22 @@ def test_layernorm_bf16_input_rows_equal_the_widened_rows(dev):
         for ob in (True, False):
             a = ops.layernorm_act(x16, gm, bt, out_bf16=ob)
             b = ops.layernorm_act(x16.float(), gm, bt, out_bf16=ob)
-            assert a.dtype == b.dtype and torch.equal(a, b)
+            assert a.dtype == b.dtype
+            assert (a.float() - b.float()).abs().max().item() <= (3e-2 if ob else 1e-5)
         dy = _rand((rows, W), dev, 74, 1e-3, dtype=torch.bfloat16)
         attn = torch.softmax(_rand((Bn, Tn), dev, 75), 1)
         dctx = _rand((Bn, W), dev, 76, 1e-3)
         pool = (attn, dctx, Tn, Bn, Bn)
         dxa, dga, dba = ops.layernorm_act_bwd(x16, gm, bt, dy, pool=pool, dx_bf16=True)
         dxb, dgb, dbb = ops.layernorm_act_bwd(x16.float(), gm, bt, dy, pool=pool, dx_bf16=True)
-        assert dxa.dtype == torch.bfloat16 and torch.equal(dxa, dxb)
+        # (bf16 rows are read on 32 lanes per row, fp32 rows on 64: the row sums associate differently -> one bf16 ulp)
+        assert dxa.dtype == torch.bfloat16
+        assert (dxa.float() - dxb.float()).abs().max().item() <= 8e-3 * dxb.float().abs().max().item()
+        with _lib.variant(LN_LPR=64):          # the 64-lane kernels read both storage types the same way
+            dxc, _, _ = ops.layernorm_act_bwd(x16, gm, bt, dy, pool=pool, dx_bf16=True)
+            a64 = ops.layernorm_act(x16, gm, bt, out_bf16=True)
+            b64 = ops.layernorm_act(x16.float(), gm, bt, out_bf16=True)
+        assert torch.equal(dxc, dxb) and torch.equal(a64, b64)
         # dgamma / dbeta: fp32 atomics, order not fixed
         assert (dga - dgb).abs().max().item() <= 1e-4 * dgb.abs().max().item()
         assert (dba - dbb).abs().max().item() <= 1e-4 * dbb.abs().max().item()

@@ -39,3 +39,15 @@ for W in (128, 256):
     print(f"LN bwd W={W} {'identity':28s} {ms:7.3f} ms  {T*B*W*12/ms/1e6:7.0f} GB/s")
     ms = timeit(lambda: torch.add(x, dy, out=dy))
     print(f"torch add W={W} (2R:1W)              {ms:7.3f} ms  {T*B*W*12/ms/1e6:7.0f} GB/s")
+
+# mixed path, width 256, every stream bf16 (LOB_X_BF16): 32 lanes per row against 64 (LOB_VAR_LN_LPR = 64)
+from lstm_ode_bci_amd import _lib
+W = 256
+x16 = torch.randn((T * B, W), device=dev).to(torch.bfloat16)
+dy16 = (torch.randn((T * B, W), device=dev) * 1e-3).to(torch.bfloat16)
+g = torch.ones(W, device=dev); b = torch.zeros(W, device=dev)
+for lpr in (16, 64):
+    with _lib.variant(LN_LPR=lpr):
+        msf = timeit(lambda: ops.layernorm_act(x16, g, b, out_bf16=True))
+        msb = timeit(lambda: ops.layernorm_act_bwd(x16, g, b, dy16, dx_bf16=True))
+    print(f"LN W=256 bf16 streams, LN_LPR={lpr}: fwd {msf:.3f} ms ({T*B*W*4/msf/1e6:.0f} GB/s), bwd {msb:.3f} ms ({T*B*W*6/msb/1e6:.0f} GB/s)")
