@@ -712,3 +712,29 @@ def test_forward_full_size_goldens_exact_fp32_mfma_kernels(dev, H):
     print(f"H={H}: |logits split - exact| {float((l2 - logits).abs().max()):.2e}, split vs golden "
           f"{np.abs(l2.cpu().numpy() - d['logits']).max():.2e}, exact vs golden {np.abs(logits.cpu().numpy() - d['logits']).max():.2e}")
     assert np.abs(l2.cpu().numpy() - d["logits"]).max() < TOL
+
+
+@pytest.mark.parametrize("H", [128, 256])
+def test_serving_shapes_one_to_five_windows_vs_oracle(dev, H):
+    """The serving call of 06_lstm_ode_integration.py:340-360 with a handful of windows (B = 1 .. 5: one 16-row tile
+    per direction, the few-window recurrent kernel below 4): fp32 logits / attention <= 1e-5 vs the CPU path, the mixed
+    path (autocast, 06:349) within its 5e-3, and every window independent of how many others share the call."""
+    from oracle import torch_cpu_path as TP
+    sd = syn.make_state_dict(61, H, 3, 2, True)
+    x, _ = syn.make_windows(5)
+    m = _model(sd, 61, H, 3, True, dev)
+    ref = TP.build(sd, 61, H)
+    with torch.no_grad():
+        rl, ra = ref(torch.from_numpy(x), return_attention=True)
+    xt = torch.from_numpy(x).to(dev)
+    for Bn in (1, 2, 3, 4, 5):
+        with torch.no_grad():
+            lg, at = m(xt[:Bn], return_attention=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                lm, am = m(xt[:Bn], return_attention=True)
+        assert lg.shape == (Bn, 2) and at.shape == (Bn, 256)
+        assert np.abs(lg.cpu().numpy() - rl.numpy()[:Bn]).max() < TOL, Bn
+        assert np.abs(at.cpu().numpy() - ra.numpy()[:Bn]).max() < TOL, Bn
+        assert np.abs(lm.float().cpu().numpy() - rl.numpy()[:Bn]).max() < 5e-3, Bn
+        assert np.abs(am.float().cpu().numpy() - ra.numpy()[:Bn]).max() < 5e-3, Bn
+        assert abs(float(am.sum(1).mean()) - 1.0) < 1e-3
