@@ -27,6 +27,11 @@
 // on the per-lane GLOBAL source address of the DMA and again on the fragment read (cdna guide rule 21); the 16 lanes a
 // ds_read_b128 services together hold 16 different r & 15, i.e. the 16 different 16-B pieces of the 256-B bank row.
 #include "lob_common.h"
+// H = 256: eight column groups re-read every activation tile from L2, and P (4.3 GB, written once) would evict
+// them: non-temporal fragment stores there (K = 512: 2.33 -> 2.31 ms, K = 256: 1.15 -> 1.12)
+#ifndef LOB_NT_WSP
+#define LOB_NT_WSP true
+#endif
 
 namespace {
 
@@ -238,7 +243,10 @@ __global__ __launch_bounds__(512, 2) void gate_gemm_ws_kernel(WSArgs g) {
                     for (int e = 0; e < 8; ++e) v[e] = (__bf16)(acc[i][cb][8 * pq + e] + bv[cb]);
                     // rows past the end (M % 64 == 32) exist only in the LAST iteration of the workgroup that owns the
                     // last tile: skipping their stores changes no later vmcnt count
-                    if (ok) *reinterpret_cast<bf16x8*>(dst + pq * 512) = v;
+                    if (ok) {
+                        if constexpr (LOB_NT_WSP && HID == 256) __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(dst + pq * 512));
+                        else *reinterpret_cast<bf16x8*>(dst + pq * 512) = v;
+                    }
                 }
             }
         }
