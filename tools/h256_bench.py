@@ -64,3 +64,15 @@ for v in (1, 0):
         dY16 = dY.to(torch.bfloat16)
         ms_b = timeit(lambda: ops.lstm_rec_bwd(G, Cs, whh, dY16, T, Bp, H, D, dp_bf16=True))
     print(f"H256_LDSW={v}: rec fwd save {ms_f:.3f} ms, inference {ms_i:.3f} ms, BPTT (bf16 dY) {ms_b:.3f} ms", flush=True)
+
+# weight gradients at H = 256 (tiled TN GEMM): dW_ih = dP^T X and, per direction, dW_hh = dP_d^T Y_d
+dPb = rnd((rows, D * 4 * H), 1e-2, torch.bfloat16)
+for K in (512, 256):
+    X = rnd((rows, K), 1.0, torch.bfloat16)
+    out = torch.zeros((D * 4 * H, K), device=dev)
+    ms = timeit(lambda: ops.gemm_tn(dPb, X, out, mixed=True))
+    report(f"dW_ih = dP^T X, X width {K}", ms, 2.0 * rows * K * D * 4 * H, 2.0 * rows * (K + D * 4 * H))
+Yb = rnd((rows, D * H), 1.0, torch.bfloat16)
+out = torch.zeros((4 * H, H), device=dev)
+ms = timeit(lambda: ops.gemm_tn(dPb[Bp:, :4 * H], Yb[:(T - 1) * Bp, :H], out, mixed=True))
+report("dW_hh (one direction) = dP_d^T Y_d", ms, 2.0 * rows * H * 4 * H, 2.0 * rows * (H + 4 * H))
