@@ -58,8 +58,9 @@ const char* lob_build_id(void);
  * simpler route (register-staged instead of LDS-DMA with hand-counted waits, the tiled GEMM instead of the
  * weight-stationary one, ...).  The parity tests run both at the bench's full shapes and compare them
  * (bit-exact where the arithmetic order is the same).  The table is process-global and read at every launch;
- * each entry starts from the environment variable of the same name, else its default.  Product code never
- * calls the setter.  lob_debug_set_variant returns the previous value, LOB_E_ARG for an unknown index.
+ * each entry starts from its default; only when LOB_DEBUG_VARIANTS=1 is set in the environment is an entry seeded
+ * from the environment variable of the same name (A/B runs), so a stray LOB_* variable cannot re-route product
+ * kernels.  Product code never calls the setter.  lob_debug_set_variant returns the previous value, LOB_E_ARG for an unknown index.
  * ---------------------------------------------------------------------------------- */
 #define LOB_VAR_REC_BWD_DMA   0  /* 1: BPTT (H=128, mixed) streams G/c by LDS-DMA; 0: register-prefetch twin      */
 #define LOB_VAR_NT_DMA        1  /* 1: bf16 TN (weight-gradient) GEMM on the LDS-DMA kernel; 0: register-staged    */
@@ -75,12 +76,15 @@ const char* lob_build_id(void);
 #define LOB_VAR_NT_TK        11  /* its k-tile: 32 or 64                                                          */
 #define LOB_VAR_NT_STAGGER   12  /* start stagger of the NT LDS-DMA GEMM (units of s_sleep(32)); 0 = off           */
 #define LOB_VAR_FUSED_DW     13  /* read by the Python host: 1 = dW_ih and dW_hh from one pass (lob_lstm_dw_bf16)  */
-#define LOB_VAR_F32_SPLIT    14  /* 1: fp32 gate GEMMs as three-way bf16 splits on bf16 MFMA; 0: exact-fp32 MFMA   */
+#define LOB_VAR_F32_SPLIT    14  /* 1: fp32 gate GEMMs / recurrent forward (H=128) carry each operand as two fp16 halves
+                                  *    (22 bits) on the 16-bit matrix pipe; 0: exact-fp32 MFMA                     */
 #define LOB_VAR_REC_F32_HALF 15  /* 1: fp32 recurrent forward may split the gate columns over two workgroups       */
 #define LOB_VAR_H256_LDSW    16  /* H=256 recurrent kernels: 0 = all W_hh fragments streamed; 1 = part of them resident in LDS      */
 #define LOB_VAR_DX_KSPLIT    17  /* 1: dX = dP W_ih on the k-split weight-stationary kernel; 0: tiled LDS-DMA NT GEMM          */
 #define LOB_VAR_REC_FEW      18  /* 1: mixed inference forward with fewer than 4 windows skips the padding registers' cell update */
-#define LOB_VAR_COUNT        19
+#define LOB_VAR_GEMM_PP      19  /* bit mask, H=256 mixed step: 1 = dX, 2 = gate GEMM, 4 = weight gradients on the 8-wave
+                                  *    ping-pong 256x256x64 kernels (csrc/gemm_pp.hip); 0 bits: the tiled / weight-stationary twins */
+#define LOB_VAR_COUNT        20
 int lob_debug_set_variant(int which, int value);
 int lob_debug_get_variant(int which);
 
@@ -238,8 +242,11 @@ int lob_layernorm_act_bwd_f32(const float* x, const float* gamma, const float* b
  * the pre-tanh hidden W1 v + b1; the caller adds dPreU W1 into dV with lob_gemm_nt_f32.   */
 int lob_attn_pool_bwd_f32(const void* V, int v_bf16, const float* U, const float* attn, const float* dctx,
                           const float* w2, float* dV, void* dPreU, int du_bf16, float* dw2,
-                          float* du_colsum, int T, int B, int Bp, int W, int W2, void* stream);
-/*   v_bf16 / du_bf16: V read / dPreU written as bf16 (mixed mode).  dV == NULL: the direct term
+                          float* du_colsum, int T, int B, int Bp, int W, int W2, const float* dattn, void* stream);
+/*   dattn [B][T] (may be NULL): gradient w.r.t. the attention WEIGHTS themselves, added to dctx . V[t] before the softmax
+ *   backward -- a stand-alone Attention module (04_lstm_model.py:112-128) returns (context, weights) and a caller may
+ *   differentiate through either; inside EnhancedLSTMModel the weights carry no gradient (NULL).
+ *   v_bf16 / du_bf16: V read / dPreU written as bf16 (mixed mode).  dV == NULL: the direct term
  *   a[t] * dctx is not materialised; pass pool_attn / pool_dctx to lob_layernorm_act_bwd_f32 instead.
  *   U == NULL (mean pooling): only dV = a[t] * dctx is written; w2, dPreU, dw2 are ignored.
  *   du_colsum != NULL (bf16 V and dPreU, dV == NULL, W = 256, W2 = 128 only): du_colsum[j] += sum_t dPreU[t][j]

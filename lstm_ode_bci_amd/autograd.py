@@ -15,6 +15,10 @@ from . import images, ops
 from .ops import ACT_GELU, ACT_NONE, ACT_TANH, ceil32
 
 
+COLLECT_HEAD = 4         # input_proj.0.{weight,bias}, input_proj.1.{weight,bias}
+COLLECT_TAIL = 12        # layer_norm (2) + attention (4) + classifier (6) positions
+
+
 def _collect(model):
     """Parameters in pipeline order.  The ablation variants (09_sensitivity_analysis.py:176-242) keep the
     positions and put None where a sub-module is nn.Identity / absent."""
@@ -223,8 +227,8 @@ def lob_forward(model, x, drops, seed):
     elif torch.is_grad_enabled():
         # an attached FusedAdamW (training.FusedAdamW(..., model=model)): the backward accumulates the parameter
         # gradients straight into its flat gradient buffer and hands autograd None for them
-        ref = getattr(model, "_lob_grad_sink", None)
-        opt = ref() if ref is not None else None
+        from .training import grad_sink_of
+        opt = grad_sink_of(model)
         if opt is not None:
             sink = opt.sink_for(params, model.num_directions)
     with ops.on_device(x.device), torch.autocast(device_type="cuda", enabled=False):
@@ -237,13 +241,46 @@ def lob_forward(model, x, drops, seed):
         return _LobModelFn.apply(x, cfg, sink, *params)
 
 
+class _AttentionFn(torch.autograd.Function):
+    """Stand-alone ``Attention.forward`` (04_lstm_model.py:123-128) as one autograd node: both outputs (context and
+    weights) are differentiable, gradients flow to the input sequence and to the four parameters."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        B, T, W = x.shape
+        v = _f32c(x).transpose(0, 1).contiguous().reshape(T * B, W)          # time-major rows t*B + b (no padding)
+        w1f, b1f, w2f, b2f = _f32c(w1), _f32c(b1), _f32c(w2), _f32c(b2)
+        u = ops.gemm_nt(v, w1f, b1f, act=ACT_TANH)
+        cx, attn = ops.attn_pool_fwd(v, u, w2f.reshape(-1), b2f, T, B, B)
+        if any(ctx.needs_input_grad):
+            ctx.sv = (v, u, attn, w1f, w2f, (B, T, W))
+        return cx, attn
+
+    @staticmethod
+    def backward(ctx, dcx, dattn):
+        v, u, attn, w1f, w2f, (B, T, W) = ctx.sv
+        with ops.on_device(v.device):
+            dcx = torch.zeros((B, W), device=v.device) if dcx is None else dcx.contiguous().float()
+            dattn = None if dattn is None else dattn.contiguous().float()
+            dV, dU, dw2 = ops.attn_pool_bwd(v, u, attn, dcx, w2f.reshape(-1), T, B, B, want_dv=True, dattn=dattn)
+            ops.gemm_nt(dU, w1f.t().contiguous(), out=dV, accumulate=True)  # + dPreU W1
+            dw1 = ops.gemm_tn(dU, v, torch.zeros_like(w1f))
+            db1 = ops.colsum(dU)
+            dx = dV.reshape(T, B, W).transpose(0, 1).contiguous()
+        # b2 cancels in the softmax over time: its gradient is exactly zero (SURVEY.md appendix A.4)
+        return dx, dw1, db1, dw2.reshape(w2f.shape), torch.zeros((1,), device=v.device)
+
+
 def attention_forward(lstm_output, w1, b1, w2, b2):
-    """Stand-alone Attention.forward on a batch-first (B,T,W) tensor (inference only)."""
+    """Stand-alone Attention.forward on a batch-first (B,T,W) tensor: (context (B,W), weights (B,T)), trainable like
+    the reference's nn.Module (04_lstm_model.py:112-128)."""
     if not lstm_output.is_cuda:
         raise ops._lib.LobError("Attention.forward: input must be on the GPU")
-    B, T, W = lstm_output.shape
     ops.same_device([lstm_output, w1, b1, w2, b2], "Attention.forward")
-    with ops.on_device(lstm_output.device):
-        v = _f32c(lstm_output).transpose(0, 1).contiguous().reshape(T * B, W)
-        u = ops.gemm_nt(v, _f32c(w1), _f32c(b1), act=ACT_TANH)
-        return ops.attn_pool_fwd(v, u, _f32c(w2).reshape(-1), _f32c(b2), T, B, B)
+    with ops.on_device(lstm_output.device), torch.autocast(device_type="cuda", enabled=False):
+        if not torch.is_grad_enabled():
+            B, T, W = lstm_output.shape
+            v = _f32c(lstm_output).transpose(0, 1).contiguous().reshape(T * B, W)
+            u = ops.gemm_nt(v, _f32c(w1), _f32c(b1), act=ACT_TANH)
+            return ops.attn_pool_fwd(v, u, _f32c(w2).reshape(-1), _f32c(b2), T, B, B)
+        return _AttentionFn.apply(lstm_output, w1, b1, w2, b2)

@@ -975,6 +975,15 @@ int lob_gemm_nt_ws(const void* A, int lda, const void* W, void* C, int ldc, int 
                    hipStream_t s);                        // gate_gemm_ws.hip
 int lob_dx_ksplit(const void* A, int lda, const void* Wt, void* C, int ldc, int M, int N, int K, int out_bf16, float drop_p,
                   uint64_t seed, hipStream_t s);         // dx_ksplit.hip
+// gemm_pp.hip: the 8-wave ping-pong 256 x 256 x 64 kernels (the matrix-bound GEMMs of the H = 256 step)
+bool lob_pp_nt_ok(int M, int N, int K);
+bool lob_pp_tn_ok(int M, int N, int Kc);
+int lob_gemm_nt_pp(const void* A, int lda, const void* Wt, int ldw, void* C, int ldc, int M, int N, int K, int out_bf16,
+                   float drop_p, uint64_t seed, hipStream_t s);
+int lob_gate_gemm_pp(const void* X, int ldx, const void* Wih, const float* bias, void* P, int T, int Bp, int H, int D, int K,
+                     hipStream_t s);
+int lob_gemm_tn_pp(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int Kc, int shift,
+                   int ex_lo, int ex_hi, hipStream_t s);
 
 // A: fp32 (a_bf16 = 0) or bf16 (a_bf16 = 1) row-major [M][lda]; W fp32 [N][ldw]; C fp32.
 inline int nt_stagger() {       // tuning knob LOB_NT_STAGGER (units of s_sleep(32) = 2048 clocks per group step)
@@ -1061,6 +1070,10 @@ extern "C" int lob_gemm_nt_bf16(const void* A, int a_bf16, int lda, const void* 
         if (!bias && (act & 0xff) == LOB_ACT_NONE && drop_p == 0.f && (K == 128 || K == 256) && (N % 256) == 0 && N <= 1024 &&
             (M % 32) == 0 && ldw == K && (ldc % 4) == 0 && al16(C) && lob_variant(LOB_VAR_GATE_WS) != 0)
             return lob_gemm_nt_ws(A, lda, W, C, ldc, M, N, K, out16, (hipStream_t)stream);
+        // wide contraction AND wide output (dX at H = 256: K = 2048, N = 512 / 256): matrix-bound -> ping-pong kernel
+        if (!bias && (act & 0xff) == LOB_ACT_NONE && K >= 1024 && lob_pp_nt_ok(M, N, K) && (ldc % 4) == 0 && al16(C) &&
+            (lob_variant(LOB_VAR_GEMM_PP) & 1))
+            return lob_gemm_nt_pp(A, lda, W, ldw, C, ldc, M, N, K, out16, drop_p, seed, (hipStream_t)stream);
         launch_nt_dma<0>(g, (hipStream_t)stream);
         LOB_CHECK_LAUNCH();
         return 0;
@@ -1090,6 +1103,9 @@ extern "C" int lob_gate_gemm_x_bf16(const void* X, int x_bf16, int ldx, const vo
     NTArgs g{X, reinterpret_cast<const float*>(Wih), bias, reinterpret_cast<float*>(P), ldx, K, N, M, N, K, LOB_ACT_NONE, 0,
              T, Bp, H, D, p_bf16, 0.f, 0, 0};
     if (w_bf16) {
+        // H = 256: matrix-bound (410 FLOP per HBM byte) -> ping-pong kernel
+        if (x_bf16 && p_bf16 && H == 256 && lob_pp_nt_ok(M, N, K) && N <= 2048 && (lob_variant(LOB_VAR_GEMM_PP) & 2))
+            return lob_gate_gemm_pp(X, ldx, Wih, bias, P, T, Bp, H, D, K, (hipStream_t)stream);
         // bf16 P: the weight-stationary kernel (gate_gemm_ws.hip) -- only the activations stream
         if (x_bf16 && p_bf16 && ((H == 128 && (K == 128 || K == 256)) || (H == 256 && (K == 256 || K == 512))) &&
             lob_variant(LOB_VAR_GATE_WS) != 0)
@@ -1119,6 +1135,9 @@ extern "C" int lob_gemm_tn_bf16(const void* A, int a_bf16, int lda, const void* 
     const int am = a_bf16 ? 8 : 4, bm = b_bf16 ? 8 : 4;
     if ((M % am) || (lda % am) || (N % bm) || (ldb % bm) || !al16(A) || !al16(B)) return LOB_E_ALIGN;
     hipStream_t s = (hipStream_t)stream;
+    // wide outputs over a long contraction (the H = 256 weight gradients): ping-pong kernel
+    if (a_bf16 && b_bf16 && lob_pp_tn_ok(M, N, Kc) && (lob_variant(LOB_VAR_GEMM_PP) & 4))
+        return lob_gemm_tn_pp(A, lda, B, ldb, C, ldc, M, N, Kc, 0, 0, 0, s);
     // big-tile LDS-DMA kernel: both sources bf16, output a multiple of 256 x 256, contraction a multiple of 32
     // (measured: 0.93 vs 1.02 ms on dW_ih 1024 x 256; on 256 x 128 tiles it LOSES to the register-staged kernel,
     //  0.33 vs 0.30 ms on dW_hh, so those shapes stay there)

@@ -1,0 +1,514 @@
+// Ping-pong bf16 GEMMs for the H = 256 mixed training step (the reference's real checkpoint size, hidden_size = 256 for
+// 61 channels, 04_lstm_model.py:877; training step 04:482-512 under autocast 04:487).
+//
+// At H = 256 the three tiled GEMM families of a layer are MATRIX-bound, not HBM-bound: per launch at B = 4096
+//     gate GEMM   P  = X  W_ih^T      1M x 2048 x 512   2.2 TFLOP for 5.4 GB  (410 FLOP/B; machine balance ~310)
+//     dX          dX = dP W_ih        1M x 512 x 2048   2.2 TFLOP for 5.4 GB
+//     dW          dW = dP^T [X | Y]   2048 x 768 x 1M   3.3 TFLOP for 6.3 GB
+// and the one-barrier-per-k-tile kernels of gemm_bf16.hip (16 waves, 64 x 64 per wave) sat at 0.9-0.95 PFLOP/s with 42 % of
+// their wave cycles parked in s_waitcnt / s_barrier (profiles/r02_train_mixed_B4096_H256_sq_counters.csv).
+//
+// Structure (cdna_hip_programming.md section 5, the 256^2 template, rebuilt around v_mfma_f32_32x32x16_bf16 because the
+// recurrent kernels' P layout is that instruction's accumulator order):
+//   * 256 x 256 output tile, 64-deep k-tiles, EIGHT waves as 2 x 4, 128 x 64 per wave (128 accumulator registers): half
+//     the LDS fragment bytes per MFMA of the 64 x 64 wave tile;
+//   * the waves form two groups (wr = 0 / 1), one wave of each on every SIMD, running the SAME instruction stream ONE
+//     BARRIER APART: every interval between two barriers one group issues 8 MFMAs (256 cycles of its SIMD's matrix
+//     pipe) while the other reads its next fragments from LDS and issues its share of the operand DMA -- the matrix pipe
+//     always has a wave with operands in registers;
+//   * two LDS buffers per operand (4 x 32 KB).  An operand region is re-staged as soon as BOTH groups have read it, so
+//     the DMA of k-tile q + 2 starts in the middle of k-tile q: 2 global_load_lds_dwordx4 per wave and interval, one
+//     counted s_waitcnt vmcnt per k-tile and wave, never 0 inside the loop; raw s_barrier;
+//   * fragment reads are inline asm (a compiler-visible LDS read of a DMA target gets an s_waitcnt vmcnt(0) in front);
+//     the s_waitcnt lgkmcnt(0) that ends a read segment names the fragment registers, so no MFMA can move above it.
+//
+// NT kernel (A[M,K] W[N,K]^T, both k-contiguous), per k-tile q and wave (buffer b = q & 1):
+//     L1  A rows 0-63 (of the wave's 128) k 0-31, B k 0-31            DMA: A-hi(q+1) -> b^1
+//     M1  acc[rb 0,1][cb 0,1] += k 0-31
+//     L2  A rows 0-63 k 32-63, B k 32-63                              DMA: B-h1(q+1) -> b^1
+//     M2  acc[rb 0,1][..] += k 32-63
+//     L3  A rows 64-127 k 0-31 (B stays in registers)                 DMA: A-lo(q+2) -> b    (A-lo(q): free after L2)
+//     M3  acc[rb 2,3][..] += k 0-31
+//     L4  A rows 64-127 k 32-63                                       DMA: B-h0(q+2) -> b    (B(q): free after L2)
+//         s_waitcnt vmcnt(4): everything of k-tile q + 1 has landed (younger: the 4 DMAs of L3 / L4)
+//     M4  acc[rb 2,3][..] += k 32-63
+// (A-lo = rows 0-63 and 128-191 of the tile: the first halves of both groups' rows; "free after L2" means after the
+//  barrier that follows the SECOND group's L2, one interval later.)  Reads per segment 8 / 8 / 4 / 4 ds_read_b128.
+//
+// TN kernel (C += A[Kc,M]^T B[Kc,N], both k-major: the weight gradients): the [k][cols] images need no transformation
+// on the way in, ds_read_b64_tr_b16 transposes on the read side; the phases split the k-tile by k-STEP (a k-quarter of
+// both operands is consumed per phase and re-staged right away: 6 fragments per segment, operand DMA three quarters
+// ahead + one k-tile: vmcnt(6)).
+#include "lob_common.h"
+#include <type_traits>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_cvoid;
+
+constexpr int PP_OP = 32768;          // bytes of one operand tile in LDS (256 rows x 64 k, or 64 k x 256 columns)
+constexpr int PP_BIAS = 4 * PP_OP;    // byte offset of the bias image (NT fragment epilogue)
+
+struct PPArgs {
+    const __bf16* A; const __bf16* W; void* C; const float* bias;
+    int lda, ldw, ldc, M, N, K;
+    int T, Bp, H;                     // fragment epilogue
+    int out_bf16; float drop_p; uint64_t seed;
+};
+
+__device__ __forceinline__ f32x16 pp_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+#define PP_RD128(dst, addr, OFF) \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "n"(OFF) : "memory")
+#define PP_BAR()                                   \
+    do {                                           \
+        __builtin_amdgcn_sched_barrier(0);         \
+        __builtin_amdgcn_s_barrier();              \
+        __builtin_amdgcn_sched_barrier(0);         \
+    } while (0)
+
+// EPI 0: row-major C[M, N] (bf16 or fp32), optional dropout mask of element (row * ldc + col): the MFMA runs with its
+//        operands SWAPPED (D[n][m]), so a lane holds 4 consecutive columns of one row per accumulator quad.
+// EPI 1: the gate GEMM: bf16 P in the recurrent kernels' fragment order [d][t][bt][w H/32][gate 4][q pair 2][lane 64][8]
+//        (include/lob.h) + bias.
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(PPArgs g) {
+    constexpr bool SWAP = EPI == 0;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * PP_OP + (EPI == 1 ? 8192 : 0)];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int r31 = lane & 31, hi = lane >> 5;
+    const int ntn = g.N >> 8, ntm = g.M >> 8;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+    const int panels = (ntm - xcd + 7) / 8, ntile = panels * ntn;      // XCD x owns the row panels mt = x (mod 8)
+    if (slot >= ntile) return;
+    const int nk = g.K >> 6;                                             // even (checked by the host)
+    const int my_tiles = (ntile - slot + nslot - 1) / nslot;
+    const int last_it = slot + (my_tiles - 1) * nslot;
+    const int total = my_tiles * nk;
+
+    if constexpr (EPI == 1) {          // bias image (read in the epilogue through an asm-opaque LDS load)
+        float* bs = reinterpret_cast<float*>(lds + PP_BIAS);
+        for (int i = tid; i < g.N && i < 2048; i += 512) bs[i] = g.bias ? g.bias[i] : 0.f;
+        __syncthreads();
+    }
+
+    // ---- producer side: operand DMA.  One wave instruction = 8 rows x 128 B; 16-B chunk c of row r lands at chunk
+    //      slot c ^ ((r >> 1) & 7) (applied on the per-lane SOURCE address; the same XOR on the fragment read).
+    struct Cur { int it, kt; const char* pa; const char* pb; };
+    auto set_cur = [&](Cur& c) {
+        const int m0 = ((c.it / ntn) * 8 + xcd) << 8, n0 = (c.it % ntn) << 8;
+        c.pa = reinterpret_cast<const char*>(g.A) + ((size_t)m0 * g.lda + (size_t)c.kt * 64) * 2;
+        c.pb = reinterpret_cast<const char*>(g.W) + ((size_t)n0 * g.ldw + (size_t)c.kt * 64) * 2;
+    };
+    auto advance = [&](Cur& c) {       // next k-tile of this workgroup's sequence; past the end: stay on the last one
+        if (c.kt + 1 < nk) { ++c.kt; c.pa += 128; c.pb += 128; }
+        else if (c.it < last_it) { c.it += nslot; c.kt = 0; set_cur(c); }
+    };
+    const int l3 = lane >> 3, l7 = lane & 7;
+    unsigned asrc[2], bsrc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int ra = wr * 128 + wc * 16 + j * 8 + l3;                  // A-lo row of this lane (A-hi: + 64)
+        asrc[j] = 2u * (unsigned)(ra * g.lda + ((l7 ^ ((ra >> 1) & 7)) << 3));
+        const int rb = wave * 16 + j * 8 + l3;                           // B row inside a 128-row half
+        bsrc[j] = 2u * (unsigned)(rb * g.ldw + ((l7 ^ ((rb >> 1) & 7)) << 3));
+    }
+    const size_t a_hi_b = (size_t)64 * g.lda * 2, b_h1_b = (size_t)128 * g.ldw * 2;
+    unsigned char* const a_dst = lds + wr * 16384 + wc * 2048;           // + buf * PP_OP (+ 8192: A-hi)
+    unsigned char* const b_dst = lds + 2 * PP_OP + wave * 2048;          // + buf * PP_OP + half * 16384
+    auto dma2 = [&](const char* src, unsigned o0, unsigned o1, unsigned char* dst) {
+        __builtin_amdgcn_global_load_lds((gbl_cvoid*)(src + o0), (lds_void*)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_cvoid*)(src + o1), (lds_void*)(dst + 1024), 16, 0, 0);
+    };
+    auto stage_a = [&](const Cur& c, int buf, int hi_half) {
+        dma2(c.pa + (hi_half ? a_hi_b : 0), asrc[0], asrc[1], a_dst + buf * PP_OP + hi_half * 8192);
+    };
+    auto stage_b = [&](const Cur& c, int buf, int half) {
+        dma2(c.pb + (half ? b_h1_b : 0), bsrc[0], bsrc[1], b_dst + buf * PP_OP + half * 16384);
+    };
+
+    // ---- consumer side: fragment read addresses: row wr*128 + 32 rb + r31 (rb, buffer: immediates), k-step ks
+    const unsigned lds_b = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const int sw = (r31 >> 1) & 7;
+    unsigned aoff[4], boff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        aoff[ks] = lds_b + (unsigned)((wr * 128 + r31) * 128 + (((2 * ks + hi) ^ sw) << 4));
+        boff[ks] = lds_b + (unsigned)(2 * PP_OP + (wc * 64 + r31) * 128 + (((2 * ks + hi) ^ sw) << 4));
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][c][r] = 0.f;
+
+    // ---- prologue: all of k-tile 0, A-lo / B-h0 of k-tile 1
+    Cur c1{slot, 0, nullptr, nullptr};
+    set_cur(c1);
+    stage_a(c1, 0, 0); stage_b(c1, 0, 0); stage_a(c1, 0, 1); stage_b(c1, 0, 1);
+    advance(c1);
+    stage_a(c1, 1, 0); stage_b(c1, 1, 0);
+    Cur c2 = c1;
+    advance(c2);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    PP_BAR();
+    if (wr == 1) PP_BAR();             // the second group runs one barrier behind
+
+    bf16x8 af[2][2], bf[2][4];
+#define PP_MMA(ACC, AF, BF) ACC = SWAP ? pp_mfma(BF, AF, ACC) : pp_mfma(AF, BF, ACC)
+#define PP_WAIT4()                                                                                              \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]))
+    auto ktile = [&](auto bufc) {      // one k-tile out of buffer BUF; c1 / c2 = k-tiles q + 1 / q + 2
+        constexpr int BUF = decltype(bufc)::value, BO = BUF * PP_OP, NB = BUF ^ 1;
+        // ---- L1 / M1
+        PP_RD128(af[0][0], aoff[0], BO);        PP_RD128(af[0][1], aoff[1], BO);
+        PP_RD128(af[1][0], aoff[0], BO + 4096); PP_RD128(af[1][1], aoff[1], BO + 4096);
+        PP_RD128(bf[0][0], boff[0], BO);        PP_RD128(bf[0][1], boff[1], BO);
+        PP_RD128(bf[1][0], boff[0], BO + 4096); PP_RD128(bf[1][1], boff[1], BO + 4096);
+        stage_a(c1, NB, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]),
+                     "+v"(bf[0][0]), "+v"(bf[0][1]), "+v"(bf[1][0]), "+v"(bf[1][1]));
+        PP_BAR();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) PP_MMA(acc[i][c], af[i][s], bf[c][s]);
+        __builtin_amdgcn_s_setprio(0);
+        PP_BAR();
+        // ---- L2 / M2
+        PP_RD128(af[0][0], aoff[2], BO);        PP_RD128(af[0][1], aoff[3], BO);
+        PP_RD128(af[1][0], aoff[2], BO + 4096); PP_RD128(af[1][1], aoff[3], BO + 4096);
+        PP_RD128(bf[0][2], boff[2], BO);        PP_RD128(bf[0][3], boff[3], BO);
+        PP_RD128(bf[1][2], boff[2], BO + 4096); PP_RD128(bf[1][3], boff[3], BO + 4096);
+        stage_b(c1, NB, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]),
+                     "+v"(bf[0][2]), "+v"(bf[0][3]), "+v"(bf[1][2]), "+v"(bf[1][3]));
+        PP_BAR();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) PP_MMA(acc[i][c], af[i][s], bf[c][2 + s]);
+        __builtin_amdgcn_s_setprio(0);
+        PP_BAR();
+        // ---- L3 / M3
+        PP_RD128(af[0][0], aoff[0], BO + 8192);  PP_RD128(af[0][1], aoff[1], BO + 8192);
+        PP_RD128(af[1][0], aoff[0], BO + 12288); PP_RD128(af[1][1], aoff[1], BO + 12288);
+        stage_a(c2, BUF, 0);
+        PP_WAIT4();
+        PP_BAR();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) PP_MMA(acc[2 + i][c], af[i][s], bf[c][s]);
+        __builtin_amdgcn_s_setprio(0);
+        PP_BAR();
+        // ---- L4 / M4
+        PP_RD128(af[0][0], aoff[2], BO + 8192);  PP_RD128(af[0][1], aoff[3], BO + 8192);
+        PP_RD128(af[1][0], aoff[2], BO + 12288); PP_RD128(af[1][1], aoff[3], BO + 12288);
+        stage_b(c2, BUF, 0);
+        PP_WAIT4();
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // k-tile q + 1 complete (this wave's share)
+        PP_BAR();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) PP_MMA(acc[2 + i][c], af[i][s], bf[c][2 + s]);
+        __builtin_amdgcn_s_setprio(0);
+        PP_BAR();
+        c1 = c2;
+        advance(c2);
+    };
+
+    int it = slot, kt = 0;
+    for (int q = 0; q < total; q += 2) {
+        ktile(std::integral_constant<int, 0>{});
+        ktile(std::integral_constant<int, 1>{});
+        kt += 2;
+        if (kt < nk) continue;
+
+        // ---- epilogue of output tile `it` (the other group keeps the matrix pipe for one more interval)
+        kt = 0;
+        const int m0 = ((it / ntn) * 8 + xcd) << 8, n0 = (it % ntn) << 8;
+        it += nslot;
+        if constexpr (EPI == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = m0 + wr * 128 + 32 * i + r31;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const size_t o = (size_t)row * g.ldc + n0 + wc * 64 + 32 * c + 4 * hi;
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) {
+                        float v0 = acc[i][c][4 * qd], v1 = acc[i][c][4 * qd + 1], v2 = acc[i][c][4 * qd + 2],
+                              v3 = acc[i][c][4 * qd + 3];
+                        if (g.drop_p > 0.f) {
+                            float d0, d1, d2, d3;
+                            lob_dropout_scale2(g.seed, (uint64_t)(o + 8 * qd), g.drop_p, d0, d1);
+                            lob_dropout_scale2(g.seed, (uint64_t)(o + 8 * qd) + 2, g.drop_p, d2, d3);
+                            v0 *= d0; v1 *= d1; v2 *= d2; v3 *= d3;
+                        }
+                        if (g.out_bf16) {
+                            bf16x4 v = {(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
+                            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(g.C) + o + 8 * qd) = v;
+                        } else {
+                            f32x4 v = {v0, v1, v2, v3};
+                            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + o + 8 * qd) = v;
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][c][r] = 0.f;
+                }
+            }
+        } else {
+            const int NBT = g.Bp >> 5, NW = g.H >> 5, H4 = 4 * g.H;
+            const float* bs = reinterpret_cast<const float*>(lds + PP_BIAS);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int ncol = n0 + wc * 64 + 32 * c;
+                const int d = ncol / H4, gate = (ncol % H4) / g.H, w = (ncol % g.H) >> 5;
+                const float bv = lds_read_f32_opaque(bs + ncol + r31);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int mrow = m0 + wr * 128 + 32 * i;
+                    const int t = mrow / g.Bp, bt = (mrow - t * g.Bp) >> 5;
+                    const size_t fo = ((((size_t)(d * g.T + t) * NBT + bt) * NW + w) * 4 + gate) * 1024;
+                    __bf16* dst = reinterpret_cast<__bf16*>(g.C) + fo + lane * 8;
+#pragma unroll
+                    for (int pq = 0; pq < 2; ++pq) {
+                        bf16x8 v;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = (__bf16)(acc[i][c][8 * pq + e] + bv);
+                        __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(dst + pq * 512));
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][c][r] = 0.f;
+                }
+            }
+        }
+    }
+    if (wr == 0) PP_BAR();             // barrier counts of the two groups match
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef PP_MMA
+#undef PP_WAIT4
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// TN: C[i][j] += sum_k A[k][i] B[k][j] over this workgroup's contraction chunk, fp32 atomics at the end (split-k).
+// One (256 x 256 output tile, chunk) per workgroup.  LDS images [64 k][256 columns] (512-B rows), 64-B granule g of
+// k-row kr stored at granule g ^ (kr & 3) (on the DMA source address and on the tr read: the four k-rows of a
+// ds_read_b64_tr_b16 block then cover the 256-B bank row).
+// B may be a time-shifted source (the h_prev operand of dW_hh): rows [ex_lo, ex_hi) have no predecessor -- their k-tiles
+// are fetched unshifted and their products skipped (Bp % 64 == 0: a k-tile never straddles two time steps).
+// ------------------------------------------------------------------------------------------------------------------
+struct TNPPArgs {
+    const __bf16* A; const __bf16* B; float* C;
+    int lda, ldb, ldc, M, N, Kc, kchunk, tiles;
+    int shift, ex_lo, ex_hi;          // B row = k + shift outside [ex_lo, ex_hi)
+};
+
+#define PP_TR(dst, addr, OFF) \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "n"(OFF) : "memory")
+
+__global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(TNPPArgs g) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * PP_OP];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int ntn = g.N >> 8;
+    // workgroups of one contraction chunk are 8 apart in blockIdx: one XCD under round-robin placement, so the source
+    // tiles they share are fetched from HBM once (speed only)
+    const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+    const int tile = rest % g.tiles, chunk = (rest / g.tiles) * 8 + xcd;
+    const int m0 = (tile / ntn) << 8, n0 = (tile % ntn) << 8;
+    const int kbeg = chunk * g.kchunk, kend = min(g.Kc, kbeg + g.kchunk);
+    if (kbeg >= kend) return;
+    const int total = (kend - kbeg) >> 6;                                // even (host)
+
+    // ---- producer: one wave instruction = 2 k-rows x 512 B; per k-quarter (16 k-rows) one instruction per wave and operand
+    const int kr2 = 2 * wave + (lane >> 5), ch = lane & 31;
+    const unsigned asrc = 2u * (unsigned)(kr2 * g.lda + ((ch ^ ((kr2 & 3) << 2)) << 3));
+    const unsigned bsrc = 2u * (unsigned)(kr2 * g.ldb + ((ch ^ ((kr2 & 3) << 2)) << 3));
+    const char* const a_base = reinterpret_cast<const char*>(g.A + m0);
+    const char* const b_base = reinterpret_cast<const char*>(g.B + n0);
+    unsigned char* const a_dst = lds + wave * 1024;                       // + buf * PP_OP + kq * 8192
+    unsigned char* const b_dst = lds + 2 * PP_OP + wave * 1024;
+    auto stage = [&](int p, int buf, int kq) {     // k-quarter kq of k-tile p (clamped: past the end the last one again)
+        const int pp = p < total ? p : total - 1;
+        const int k0 = kbeg + 64 * pp;
+        const bool ex = k0 >= g.ex_lo && k0 < g.ex_hi;
+        const char* pa = a_base + ((size_t)(k0 + 16 * kq) * g.lda) * 2;
+        const char* pb = b_base + ((size_t)(k0 + 16 * kq + (ex ? 0 : g.shift)) * g.ldb) * 2;
+        __builtin_amdgcn_global_load_lds((gbl_cvoid*)(pa + asrc), (lds_void*)(a_dst + buf * PP_OP + kq * 8192), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_cvoid*)(pb + bsrc), (lds_void*)(b_dst + buf * PP_OP + kq * 8192), 16, 0, 0);
+    };
+
+    // ---- consumer: tr-read addresses.  Element (k-row 8 h + q, column c + 16 mh + 4 p) of a block sits at column
+    //      (c ^ 32 q) + 16 mh + 4 p; the 32-column block index meets the swizzle in its two low bits only.
+    const int fh = lane >> 5, fmh = (lane >> 4) & 1, fq = (lane >> 2) & 3, fp = lane & 3;
+    const unsigned lds_b = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const unsigned frow = (unsigned)((8 * fh + fq) * 512 + 2 * (16 * fmh + 4 * fp));
+    const unsigned a0 = lds_b + frow + 2u * (unsigned)(wr * 128 + 32 * fq);                 // block rb: ^ (rb << 6)
+    const unsigned b0 = lds_b + 2 * PP_OP + frow + 2u * (unsigned)((wc * 64) ^ (32 * fq));  // block cb: ^ (cb << 6)
+    unsigned av[4], bv[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) av[i] = a0 ^ (unsigned)(i << 6);
+    bv[0] = b0; bv[1] = b0 ^ 64u;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][c][r] = 0.f;
+
+    // ---- prologue: k-tile 0 and k-quarters 0..2 of k-tile 1
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) stage(0, 0, kq);
+#pragma unroll
+    for (int kq = 0; kq < 3; ++kq) stage(1, 1, kq);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    PP_BAR();
+    if (wr == 1) PP_BAR();
+
+    bf16x4 al[4], ah[4], bl[2], bh[2];
+#define PP_FRAG(l, h) bf16x8{l[0], l[1], l[2], l[3], h[0], h[1], h[2], h[3]}
+    auto phase = [&](auto bufc, auto ksc, int q, bool on) {
+        constexpr int BUF = decltype(bufc)::value, KS = decltype(ksc)::value, O = BUF * PP_OP + KS * 8192;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { PP_TR(al[i], av[i], O); PP_TR(ah[i], av[i], O + 2048); }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) { PP_TR(bl[c], bv[c], O); PP_TR(bh[c], bv[c], O + 2048); }
+        // DMA: the k-quarter both groups finished reading one phase ago
+        if constexpr (KS == 0) stage(q + 1, BUF ^ 1, 3);
+        else                   stage(q + 2, BUF, KS - 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(al[0]), "+v"(ah[0]), "+v"(al[1]), "+v"(ah[1]), "+v"(al[2]), "+v"(ah[2]),
+                     "+v"(al[3]), "+v"(ah[3]), "+v"(bl[0]), "+v"(bh[0]), "+v"(bl[1]), "+v"(bh[1]));
+        if constexpr (KS == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // k-tile q + 1 complete
+        PP_BAR();
+        if (on) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) acc[i][c] = pp_mfma(PP_FRAG(al[i], ah[i]), PP_FRAG(bl[c], bh[c]), acc[i][c]);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        PP_BAR();
+    };
+    auto ktile = [&](auto bufc, int q) {
+        const int k0 = kbeg + 64 * q;
+        const bool on = !(k0 >= g.ex_lo && k0 < g.ex_hi);
+        phase(bufc, std::integral_constant<int, 0>{}, q, on);
+        phase(bufc, std::integral_constant<int, 1>{}, q, on);
+        phase(bufc, std::integral_constant<int, 2>{}, q, on);
+        phase(bufc, std::integral_constant<int, 3>{}, q, on);
+    };
+    for (int q = 0; q < total; q += 2) {
+        ktile(std::integral_constant<int, 0>{}, q);
+        ktile(std::integral_constant<int, 1>{}, q + 1);
+    }
+    if (wr == 0) PP_BAR();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef PP_FRAG
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int col = n0 + wc * 64 + 32 * c + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wr * 128 + 32 * i + acc_row(r, lane);
+                atomicAdd(g.C + (size_t)row * g.ldc + col, acc[i][c][r]);
+            }
+        }
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+inline int pp_grid(int M, int N) {          // persistent: one workgroup per CU, a multiple of 8 for the XCD map
+    const long tiles = (long)(M >> 8) * (N >> 8);
+    long gsz = 256;
+    if (gsz > tiles) gsz = ((tiles + 7) / 8) * 8;
+    // an XCD's panels may be fewer than its share of workgroups when M is small: the surplus exits at once
+    return (int)gsz;
+}
+
+}  // namespace
+
+// Shapes the ping-pong NT kernels take (checked again by the entry points).
+bool lob_pp_nt_ok(int M, int N, int K) {
+    return M > 0 && (M % 256) == 0 && (N % 256) == 0 && N >= 256 && (K % 128) == 0 && K >= 256;
+}
+
+// Row-major C[M, N] = A[M, K] Wt[N, K]^T (bf16 operands, bf16 or fp32 C, optional dropout mask).  Preconditions beyond
+// lob_pp_nt_ok (checked by the caller, lob_gemm_nt_bf16): 16-B aligned bases, lda % 8 == 0, ldw % 8 == 0, ldc % 4 == 0.
+int lob_gemm_nt_pp(const void* A, int lda, const void* Wt, int ldw, void* C, int ldc, int M, int N, int K, int out_bf16,
+                   float drop_p, uint64_t seed, hipStream_t s) {
+    if (!lob_pp_nt_ok(M, N, K)) return LOB_E_SHAPE;
+    // 32-bit lane offsets of the DMA sources
+    if ((long)256 * lda * 2 >= (1L << 31) || (long)256 * ldw * 2 >= (1L << 31)) return LOB_E_SHAPE;
+    PPArgs g{(const __bf16*)A, (const __bf16*)Wt, C, nullptr, lda, ldw, ldc, M, N, K, 0, 0, 0, out_bf16, drop_p, seed};
+    hipLaunchKernelGGL((gemm_nt_pp_kernel<0>), dim3((unsigned)pp_grid(M, N)), dim3(512), 0, s, g);
+    LOB_CHECK_LAUNCH();
+    return 0;
+}
+
+// The gate GEMM: bf16 fragment-order P[T*Bp, D*4H] = X[T*Bp, K] W_ih[D*4H, K]^T + bias.  N = D*4H <= 2048.
+int lob_gate_gemm_pp(const void* X, int ldx, const void* Wih, const float* bias, void* P, int T, int Bp, int H, int D, int K,
+                     hipStream_t s) {
+    const int M = T * Bp, N = D * 4 * H;
+    if (!lob_pp_nt_ok(M, N, K) || N > 2048 || (H % 32) || (Bp % 32)) return LOB_E_SHAPE;
+    if ((long)256 * ldx * 2 >= (1L << 31)) return LOB_E_SHAPE;
+    PPArgs g{(const __bf16*)X, (const __bf16*)Wih, P, bias, ldx, K, N, M, N, K, T, Bp, H, 1, 0.f, 0};
+    hipLaunchKernelGGL((gemm_nt_pp_kernel<1>), dim3((unsigned)pp_grid(M, N)), dim3(512), 0, s, g);
+    LOB_CHECK_LAUNCH();
+    return 0;
+}
+
+bool lob_pp_tn_ok(int M, int N, int Kc) {
+    return (M % 256) == 0 && (N % 256) == 0 && M >= 256 && N >= 256 && (Kc % 128) == 0 && Kc >= 256;
+}
+
+// C[M, N] (fp32, += by atomics) = A[Kc, M]^T B'[Kc, N], B'[k] = B[k + shift] outside [ex_lo, ex_hi), 0 inside.
+// shift != 0 needs ex_hi - ex_lo and ex_lo multiples of 64 covering every k with k + shift outside [0, Kc).
+int lob_gemm_tn_pp(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int Kc, int shift,
+                   int ex_lo, int ex_hi, hipStream_t s) {
+    if (!lob_pp_tn_ok(M, N, Kc)) return LOB_E_SHAPE;
+    if ((ex_lo % 64) || (ex_hi % 64)) return LOB_E_SHAPE;
+    if ((long)16 * lda * 2 >= (1L << 31) || (long)16 * ldb * 2 >= (1L << 31)) return LOB_E_SHAPE;
+    const int tiles = (M >> 8) * (N >> 8);
+    int nchunk = (256 + tiles - 1) / tiles;                  // one workgroup per CU
+    long kchunk = ((long)Kc + nchunk - 1) / nchunk;
+    kchunk = ((kchunk + 127) / 128) * 128;
+    if (kchunk < 1024) kchunk = 1024;
+    if (kchunk > Kc) kchunk = Kc;
+    nchunk = (int)((Kc + kchunk - 1) / kchunk);
+    const int nchunk8 = ((nchunk + 7) / 8) * 8;
+    TNPPArgs g{(const __bf16*)A, (const __bf16*)B, C, lda, ldb, ldc, M, N, Kc, (int)kchunk, tiles, shift, ex_lo, ex_hi};
+    hipLaunchKernelGGL(gemm_tn_pp_kernel, dim3((unsigned)(tiles * nchunk8)), dim3(512), 0, s, g);
+    LOB_CHECK_LAUNCH();
+    return 0;
+}

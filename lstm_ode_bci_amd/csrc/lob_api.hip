@@ -33,6 +33,7 @@ const VarDef kVars[LOB_VAR_COUNT] = {
     {"LOB_H256_LDSW", 1},     // LOB_VAR_H256_LDSW
     {"LOB_DX_KSPLIT", 1},     // LOB_VAR_DX_KSPLIT
     {"LOB_REC_FEW", 1},       // LOB_VAR_REC_FEW
+    {"LOB_GEMM_PP", 7},       // LOB_VAR_GEMM_PP
 };
 std::atomic<int> g_vals[LOB_VAR_COUNT];
 std::atomic<int> g_init{0};
@@ -41,8 +42,11 @@ void init_once() {
     if (g_init.load(std::memory_order_acquire) == 2) return;
     int expect = 0;
     if (g_init.compare_exchange_strong(expect, 1)) {
+        // environment seeding is opt-in (LOB_DEBUG_VARIANTS=1): a stray LOB_* variable must not re-route product kernels
+        const char* dbg = getenv("LOB_DEBUG_VARIANTS");
+        const bool seed_env = dbg && dbg[0] == '1';
         for (int i = 0; i < LOB_VAR_COUNT; ++i) {
-            const char* e = getenv(kVars[i].env);
+            const char* e = seed_env ? getenv(kVars[i].env) : nullptr;
             g_vals[i].store(e ? atoi(e) : kVars[i].dflt, std::memory_order_relaxed);
         }
         g_init.store(2, std::memory_order_release);

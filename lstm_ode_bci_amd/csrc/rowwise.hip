@@ -480,13 +480,14 @@ __global__ __launch_bounds__(256) void layernorm_act_bwd_vec_kernel(
 
 // Backward of attn_pool_fwd_kernel, one workgroup per window.
 //   dV[t,b,:]    = a[t] * dctx[b,:]                      (the W1 path is added by a GEMM afterwards)
-//   ds[t]        = a[t] * (da[t] - sum_t a da),  da[t] = dctx . V[t,b,:]
+//   ds[t]        = a[t] * (da[t] - sum_t a da),  da[t] = dctx . V[t,b,:] (+ dattn[b,t]: the gradient that arrives through
+//                  the WEIGHTS output of a stand-alone Attention module, 04_lstm_model.py:112-128)
 //   dPreU[t,b,j] = ds[t] * w2[j] * (1 - U^2);   dw2[j] += sum_t ds[t] U[t,b,j]
 template <typename VE, typename UE>
 __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(
     const VE* __restrict__ V, const float* __restrict__ U, const float* __restrict__ attn,
     const float* __restrict__ dctx, const float* __restrict__ w2, float* __restrict__ dV,
-    UE* __restrict__ dPreU, float* __restrict__ dw2, int T, int Bp, int W, int W2) {
+    UE* __restrict__ dPreU, float* __restrict__ dw2, int T, int Bp, int W, int W2, const float* __restrict__ dattn) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* a = sm;            // [T]
     float* ds = sm + T;       // [T]  (da, then ds)
@@ -509,7 +510,7 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(
         float s = 0.f;
         for (int c = lane; c < W; c += 64) s = fmaf(dc[c], (float)v[c], s);
         s = wave_sum(s);
-        if (lane == 0) ds[t] = s;
+        if (lane == 0) ds[t] = s + (dattn ? dattn[(size_t)b * T + t] : 0.f);
     }
     __syncthreads();
     float dot = 0.f;
@@ -910,13 +911,15 @@ extern "C" int lob_layernorm_act_bwd_f32(const float* x, const float* gamma, con
 
 extern "C" int lob_attn_pool_bwd_f32(const void* V, int v_bf16, const float* U, const float* attn, const float* dctx,
                                      const float* w2, float* dV, void* dPreU, int du_bf16, float* dw2,
-                                     float* du_colsum, int T, int B, int Bp, int W, int W2, void* stream) {
+                                     float* du_colsum, int T, int B, int Bp, int W, int W2, const float* dattn,
+                                     void* stream) {
     if (!V || !attn || !dctx) return LOB_E_ARG;
+    if (dattn && (!U || du_colsum)) return LOB_E_SHAPE;      // the weights' gradient: generic kernel with a score MLP only
     if (U ? (!w2 || !dPreU || !dw2 || W2 <= 0) : !dV) return LOB_E_ARG;
     if (T <= 0 || B <= 0 || Bp < B || W <= 0) return LOB_E_ARG;
     const size_t smem = ((size_t)2 * T + W) * sizeof(float);
     if (smem > 60 * 1024) return LOB_E_SHAPE;
-    if (v_bf16 && du_bf16 && U && !dV && ((W == 256 && W2 == 128) || (W == 512 && W2 == 256)) &&
+    if (v_bf16 && du_bf16 && U && !dV && !dattn && ((W == 256 && W2 == 128) || (W == 512 && W2 == 256)) &&
         ((reinterpret_cast<uintptr_t>(V) | reinterpret_cast<uintptr_t>(U) | reinterpret_cast<uintptr_t>(w2) |
           reinterpret_cast<uintptr_t>(dctx)) & 15) == 0 && (reinterpret_cast<uintptr_t>(dPreU) & 7) == 0) {
         const size_t sm2 = ((size_t)2 * T + 4 * W2) * sizeof(float);
@@ -929,7 +932,7 @@ extern "C" int lob_attn_pool_bwd_f32(const void* V, int v_bf16, const float* U, 
     }
     if (du_colsum) return LOB_E_SHAPE;        // fused column sums exist on the vectorised path only
 #define LOB_APB(VE, UE) hipLaunchKernelGGL((attn_pool_bwd_kernel<VE, UE>), dim3(B), dim3(256), smem, (hipStream_t)stream, \
-        reinterpret_cast<const VE*>(V), U, attn, dctx, w2, dV, reinterpret_cast<UE*>(dPreU), dw2, T, Bp, W, W2)
+        reinterpret_cast<const VE*>(V), U, attn, dctx, w2, dV, reinterpret_cast<UE*>(dPreU), dw2, T, Bp, W, W2, dattn)
     if (v_bf16 && du_bf16) LOB_APB(__bf16, __bf16);
     else if (v_bf16) LOB_APB(__bf16, float);
     else if (du_bf16) LOB_APB(float, __bf16);

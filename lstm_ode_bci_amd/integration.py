@@ -36,10 +36,13 @@ class LSTMODEIntegration:
     #: ``max_device_chunk = n`` (per object) make the caller's number a true upper bound -- a memory cap.
     min_device_chunk = 4096
     max_device_chunk = None
-    #: the reference enters ``autocast()`` whenever CUDA is available (06:340, 349).  Here the default is the fp32
-    #: parity path (<= 1e-5 on probabilities); ``use_amp=True`` (per call) or this attribute select the mixed path
-    #: (bf16 MFMA inputs, fp32 accumulate / state), as the reference's GPU runs do.
-    use_amp = False
+    #: the reference enters ``autocast()`` whenever CUDA is available (06:340, 349): ITS GPU runs are mixed precision,
+    #: its CPU runs fp32.  ``use_amp=True`` (per call, or this attribute) selects the mixed path (bf16 MFMA inputs, fp32
+    #: accumulate / state; 2.3x the window rate), ``False`` the fp32 path that matches the reference's CPU results to
+    #: <= 1e-5.  Left at ``None`` the calls run fp32 and say so ONCE (``warnings.warn``), naming the switch -- a
+    #: maintainer who only swaps the import should learn that the reference's own GPU setting is the other one.
+    use_amp = None
+    _warned_fp32_default = False
 
     def __init__(self, lstm_model, ode_model, coupling_strength=0.5):
         self.lstm_model = lstm_model
@@ -51,17 +54,39 @@ class LSTMODEIntegration:
     def _device(self):
         return next(self.lstm_model.parameters()).device
 
-    def _probs_device(self, X):
-        """(probs, attention) device tensors for a batch-first (B,T,C) array/tensor."""
+    def _resolve_amp(self, use_amp=None):
+        """Precision of one call: the call's argument, else the object's / class's ``use_amp``, else fp32 with a one-time
+        note (see the class attribute).  Resolved per call -- no mutable per-object state, so the single-window and the
+        batch entry points agree and concurrent callers cannot see each other's choice."""
+        if use_amp is not None:
+            return bool(use_amp)
+        if self.use_amp is not None:
+            return bool(self.use_amp)
+        if not LSTMODEIntegration._warned_fp32_default:
+            LSTMODEIntegration._warned_fp32_default = True
+            import warnings
+            warnings.warn("LSTMODEIntegration runs the fp32 parity path (matches the reference's CPU results to 1e-5). "
+                          "The reference's own GPU runs use autocast (06_lstm_ode_integration.py:340): pass use_amp=True "
+                          "or set integration.use_amp = True for the mixed path (about 2.3x the window rate), or "
+                          "use_amp=False to keep fp32 without this note.", stacklevel=3)
+        return False
+
+    def _probs_device(self, X, amp=False):
+        """(probs, attention) device tensors for a batch-first (B,T,C) array/tensor; amp: run the model under autocast."""
         if isinstance(X, np.ndarray):
             X = torch.from_numpy(np.ascontiguousarray(X, dtype=np.float32))
         dev = self._device()
         X = X.to(dev, dtype=torch.float32)
-        with ops.on_device(dev), torch.autocast("cuda", dtype=torch.bfloat16, enabled=bool(self._amp_now)):
+        with ops.on_device(dev), torch.autocast("cuda", dtype=torch.bfloat16, enabled=bool(amp)):
             logits, attention = self.lstm_model(X, return_attention=True)
             return ops.softmax_rows(logits.float().contiguous()), attention
 
-    _amp_now = False
+    def release_staging(self):
+        """Free the page-locked host buffers, device double buffers and side streams that ``predict_batch`` keeps
+        between calls (2 x 256 MB pinned + 2 x 256 MB of HBM at 4096 x 256 x 61 windows, plus the result staging)."""
+        for a in ("_h2d_key", "_h2d_stream", "_h2d_stage", "_h2d_dbuf", "_d2h_key", "_d2h_stream", "_d2h_stage"):
+            if hasattr(self, a):
+                delattr(self, a)
 
     def _chunk(self, batch_size, respect_batch_size):
         chunk = int(batch_size)
@@ -73,11 +98,12 @@ class LSTMODEIntegration:
             chunk = min(chunk, int(self.max_device_chunk))
         return chunk
 
-    def get_lstm_probabilities(self, X):
+    def get_lstm_probabilities(self, X, use_amp=None):
         """(probs (B,2) [P(open), P(closed)], attention (B,T)) as numpy (06:216-234)."""
         self.lstm_model.eval()
+        amp = self._resolve_amp(use_amp)
         with torch.no_grad(), ops.on_device(self._device()):
-            probs, attention = self._probs_device(X)
+            probs, attention = self._probs_device(X, amp)
         return probs.cpu().numpy(), attention.cpu().numpy()
 
     def modulate_ode_rates(self, p_closed, p_open):
@@ -99,11 +125,12 @@ class LSTMODEIntegration:
         return getattr(self.ode_model, "rk4_substeps", 16)
 
     # ---------------------------------------------------------------------------------
-    def predict_trajectory(self, X, initial_state=None, forecast_steps=10):
+    def predict_trajectory(self, X, initial_state=None, forecast_steps=10, use_amp=None):
         """(trajectory (steps,3), probs (1,2), attention (1,T)) for one window (06:266-306)."""
         self.lstm_model.eval()
+        amp = self._resolve_amp(use_amp)
         with torch.no_grad(), ops.on_device(self._device()):
-            probs, attention = self._probs_device(X)
+            probs, attention = self._probs_device(X, amp)
             if initial_state is None:
                 traj, _, _ = ops.ode_rk4(self._base_rates(), forecast_steps, 0.0, float(forecast_steps),
                                          self._substeps(), probs=probs[:1].contiguous(),
@@ -126,19 +153,16 @@ class LSTMODEIntegration:
         chunk = self._chunk(batch_size, respect_batch_size)
         self.lstm_model.eval()
         dev = self._device()
-        self._amp_now = self.use_amp if use_amp is None else bool(use_amp)
-        try:
-            with torch.no_grad(), ops.on_device(dev):
-                probs_all = []
-                for Xc in self._device_chunks(X_batch, n, chunk, dev):
-                    probs, _ = self._probs_device(Xc)
-                    probs_all.append(probs)
-                probs = torch.cat(probs_all, 0) if len(probs_all) > 1 else probs_all[0]
-                traj, _, pred = ops.ode_rk4(self._base_rates(), forecast_steps, 0.0, float(forecast_steps),
-                                            self._substeps(), probs=probs, alpha=self.coupling_strength,
-                                            want_traj=want_traj, want_pred=True)
-        finally:
-            self._amp_now = False
+        amp = self._resolve_amp(use_amp)
+        with torch.no_grad(), ops.on_device(dev):
+            probs_all = []
+            for Xc in self._device_chunks(X_batch, n, chunk, dev):
+                probs, _ = self._probs_device(Xc, amp)
+                probs_all.append(probs)
+            probs = torch.cat(probs_all, 0) if len(probs_all) > 1 else probs_all[0]
+            traj, _, pred = ops.ode_rk4(self._base_rates(), forecast_steps, 0.0, float(forecast_steps),
+                                        self._substeps(), probs=probs, alpha=self.coupling_strength,
+                                        want_traj=want_traj, want_pred=True)
         return traj, probs, pred
 
     def _device_chunks(self, X_batch, n, chunk, dev):
@@ -246,37 +270,34 @@ class LSTMODEIntegration:
             probs[i0:i0 + m] = sp[:m]
             pred[i0:i0 + m] = sd[:m]
 
-        self._amp_now = self.use_amp if use_amp is None else bool(use_amp)
-        try:
-            with torch.no_grad(), ops.on_device(dev):
-                main = torch.cuda.current_stream(dev)
-                pending, i0, k = None, 0, 0
-                for Xc in self._device_chunks(X_batch, n, chunk, dev):
-                    m = Xc.shape[0]
-                    probs_d, _ = self._probs_device(Xc)
-                    traj_d, _, pred_d = ops.ode_rk4(self._base_rates(), steps, 0.0, float(steps), self._substeps(),
-                                                    probs=probs_d, alpha=self.coupling_strength, want_traj=True,
-                                                    want_pred=True)
-                    ready = torch.cuda.Event()
-                    ready.record(main)
-                    b = k & 1               # staging set b was drained when chunk k-1 was queued
-                    with torch.cuda.stream(side):
-                        side.wait_event(ready)
-                        stage[b][0][:m].copy_(traj_d, non_blocking=True)
-                        stage[b][1][:m].copy_(probs_d, non_blocking=True)
-                        stage[b][2][:m].copy_(pred_d, non_blocking=True)
-                        ev = torch.cuda.Event()
-                        ev.record(side)
-                    if pending is not None:
-                        drain(pending)      # the host copy of chunk k-1 runs while the GPU is in chunk k
-                    # the device results stay referenced until their download has been waited for (they were
-                    # allocated on the compute stream and are read on the side stream)
-                    pending = (i0, m, b, ev, (traj_d, probs_d, pred_d))
-                    i0 += m
-                    k += 1
+        amp = self._resolve_amp(use_amp)
+        with torch.no_grad(), ops.on_device(dev):
+            main = torch.cuda.current_stream(dev)
+            pending, i0, k = None, 0, 0
+            for Xc in self._device_chunks(X_batch, n, chunk, dev):
+                m = Xc.shape[0]
+                probs_d, _ = self._probs_device(Xc, amp)
+                traj_d, _, pred_d = ops.ode_rk4(self._base_rates(), steps, 0.0, float(steps), self._substeps(),
+                                                probs=probs_d, alpha=self.coupling_strength, want_traj=True,
+                                                want_pred=True)
+                ready = torch.cuda.Event()
+                ready.record(main)
+                b = k & 1               # staging set b was drained when chunk k-1 was queued
+                with torch.cuda.stream(side):
+                    side.wait_event(ready)
+                    stage[b][0][:m].copy_(traj_d, non_blocking=True)
+                    stage[b][1][:m].copy_(probs_d, non_blocking=True)
+                    stage[b][2][:m].copy_(pred_d, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
                 if pending is not None:
-                    drain(pending)
-        finally:
-            self._amp_now = False
+                    drain(pending)      # the host copy of chunk k-1 runs while the GPU is in chunk k
+                # the device results stay referenced until their download has been waited for (they were
+                # allocated on the compute stream and are read on the side stream)
+                pending = (i0, m, b, ev, (traj_d, probs_d, pred_d))
+                i0 += m
+                k += 1
+            if pending is not None:
+                drain(pending)
         self.ode_model.params = self.base_params.copy()
         return traj, probs, pred

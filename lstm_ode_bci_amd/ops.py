@@ -492,9 +492,11 @@ def can_fuse_colsum(width):
     return width in (128, 256, 512)
 
 
-def attn_pool_bwd(v, u, attn, dctx, w2, T, B, Bp, want_dv=True, du_bf16=False, du_colsum=None, dw2=None):
+def attn_pool_bwd(v, u, attn, dctx, w2, T, B, Bp, want_dv=True, du_bf16=False, du_colsum=None, dw2=None, dattn=None):
     """Returns (dV [T*Bp,W] fp32 or None, dPreU [T*Bp,W2] fp32|bf16, dw2 [W2]); pad rows are zero.
-    want_dv=False: the direct term a[t]*dctx is left to layernorm_act_bwd(pool=...)."""
+    want_dv=False: the direct term a[t]*dctx is left to layernorm_act_bwd(pool=...).  dattn [B,T]: gradient w.r.t. the
+    weights themselves (stand-alone Attention module)."""
+    _chk(dattn, "dattn")
     v16 = v.dtype == torch.bfloat16
     _chk(v, "v", v.dtype if v16 else torch.float32); _chk(u, "u"); _chk(attn, "attn"); _chk(dctx, "dctx"); _chk(w2, "w2")
     W = v.shape[1]
@@ -502,7 +504,7 @@ def attn_pool_bwd(v, u, attn, dctx, w2, T, B, Bp, want_dv=True, du_bf16=False, d
     if u is None:                # mean pooling: dV = dctx / T only
         dV = alloc((T * Bp, W), device=v.device, dtype=torch.float32)
         rc = _lib.lib().lob_attn_pool_bwd_f32(_ptr(v), int(v16), None, _ptr(attn), _ptr(dctx), None, _ptr(dV), None, 0,
-                                              None, None, T, B, Bp, W, 0, _stream())
+                                              None, None, T, B, Bp, W, 0, None, _stream())
         _lib.check(rc, "lob_attn_pool_bwd_f32")
         return dV, None, None
     W2 = u.shape[1]
@@ -511,7 +513,8 @@ def attn_pool_bwd(v, u, attn, dctx, w2, T, B, Bp, want_dv=True, du_bf16=False, d
     if dw2 is None:
         dw2 = torch.zeros((W2,), device=v.device, dtype=torch.float32)
     rc = _lib.lib().lob_attn_pool_bwd_f32(_ptr(v), int(v16), _ptr(u), _ptr(attn), _ptr(dctx), _ptr(w2), _ptr(dV),
-                                          _ptr(dU), int(du_bf16), _ptr(dw2), _ptr(du_colsum), T, B, Bp, W, W2, _stream())
+                                          _ptr(dU), int(du_bf16), _ptr(dw2), _ptr(du_colsum), T, B, Bp, W, W2, _ptr(dattn),
+                                          _stream())
     _lib.check(rc, "lob_attn_pool_bwd_f32")
     return dV, dU, dw2
 

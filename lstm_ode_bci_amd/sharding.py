@@ -164,6 +164,13 @@ def dp_sum_(t, group=None):
     return t
 
 
+def dp_broadcast_(t, src=0, group=None):
+    """In-place broadcast of rank `src`'s tensor (the flat parameter buffer at the start of a data-parallel run)."""
+    if dist.get_world_size(group) > 1:
+        dist.broadcast(t, src=src, group=group)
+    return t
+
+
 def all_reduce_flat_grad_(flat_grad, group=None):
     """Sum the flat gradient buffer over the ranks in place and return ``(flat_grad, 1 / world)``: the factor is
     handed to ``FusedAdamW.step(grad_scale=...)`` so that the mean is taken inside the optimizer launch instead of

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import math
 import time
+import weakref as _weakref
 
 import numpy as np
 import torch
@@ -25,7 +26,7 @@ import torch.nn as nn
 
 from . import ops
 from .model import AblationLSTMModel
-from .sharding import all_reduce_flat_grad_, dp_assert_equal, dp_sum_
+from .sharding import all_reduce_flat_grad_, dp_assert_equal, dp_broadcast_, dp_sum_
 
 
 # ---------------------------------------------------------------------------------------------
@@ -63,9 +64,11 @@ class WeightedCrossEntropy(nn.Module):
         return loss
 
 
-def class_weights_from_labels(y_train):
-    """04:430-432: inverse class frequency, normalised to sum 2."""
-    counts = np.bincount(np.asarray(y_train))
+def class_weights_from_labels(y_train, counts=None):
+    """04:430-432: inverse class frequency, normalised to sum 2.  ``counts``: class counts obtained elsewhere (the
+    data-parallel run sums them over the ranks' shards)."""
+    if counts is None:
+        counts = np.bincount(np.asarray(y_train))
     w = np.array([1.0 / c for c in counts], dtype=np.float32)
     return w / w.sum() * np.float32(2.0)
 
@@ -81,6 +84,17 @@ def warmup_cosine(current_epoch, warmup_epochs, epochs):
 # ---------------------------------------------------------------------------------------------
 # optimizer
 # ---------------------------------------------------------------------------------------------
+#: model -> weakref of the FusedAdamW that is its gradient sink.  Kept OUTSIDE the nn.Module (an attribute holding a
+#: weakref made the model unpicklable: torch.save(model), pickle, spawn-ed workers)
+_GRAD_SINKS = _weakref.WeakKeyDictionary()
+
+
+def grad_sink_of(model):
+    """The live FusedAdamW attached to `model` as its gradient sink, or None."""
+    ref = _GRAD_SINKS.get(model)
+    return ref() if ref is not None else None
+
+
 class _GradSink:
     """Accumulation targets of one backward inside FusedAdamW's flat gradient buffer: `offs[i]` = offset of the i-th
     parameter of autograd._collect(model) (None entries: absent sub-modules of the ablation variants)."""
@@ -95,7 +109,15 @@ class _GradSink:
         return self.flat_grad[self.offs[i]:self.offs[i] + n].view(tuple(shape))
 
     def span(self, i, step, count, shape):
-        """Parameters i, i + step, ..., laid out back to back (checked by FusedAdamW.sink_for)."""
+        """Parameters i, i + step, ..., (i + (count - 1) step) as ONE view: they must lie back to back in the flat buffer
+        (FusedAdamW._kernel_order lays the directions of an LSTM tensor out that way; sink_for checks it)."""
+        n = 1
+        for s in shape:
+            n *= int(s)
+        per = n // max(int(count), 1)
+        for k in range(1, int(count)):
+            if self.offs[i + step * k] != self.offs[i] + k * per:
+                raise ops._lib.LobError("gradient sink: parameters of one span are not contiguous in the flat buffer")
         return self.view(i, shape)
 
 
@@ -144,9 +166,8 @@ class FusedAdamW(torch.optim.Optimizer):
         self._off_of = {id(p): off for p, off in zip(ps, self._offsets)}
         self._model_ref = None
         if model is not None:
-            import weakref
-            self._model_ref = weakref.ref(model)
-            model._lob_grad_sink = weakref.ref(self)
+            self._model_ref = _weakref.ref(model)
+            _GRAD_SINKS[model] = _weakref.ref(self)
 
     @staticmethod
     def _kernel_order(model, params):
@@ -182,8 +203,8 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def detach_model(self):
         m = self._model_ref() if self._model_ref is not None else None
-        if m is not None and getattr(m, "_lob_grad_sink", None) is not None:
-            m._lob_grad_sink = None
+        if m is not None and grad_sink_of(m) is self:
+            del _GRAD_SINKS[m]
         self._model_ref = None
 
     def sink_for(self, params, D=None):
@@ -208,10 +229,15 @@ class FusedAdamW(torch.optim.Optimizer):
                 p.grad = view
             offs.append(off)
         n = len(params)
-        nl = n - 16                                   # 4 projection + 2 LayerNorm + 4 attention + 6 classifier tensors
+        # autograd._collect order: 4 projection tensors, 4 * D per LSTM layer, then the tail (2 LayerNorm + 4 attention +
+        # 6 classifier positions, None where a sub-module is absent).  A model whose list does not have that shape is not
+        # one whose backward can write into the flat buffer: say so instead of silently taking another path
+        from .autograd import COLLECT_HEAD, COLLECT_TAIL
+        nl = n - COLLECT_HEAD - COLLECT_TAIL
         if D is None or nl <= 0 or nl % (4 * D):
-            return None
-        for base in range(4, 4 + nl, 4 * D):
+            raise ops._lib.LobError(f"FusedAdamW.sink_for: {n} parameter positions do not fit the model layout "
+                                    f"({COLLECT_HEAD} + 4*D*L + {COLLECT_TAIL}, D = {D})")
+        for base in range(COLLECT_HEAD, COLLECT_HEAD + nl, 4 * D):
             for j in range(4):
                 for d in range(1, D):
                     a, b = offs[base + j], offs[base + j + 4 * d]
@@ -368,8 +394,18 @@ def train_model(model, train_loader, val_loader, y_train, epochs=100, learning_r
         dp_assert_equal((len(train_loader), len(val_loader), int(gradient_accumulation_steps), int(epochs)),
                         process_group, "batches per epoch (train, val), accumulation steps, epochs")
 
-    criterion = WeightedCrossEntropy(class_weights_from_labels(y_train)).to(dev)
+    counts = None
+    if dp:
+        # the CE weights of 04:430-432 come from the class counts of the WHOLE training set: sum the shards' counts
+        n_cls = int(model.classifier[-1].out_features)
+        counts = torch.as_tensor(np.bincount(np.asarray(y_train), minlength=n_cls)[:n_cls].astype(np.float64), device=dev)
+        counts = dp_sum_(counts, process_group).cpu().numpy()
+    criterion = WeightedCrossEntropy(class_weights_from_labels(y_train, counts)).to(dev)
     optimizer = FusedAdamW(model.parameters(), lr=learning_rate, weight_decay=weight_decay, model=model)
+    if dp:
+        # every rank starts from rank 0's weights (ranks built with different seeds / checkpoints would otherwise
+        # all-reduce gradients onto different weights and drift apart without any error); the moments start at zero
+        dp_broadcast_(optimizer.flat_param, 0, process_group)
     scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lambda e: warmup_cosine(e, warmup_epochs, epochs))
     acc_steps = gradient_accumulation_steps
     best_val_f1, best_state, stale = 0, None, 0

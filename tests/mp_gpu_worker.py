@@ -13,6 +13,33 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def train_mode(rank, world, dev, out):
+    """train_model(data_parallel=True) with ranks that were built from DIFFERENT seeds and hold shards with different
+    class balance: the run must start from rank 0's weights and weight the loss by the GLOBAL class counts."""
+    import pickle
+    from lstm_ode_bci_amd import EnhancedLSTMModel
+    from lstm_ode_bci_amd import synthetic as syn
+    from lstm_ode_bci_amd.training import DeviceWindowLoader, train_model
+    C, H, T = 13, 32, 16
+    torch.manual_seed(100 + rank)                   # different initial weights per rank
+    m = EnhancedLSTMModel(C, H, 2, 2, 0.0, True).to(dev)
+    w0 = torch.cat([p.detach().flatten() for p in m.parameters()]).cpu().numpy()
+    x, _ = syn.make_windows(48, T, C, seed=31 + rank)
+    y = np.zeros(48, dtype=np.int64)
+    y[: (8 if rank == 0 else 30)] = 1               # 8 / 48 positives on rank 0, 30 / 48 on rank 1
+    xv, yv = syn.make_windows(16, T, C, seed=41 + rank)
+    tl = DeviceWindowLoader(x, y, 12, "sequential", dev)
+    vl = DeviceWindowLoader(xv, yv, 16, "sequential", dev)
+    m, hist = train_model(m, tl, vl, y, epochs=2, learning_rate=1e-3, patience=5, warmup_epochs=1,
+                          gradient_accumulation_steps=2, use_amp=False, verbose=False, data_parallel=True)
+    w1 = torch.cat([p.detach().flatten() for p in m.parameters()]).cpu().numpy()
+    blob = pickle.dumps(m)                          # the trained model stays picklable (no weakref attribute on it)
+    np.savez(os.path.join(out, f"rank{rank}.npz"), w0=w0, w1=w1, train_loss=np.array(hist["train_loss"]),
+             val_f1=np.array(hist["val_f1"]), pickled=np.int64(len(blob)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     backend = os.environ.get("LOB_MP_BACKEND", "gloo")
@@ -23,6 +50,8 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     else:
         dist.init_process_group(backend)
+    if os.environ.get("LOB_MP_MODE") == "train":
+        return train_mode(rank, world, dev, out)
     from lstm_ode_bci_amd import CognitiveStateODE, EnhancedLSTMModel, LSTMODEIntegration, sharding
     from lstm_ode_bci_amd import synthetic as syn
     from lstm_ode_bci_amd.training import FusedAdamW, WeightedCrossEntropy

@@ -29,13 +29,13 @@ def _free_port():
     return p
 
 
-def _run_ranks(world, backend, tmp_path):
+def _run_ranks(world, backend, tmp_path, mode=""):
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), LOB_MP_BACKEND=backend, LOB_MP_OUT=str(tmp_path),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   LOB_MP_MODE=mode, HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mp_gpu_worker.py")], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -109,3 +109,15 @@ def test_rccl_world_size_one_smoke(tmp_path):
     (d,) = _run_ranks(1, "nccl", tmp_path)
     assert np.array_equal(d["traj"], ref["traj"]) and np.array_equal(d["probs"], ref["probs"])
     assert d["gscale"] == 1.0 and np.array_equal(d["nccl_gather"], np.ones((4, 2), np.float32))
+
+
+def test_data_parallel_train_model_syncs_start_state_and_class_weights(tmp_path):
+    """ranks built from different seeds must not drift apart silently.  train_model(data_parallel=True)
+    broadcasts rank 0's parameters before the first step and weights the loss by the class counts of the WHOLE
+    training set (04_lstm_model.py:430-432), so both ranks end with bit-identical weights and histories."""
+    r0, r1 = _run_ranks(2, "gloo", tmp_path, mode="train")
+    assert not np.array_equal(r0["w0"], r1["w0"])                 # the ranks really started apart
+    assert np.array_equal(r0["w1"], r1["w1"])
+    assert np.array_equal(r0["train_loss"], r1["train_loss"]) and np.array_equal(r0["val_f1"], r1["val_f1"])
+    assert np.isfinite(r0["w1"]).all() and not np.array_equal(r0["w1"], r0["w0"])
+    assert int(r0["pickled"]) > 0

@@ -49,7 +49,8 @@ def test_signatures_mirror_the_reference():
     assert [p.default for p in list(pb.parameters.values())[2:5]] == [20, 512, True]
     assert [p.default for p in list(pb.parameters.values())[5:]] == [None, False]       # use_amp, respect_batch_size
     pt = inspect.signature(LSTMODEIntegration.predict_trajectory)
-    assert list(pt.parameters) == ["self", "X", "initial_state", "forecast_steps"]
+    assert list(pt.parameters)[:4] == ["self", "X", "initial_state", "forecast_steps"]      # + use_amp=None
+    assert [p.default for p in list(pt.parameters.values())[4:]] == [None]
     assert list(inspect.signature(CognitiveStateODE.solve).parameters)[:4] == ["self", "initial_state", "t_span",
                                                                               "n_points"]
     assert isinstance(Attention(16).attention, torch.nn.Sequential)
@@ -280,3 +281,59 @@ def test_library_identity_and_variant_table():
     with _lib.variant(GATE_WS=0, REC_BWD_DMA=0):
         assert _lib.get_variant("GATE_WS") == 0 and _lib.get_variant("REC_BWD_DMA") == 0
     assert _lib.get_variant("GATE_WS") == before and _lib.get_variant("REC_BWD_DMA") == 1
+
+
+def test_variant_table_ignores_stray_environment_variables(tmp_path):
+    """a stray LOB_* variable on a user's box must not re-route product kernels.  The table is seeded from
+    the environment only under LOB_DEBUG_VARIANTS=1 (A/B runs)."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); from lstm_ode_bci_amd import _lib; "
+            "print(_lib.get_variant('GATE_WS'), _lib.get_variant('DMA_KT'))" % os.path.dirname(os.path.dirname(__file__)))
+    env = dict(os.environ, LOB_GATE_WS="0", LOB_DMA_KT="32")
+    env.pop("LOB_DEBUG_VARIANTS", None)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split()
+    assert out == ["1", "64"]                       # defaults, whatever the environment says
+    env["LOB_DEBUG_VARIANTS"] = "1"
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split()
+    assert out == ["0", "32"]
+
+
+def test_integration_precision_is_resolved_per_call_and_fp32_default_says_so_once():
+    """06_lstm_ode_integration.py:340: the reference's GPU runs enter autocast.  Here use_amp=None keeps the fp32 parity
+    path but names the switch once; an explicit choice (argument or attribute) is silent; nothing is stored on the
+    object between calls."""
+    import warnings
+    integ = LSTMODEIntegration.__new__(LSTMODEIntegration)
+    LSTMODEIntegration._warned_fp32_default = False
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert integ._resolve_amp(None) is False
+        assert integ._resolve_amp(None) is False
+    assert len(w) == 1 and "use_amp=True" in str(w[0].message)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert integ._resolve_amp(True) is True and integ._resolve_amp(False) is False
+        integ.use_amp = True
+        assert integ._resolve_amp(None) is True and integ._resolve_amp(False) is False
+    assert not w and not hasattr(integ, "_amp_now")
+    sig = inspect.signature(LSTMODEIntegration.predict_trajectory)
+    assert list(sig.parameters)[:4] == ["self", "X", "initial_state", "forecast_steps"]
+
+
+def test_model_with_attached_optimizer_state_stays_picklable():
+    """the gradient-sink registration lives outside the nn.Module (a weakref attribute on it broke
+    torch.save(model) / pickle / spawn)."""
+    import pickle
+    from lstm_ode_bci_amd import training
+    m = EnhancedLSTMModel(5, 8, 1, 2, 0.0, False)
+
+    class _Opt:                                      # stands in for a FusedAdamW (which needs GPU parameters)
+        pass
+    opt = _Opt()
+    import weakref
+    training._GRAD_SINKS[m] = weakref.ref(opt)
+    assert training.grad_sink_of(m) is opt
+    assert len(pickle.dumps(m)) > 0 and not hasattr(m, "_lob_grad_sink")
+    del opt
+    assert training.grad_sink_of(m) is None

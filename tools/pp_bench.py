@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Same-process A/B of the H = 256 step's matrix-bound GEMMs at B = 4096: ping-pong kernels (csrc/gemm_pp.hip) against
+the tiled LDS-DMA / weight-stationary twins, interleaved rounds, HIP-event times (median / min)."""
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lstm_ode_bci_amd import _lib, ops
+
+dev = torch.device("cuda:0")
+T, H, D, B = 256, 256, 2, int(os.environ.get("KB_B", "4096"))
+Bp = ops.ceil32(B)
+rows = T * Bp
+g = torch.Generator(device=dev).manual_seed(1)
+
+
+def rnd(shape, scale=1.0, dtype=torch.float32):
+    return (torch.randn(shape, generator=g, device=dev) * scale).to(dtype)
+
+
+def ab(name, fn, flop, variants, rounds=6):
+    ts = {k: [] for k in variants}
+    for k, kw in variants.items():
+        with _lib.variant(**kw):
+            fn(); fn()
+    torch.cuda.synchronize()
+    for _ in range(rounds):
+        for k, kw in variants.items():
+            with _lib.variant(**kw):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record(); fn(); e.record()
+                torch.cuda.synchronize()
+                ts[k].append(s.elapsed_time(e))
+    for k in variants:
+        med, mn = float(np.median(ts[k])), float(np.min(ts[k]))
+        print(f"{name:34s} {k:10s} {med:7.3f} ms (min {mn:7.3f})  {flop / med / 1e9:7.0f} TFLOP/s", flush=True)
+
+
+V = {"pingpong": dict(GEMM_PP=7), "twin": dict(GEMM_PP=0)}
+want = set(sys.argv[1:])
+dP = rnd((rows, D * 4 * H), 1e-2, torch.bfloat16)
+if not want or "dx" in want:
+    for N in (512, 256):
+        wt = rnd((N, D * 4 * H), 0.05, torch.bfloat16)
+        ab(f"dX K=2048 N={N}", lambda: ops.gemm_nt(dP, wt, mixed=True, out_bf16=True, drop_p=0.4, seed=3),
+           2.0 * rows * N * D * 4 * H, V)
+if not want or "gate" in want:
+    bias = rnd((D * 4 * H,), 0.1)
+    for K in (512, 256):
+        x = rnd((rows, K), 1.0, torch.bfloat16)
+        w = rnd((D * 4 * H, K), 0.05, torch.bfloat16)
+        ab(f"gate K={K}", lambda: ops.gate_gemm_x(x, w, bias, T, Bp, H, D, True, mixed=True), 2.0 * rows * K * D * 4 * H, V)
+if not want or "dw" in want:
+    for K in (512, 256):
+        x = rnd((rows, K), 1.0, torch.bfloat16)
+        out = torch.zeros((D * 4 * H, K), device=dev)
+        ab(f"dW_ih X width {K}", lambda: ops.gemm_tn(dP, x, out), 2.0 * rows * K * D * 4 * H, V)
+    y = rnd((rows, D * H), 1.0, torch.bfloat16)
+    out = torch.zeros((4 * H, H), device=dev)
+    ab("dW_hh one direction", lambda: ops.gemm_tn(dP[Bp:, :4 * H], y[:(T - 1) * Bp, :H], out), 2.0 * rows * H * 4 * H, V)
