@@ -114,7 +114,12 @@ int lob_gemm_tn_f32(const float* A, int lda, const float* B, int ldb, float* C, 
  * ---------------------------------------------------------------------------------- */
 int lob_gate_gemm_x_f32(const float* X, int ldx, const float* Wih, const float* bias,
                         float* P, int T, int Bp, int H, int D, int K, int frag,
-                        void* stream);
+                        const float* range, void* stream);
+/*   frag & 2: never take the fp16-split kernel (exact-fp32 MFMA; for activations without a known bound).
+ *   range (device, may be NULL; read by the H = 128 fp16-split kernel only): range[d] = max |W_ih| of direction d,
+ *   range[D] = an upper bound on |X|.  The split kernel carries every fp32 operand as two fp16 halves of s = x 2^k; with
+ *   `range` it chooses k per operand tensor so that max|s| lies in [2^13, 2^14) -- any finite weights / activations stay
+ *   inside fp16's range (a fixed k = 8 / 6 overflowed to inf/NaN beyond |w| >= 256 or |x| >= 1024).  NULL: k = 8 / 6. */
 
 /* ------------------------------------------------------------------------------------
  * Recurrent part of one LSTM layer, all T steps inside one persistent kernel, both
@@ -130,7 +135,9 @@ int lob_gate_gemm_x_f32(const float* X, int ldx, const float* Wih, const float* 
  *         when frag) for the backward kernel.
  * ---------------------------------------------------------------------------------- */
 int lob_lstm_rec_fwd_f32(float* P, const float* Whh, float* Y, float* Csave,
-                         int T, int Bp, int H, int D, int save, void* stream);
+                         int T, int Bp, int H, int D, int save, const float* range, void* stream);
+/*   range (device, may be NULL; H = 128 fp16-split kernel only): range[d] = max |W_hh| of direction d -- the weight
+ *   pre-scale is chosen from it (see lob_gate_gemm_x_f32); h needs none (|h| < 1).                                   */
 
 /* 1 if the recurrent kernels for hidden size H use the fragment layout (H = 32, 64, 128, 256:
  * MFMA kernels; W_hh register-resident at 128, streamed from L2 otherwise), 0 for the generic
@@ -368,6 +375,11 @@ int lob_abs_colsum_f32(const float* gx, int64_t rows, int C, float scale, float*
 #define LOB_PREP_MAX 64
 #define LOB_PREP_TRANSPOSE 1
 #define LOB_PREP_BF16 2
+#define LOB_PREP_ABSMAX 4   /* dst[0] (fp32) = max |src[r][c]|: the operand range of the fp16-split kernels, see `range` of
+                             * lob_gate_gemm_x_f32 / lob_lstm_rec_fwd_f32 (one workgroup; no other field of the op is used) */
+#define LOB_PREP_LNBOUND 8  /* dst[0] = (sqrt(cols) max|src| + max|src2|) * reserved / 1000: an upper bound on
+                             * |dropout(GELU(LayerNorm(.)))| from the LayerNorm's gain (src) and bias (src2) -- what the
+                             * first LSTM layer's gate GEMM can see as an activation; src == NULL: dst[0] = reserved / 1000 */
 typedef struct LobPrepOp {
     const float* src; const float* src2; void* dst;
     int rows, cols, ld_src, ld_dst, pad_to, kind, blk0 /* internal */, reserved;

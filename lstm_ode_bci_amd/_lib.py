@@ -22,9 +22,9 @@ _SIGS = {
     "lob_gemm_tn_f32": ([_f32p, C.c_int, _f32p, C.c_int, _f32p, C.c_int, C.c_int, C.c_int, C.c_int,
                          C.c_void_p], C.c_int),
     "lob_gate_gemm_x_f32": ([_f32p, C.c_int, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                             C.c_int, C.c_void_p], C.c_int),
+                             C.c_int, _f32p, C.c_void_p], C.c_int),
     "lob_lstm_rec_fwd_f32": ([_f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                              C.c_void_p], C.c_int),
+                              _f32p, C.c_void_p], C.c_int),
     "lob_layernorm_act_f32": ([_f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
                                C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_void_p], C.c_int),
     "lob_lstm_rec_bwd_f32": ([_f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, _f32p, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -76,7 +76,7 @@ class PrepOp(C.Structure):
                 ("reserved", C.c_int)]
 
 
-PREP_MAX, PREP_TRANSPOSE, PREP_BF16 = 64, 1, 2
+PREP_MAX, PREP_TRANSPOSE, PREP_BF16, PREP_ABSMAX, PREP_LNBOUND = 64, 1, 2, 4, 8
 
 
 class LobError(RuntimeError):

@@ -105,7 +105,11 @@ def _forward_impl(x, ps, cfg, save):
             w_in = img.get(("wih16", layer))
             if w_in is None:
                 w_in = wih.to(bf16)
-        P = ops.gate_gemm_x(inp, w_in, bias, T, Bp, H, D, frag, mixed=mixed)
+        # fp32 path, H = 128: operand ranges for the fp16-split kernels (images.build); without a bound on the layer's
+        # activations (nn.Identity in place of the projection LayerNorm) the gate GEMM stays on the exact-fp32 kernel
+        g_rng, r_rng = img.get(("gate_range", layer)), img.get(("rec_range", layer))
+        P = ops.gate_gemm_x(inp, w_in, bias, T, Bp, H, D, frag, mixed=mixed, range=g_rng,
+                            exact=(not mixed and g_rng is None and r_rng is not None))
         last = layer + 1 == L
         drop_here = not last and p_lstm > 0
         bf16_out = ops.can_fuse_dropout(H, mixed)        # the bf16-MFMA recurrent kernel emits bf16 copies itself
@@ -115,7 +119,7 @@ def _forward_impl(x, ps, cfg, save):
         Y, Cs, Y16, Yd = ops.lstm_rec_fwd(P, whh, T, Bp, H, D, save, mixed=mixed,
                                           drop_p=p_lstm if fuse else 0.0, seed=_seed(seed, 10 + layer),
                                           want_f32=(last and not ln_x16) or not bf16_out,
-                                          want_bf16=bf16_out and (save or not last or ln_x16), nvalid=B)
+                                          want_bf16=bf16_out and (save or not last or ln_x16), nvalid=B, range=r_rng)
         if fuse:
             nxt = Yd
         elif bf16_out and not last:

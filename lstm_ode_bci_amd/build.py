@@ -60,7 +60,8 @@ def isa_checks():
     if tools not in sys.path:
         sys.path.insert(0, tools)
     import isa_check
-    return isa_check.main() + isa_check.check_dma_gemms() + isa_check.check_gate_ws() + isa_check.check_dx_ksplit()
+    return (isa_check.main() + isa_check.check_dma_gemms() + isa_check.check_gate_ws() + isa_check.check_dx_ksplit() +
+            isa_check.check_gemm_pp())
 
 
 def build(force=False, verbose=True, check_isa=True):

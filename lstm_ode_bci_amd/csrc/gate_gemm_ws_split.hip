@@ -27,9 +27,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_cvoid;
 
-constexpr float SX = 64.f, SW = 256.f, S_LO = 2048.f;
-constexpr float R_HH = 1.f / 16384.f;        // 2^-14
-constexpr float R_SM = 1.f / 33554432.f;     // 2^-25
+constexpr float SX = 64.f, SW = 256.f, S_LO = 2048.f;      // default pre-scales (no `range`): 2^6, 2^8
 
 __device__ __forceinline__ void split2(float x, float scale, _Float16& hi, _Float16& lo) {
     const float s = x * scale;
@@ -40,6 +38,7 @@ __device__ __forceinline__ void split2(float x, float scale, _Float16& hi, _Floa
 struct WSSArgs {
     const float* A; const float* W; const float* bias; float* P;
     int lda, M, T, Bp, D;
+    const float* range;       // [D] max |W| per direction, [D] bound on |A| (lob.h); NULL: the default scales
 };
 
 template <int K>
@@ -68,6 +67,11 @@ __global__ __launch_bounds__(512, 2) void gate_gemm_ws_split_kernel(WSSArgs g) {
     if (quad >= panels) return;
     const int total = (panels - quad + nquad - 1) / nquad;
     const int ncol0 = 256 * cg + 32 * wv;                   // this wave's first gate column
+    // operand pre-scales: powers of two chosen from the operands' ranges (any finite weights / activations stay inside
+    // fp16's range); x w = r_hh hi hi + r_sm (hi lo + lo hi)
+    float sx = SX, sw = SW;
+    if (g.range) { sw = lob_split_scale(g.range[ncol0 / 512]); sx = lob_split_scale(g.range[g.D]); }
+    const float R_HH = 1.f / (sx * sw), R_SM = R_HH * (1.f / S_LO);
 
     // ---- stationary B fragments, both halves: W[ncol0 + r31][16 s + 8 hi .. + 7]
     f16x8 whi[KS], wlo[KS];
@@ -80,8 +84,8 @@ __global__ __launch_bounds__(512, 2) void gate_gemm_ws_split_kernel(WSSArgs g) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 _Float16 hh, ll;
-                split2(a[j], SW, hh, ll); h8[j] = hh; l8[j] = ll;
-                split2(b[j], SW, hh, ll); h8[4 + j] = hh; l8[4 + j] = ll;
+                split2(a[j], sw, hh, ll); h8[j] = hh; l8[j] = ll;
+                split2(b[j], sw, hh, ll); h8[4 + j] = hh; l8[4 + j] = ll;
             }
             whi[s] = h8; wlo[s] = l8;
         }
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(512, 2) void gate_gemm_ws_split_kernel(WSSArgs g) {
             for (int j = 0; j < EPT / 4; ++j) {
                 f16x4 h4, l4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { _Float16 hh, ll; split2(v[j][e], SX, hh, ll); h4[e] = hh; l4[e] = ll; }
+                for (int e = 0; e < 4; ++e) { _Float16 hh, ll; split2(v[j][e], sx, hh, ll); h4[e] = hh; l4[e] = ll; }
                 const int k = 4 * (ccs + 16 * j);                        // first element of this 4-element piece
                 const unsigned o = (unsigned)(crow * ROWH + ((((k >> 3) ^ (crow & 15)) * 16) + (k & 4) * 2));
                 asm volatile("ds_write_b64 %0, %1" :: "v"(img_b + o), "v"(h4) : "memory");
@@ -195,14 +199,14 @@ __global__ __launch_bounds__(512, 2) void gate_gemm_ws_split_kernel(WSSArgs g) {
 // Internal entry point used by lob_gate_gemm_x_f32 (gemm_f32.hip).  Preconditions checked by the caller: fp32 X / W / P,
 // fragment order, H == 128, K in {128, 256}, ldx % 4 == 0, 16-B aligned bases, Bp % 32 == 0.
 int lob_gate_gemm_ws_split(const float* X, int ldx, const float* Wih, const float* bias, float* P, int T, int Bp, int D,
-                           int K, hipStream_t s) {
+                           int K, const float* range, hipStream_t s) {
     const int M = T * Bp;
     const int ntile = (M + 31) / 32;
     const int ncg = D * 2;
     int nqx = (ntile + 7) / 8;                        // quads per XCD, one workgroup per CU at most
     const int cap = 32 / ncg;
     if (nqx > cap) nqx = cap;
-    WSSArgs g{X, Wih, bias, P, ldx, M, T, Bp, D};
+    WSSArgs g{X, Wih, bias, P, ldx, M, T, Bp, D, range};
     const dim3 grid((unsigned)(8 * ncg * nqx)), block(512);
     if (K == 256) hipLaunchKernelGGL(gate_gemm_ws_split_kernel<256>, grid, block, 0, s, g);
     else          hipLaunchKernelGGL(gate_gemm_ws_split_kernel<128>, grid, block, 0, s, g);

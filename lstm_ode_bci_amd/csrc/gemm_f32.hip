@@ -499,11 +499,11 @@ extern "C" int lob_gemm_nt_f32(const float* A, int lda, const float* W, int ldw,
 }
 
 int lob_gate_gemm_ws_split(const float* X, int ldx, const float* Wih, const float* bias, float* P, int T, int Bp, int D,
-                           int K, hipStream_t s);        // gate_gemm_ws_split.hip
+                           int K, const float* range, hipStream_t s);        // gate_gemm_ws_split.hip
 
 extern "C" int lob_gate_gemm_x_f32(const float* X, int ldx, const float* Wih, const float* bias,
                                    float* P, int T, int Bp, int H, int D, int K, int frag,
-                                   void* stream) {
+                                   const float* range, void* stream) {
     if (!X || !Wih || !P || T <= 0 || Bp <= 0 || H <= 0 || K <= 0 || (D != 1 && D != 2)) return LOB_E_ARG;
     if (ldx < K) return LOB_E_SHAPE;
     const int N = D * 4 * H;
@@ -513,9 +513,11 @@ extern "C" int lob_gate_gemm_x_f32(const float* X, int ldx, const float* Wih, co
     }
     // H = 128: fp32-accurate two-way fp16 split on the 16-bit matrix pipe, weights stationary (gate_gemm_ws_split.hip);
     // LOB_VAR_F32_SPLIT = 0 keeps the exact-fp32 MFMA kernels of this file
-    if (frag && H == 128 && (K == 128 || K == 256) && (ldx % 4) == 0 && aligned16(X) && aligned16(Wih) &&
+    // (frag & 2: the caller has no bound on |X| -- exact kernels)
+    if ((frag & 1) && !(frag & 2) && H == 128 && (K == 128 || K == 256) && (ldx % 4) == 0 && aligned16(X) && aligned16(Wih) &&
         lob_variant(LOB_VAR_F32_SPLIT) != 0)
-        return lob_gate_gemm_ws_split(X, ldx, Wih, bias, P, T, Bp, D, K, (hipStream_t)stream);
+        return lob_gate_gemm_ws_split(X, ldx, Wih, bias, P, T, Bp, D, K, range, (hipStream_t)stream);
+    frag &= 1;
     GemmNT g{X, Wih, bias, P, ldx, K, N, T * Bp, N, K, LOB_ACT_NONE, 0, T, Bp, H, D};
     return launch_nt(g, frag ? 1 : 0, (hipStream_t)stream);
 }

@@ -76,7 +76,11 @@ __device__ __forceinline__ f32x16 pp_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
 //        operands SWAPPED (D[n][m]), so a lane holds 4 consecutive columns of one row per accumulator quad.
 // EPI 1: the gate GEMM: bf16 P in the recurrent kernels' fragment order [d][t][bt][w H/32][gate 4][q pair 2][lane 64][8]
 //        (include/lob.h) + bias.
-template <int EPI>
+// ABL (diagnostic builds only, results are garbage): 1 = no operand DMA inside the loop, 2 = no fragment reads,
+// 4 = no MFMAs -- what each component costs the interval (tools/pp_bench.py abl)
+// PRIO (A/B of the priority protocol): 0 = s_setprio 1 around every MFMA cluster, 1 = no priority changes,
+// 2 = the READ / DMA segment runs at priority 1 instead
+template <int EPI, int ABL = 0, int PRIO = 0>
 __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(PPArgs g) {
     constexpr bool SWAP = EPI == 0;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * PP_OP + (EPI == 1 ? 8192 : 0)];
@@ -127,10 +131,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(PPArgs g) {
         __builtin_amdgcn_global_load_lds((gbl_cvoid*)(src + o0), (lds_void*)dst, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gbl_cvoid*)(src + o1), (lds_void*)(dst + 1024), 16, 0, 0);
     };
+    bool in_loop = false;
     auto stage_a = [&](const Cur& c, int buf, int hi_half) {
+        if ((ABL & 1) && in_loop) return;
         dma2(c.pa + (hi_half ? a_hi_b : 0), asrc[0], asrc[1], a_dst + buf * PP_OP + hi_half * 8192);
     };
     auto stage_b = [&](const Cur& c, int buf, int half) {
+        if ((ABL & 1) && in_loop) return;
         dma2(c.pb + (half ? b_h1_b : 0), bsrc[0], bsrc[1], b_dst + buf * PP_OP + half * 16384);
     };
 
@@ -165,77 +172,88 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(PPArgs g) {
     if (wr == 1) PP_BAR();             // the second group runs one barrier behind
 
     bf16x8 af[2][2], bf[2][4];
-#define PP_MMA(ACC, AF, BF) ACC = SWAP ? pp_mfma(BF, AF, ACC) : pp_mfma(AF, BF, ACC)
+    if constexpr (ABL != 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { for (int e = 0; e < 8; ++e) af[i][j][e] = (__bf16)0.f; asm volatile("" : "+v"(af[i][j])); }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { for (int e = 0; e < 8; ++e) bf[i][j][e] = (__bf16)0.f; asm volatile("" : "+v"(bf[i][j])); }
+        }
+        in_loop = true;
+    }
+#define PP_MMA(ACC, AF, BF) do { if constexpr (!(ABL & 4)) ACC = SWAP ? pp_mfma(BF, AF, ACC) : pp_mfma(AF, BF, ACC); } while (0)
 #define PP_WAIT4()                                                                                              \
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]))
+#define PP_RDA(dst, addr, OFF) do { if constexpr (!(ABL & 2)) PP_RD128(dst, addr, OFF); } while (0)
     auto ktile = [&](auto bufc) {      // one k-tile out of buffer BUF; c1 / c2 = k-tiles q + 1 / q + 2
         constexpr int BUF = decltype(bufc)::value, BO = BUF * PP_OP, NB = BUF ^ 1;
         // ---- L1 / M1
-        PP_RD128(af[0][0], aoff[0], BO);        PP_RD128(af[0][1], aoff[1], BO);
-        PP_RD128(af[1][0], aoff[0], BO + 4096); PP_RD128(af[1][1], aoff[1], BO + 4096);
-        PP_RD128(bf[0][0], boff[0], BO);        PP_RD128(bf[0][1], boff[1], BO);
-        PP_RD128(bf[1][0], boff[0], BO + 4096); PP_RD128(bf[1][1], boff[1], BO + 4096);
+        PP_RDA(af[0][0], aoff[0], BO);        PP_RDA(af[0][1], aoff[1], BO);
+        PP_RDA(af[1][0], aoff[0], BO + 4096); PP_RDA(af[1][1], aoff[1], BO + 4096);
+        PP_RDA(bf[0][0], boff[0], BO);        PP_RDA(bf[0][1], boff[1], BO);
+        PP_RDA(bf[1][0], boff[0], BO + 4096); PP_RDA(bf[1][1], boff[1], BO + 4096);
         stage_a(c1, NB, 1);
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]),
                      "+v"(bf[0][0]), "+v"(bf[0][1]), "+v"(bf[1][0]), "+v"(bf[1][1]));
         PP_BAR();
-        __builtin_amdgcn_s_setprio(1);
+        if constexpr (PRIO == 0) __builtin_amdgcn_s_setprio(1); else if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int c = 0; c < 2; ++c) PP_MMA(acc[i][c], af[i][s], bf[c][s]);
-        __builtin_amdgcn_s_setprio(0);
+        if constexpr (PRIO == 0) __builtin_amdgcn_s_setprio(0); else if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(1);
         PP_BAR();
         // ---- L2 / M2
-        PP_RD128(af[0][0], aoff[2], BO);        PP_RD128(af[0][1], aoff[3], BO);
-        PP_RD128(af[1][0], aoff[2], BO + 4096); PP_RD128(af[1][1], aoff[3], BO + 4096);
-        PP_RD128(bf[0][2], boff[2], BO);        PP_RD128(bf[0][3], boff[3], BO);
-        PP_RD128(bf[1][2], boff[2], BO + 4096); PP_RD128(bf[1][3], boff[3], BO + 4096);
+        PP_RDA(af[0][0], aoff[2], BO);        PP_RDA(af[0][1], aoff[3], BO);
+        PP_RDA(af[1][0], aoff[2], BO + 4096); PP_RDA(af[1][1], aoff[3], BO + 4096);
+        PP_RDA(bf[0][2], boff[2], BO);        PP_RDA(bf[0][3], boff[3], BO);
+        PP_RDA(bf[1][2], boff[2], BO + 4096); PP_RDA(bf[1][3], boff[3], BO + 4096);
         stage_b(c1, NB, 1);
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]),
                      "+v"(bf[0][2]), "+v"(bf[0][3]), "+v"(bf[1][2]), "+v"(bf[1][3]));
         PP_BAR();
-        __builtin_amdgcn_s_setprio(1);
+        if constexpr (PRIO == 0) __builtin_amdgcn_s_setprio(1); else if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int c = 0; c < 2; ++c) PP_MMA(acc[i][c], af[i][s], bf[c][2 + s]);
-        __builtin_amdgcn_s_setprio(0);
+        if constexpr (PRIO == 0) __builtin_amdgcn_s_setprio(0); else if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(1);
         PP_BAR();
         // ---- L3 / M3
-        PP_RD128(af[0][0], aoff[0], BO + 8192);  PP_RD128(af[0][1], aoff[1], BO + 8192);
-        PP_RD128(af[1][0], aoff[0], BO + 12288); PP_RD128(af[1][1], aoff[1], BO + 12288);
+        PP_RDA(af[0][0], aoff[0], BO + 8192);  PP_RDA(af[0][1], aoff[1], BO + 8192);
+        PP_RDA(af[1][0], aoff[0], BO + 12288); PP_RDA(af[1][1], aoff[1], BO + 12288);
         stage_a(c2, BUF, 0);
         PP_WAIT4();
         PP_BAR();
-        __builtin_amdgcn_s_setprio(1);
+        if constexpr (PRIO == 0) __builtin_amdgcn_s_setprio(1); else if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int c = 0; c < 2; ++c) PP_MMA(acc[2 + i][c], af[i][s], bf[c][s]);
-        __builtin_amdgcn_s_setprio(0);
+        if constexpr (PRIO == 0) __builtin_amdgcn_s_setprio(0); else if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(1);
         PP_BAR();
         // ---- L4 / M4
-        PP_RD128(af[0][0], aoff[2], BO + 8192);  PP_RD128(af[0][1], aoff[3], BO + 8192);
-        PP_RD128(af[1][0], aoff[2], BO + 12288); PP_RD128(af[1][1], aoff[3], BO + 12288);
+        PP_RDA(af[0][0], aoff[2], BO + 8192);  PP_RDA(af[0][1], aoff[3], BO + 8192);
+        PP_RDA(af[1][0], aoff[2], BO + 12288); PP_RDA(af[1][1], aoff[3], BO + 12288);
         stage_b(c2, BUF, 0);
         PP_WAIT4();
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // k-tile q + 1 complete (this wave's share)
         PP_BAR();
-        __builtin_amdgcn_s_setprio(1);
+        if constexpr (PRIO == 0) __builtin_amdgcn_s_setprio(1); else if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int c = 0; c < 2; ++c) PP_MMA(acc[2 + i][c], af[i][s], bf[c][2 + s]);
-        __builtin_amdgcn_s_setprio(0);
+        if constexpr (PRIO == 0) __builtin_amdgcn_s_setprio(0); else if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(1);
         PP_BAR();
         c1 = c2;
         advance(c2);
@@ -312,6 +330,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(PPArgs g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #undef PP_MMA
 #undef PP_WAIT4
+#undef PP_RDA
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -446,6 +465,314 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(TNPPArgs g) {
         }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Ring schedule.  Measured on the first schedule (tools/pp_bench.py abl, dX at B = 4096; full kernel 1.91 ms): MFMAs +
+// barriers alone 1.21 ms, fragment reads + barriers alone 0.81 ms, the operand DMA + barriers ALONE 1.66 ms -- the
+// kernel is bound by how fast 17 GB cross L2 -> LDS, and that rate was set by bytes in flight: with two buffers per
+// operand the last-staged quarter of a k-tile is requested only 4 intervals (~0.8 us) before the wait that retires
+// it.  (A schedule with 16 MFMAs per segment, i.e. 2 intervals of lead, was built and measured: 2.49 ms -- slower.)
+// Here ALL 160 KB of LDS form one ring of 16-KB slots (10: two and a half k-tiles) and every quarter of k-tile q + 2
+// is requested during k-tile q, as soon as its slot has been read: 10-14 intervals ahead, ~96 KB in flight per CU.
+//   chunks of a k-tile, in ring order: A-lo | B rows 0-127 | B rows 128-255 | A-hi  (the first three are read in the
+//   k-tile's first two segments, A-hi in the last two)
+//   L1(q): DMA A-lo(q+2)   L2(q): B-h0(q+2), then vmcnt(12): A-hi(q) landed      (read in L3 / L4)
+//   L3(q): DMA B-h1(q+2)   L4(q): A-hi(q+2), then vmcnt(10): A-lo, B of q+1 landed (read from L1(q+1) on)
+// Slot offsets rotate at run time (scalar registers; the fragment-read address registers are rebuilt once per k-tile).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int RS = 16384;            // ring slot bytes
+
+__global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(PPArgs g) {
+    constexpr int NS = 10;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * RS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int r31 = lane & 31, hi = lane >> 5;
+    const int ntn = g.N >> 8, ntm = g.M >> 8;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+    const int panels = (ntm - xcd + 7) / 8, ntile = panels * ntn;
+    if (slot >= ntile) return;
+    const int nk = g.K >> 6;
+    const int my_tiles = (ntile - slot + nslot - 1) / nslot;
+    const int last_it = slot + (my_tiles - 1) * nslot;
+    const int total = my_tiles * nk;
+
+    struct Cur { int it, kt; const char* pa; const char* pb; };
+    auto set_cur = [&](Cur& c) {
+        const int m0 = ((c.it / ntn) * 8 + xcd) << 8, n0 = (c.it % ntn) << 8;
+        c.pa = reinterpret_cast<const char*>(g.A) + ((size_t)m0 * g.lda + (size_t)c.kt * 64) * 2;
+        c.pb = reinterpret_cast<const char*>(g.W) + ((size_t)n0 * g.ldw + (size_t)c.kt * 64) * 2;
+    };
+    auto advance = [&](Cur& c) {       // next k-tile of this workgroup's sequence; past the end: stay on the last one
+        if (c.kt + 1 < nk) { ++c.kt; c.pa += 128; c.pb += 128; }
+        else if (c.it < last_it) { c.it += nslot; c.kt = 0; set_cur(c); }
+    };
+    const int l3 = lane >> 3, l7 = lane & 7;
+    unsigned asrc[2], bsrc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int ra = wr * 128 + wc * 16 + j * 8 + l3;                  // A-lo row of this lane (A-hi: + 64)
+        asrc[j] = 2u * (unsigned)(ra * g.lda + ((l7 ^ ((ra >> 1) & 7)) << 3));
+        const int rb = wave * 16 + j * 8 + l3;                           // B row inside a 128-row half
+        bsrc[j] = 2u * (unsigned)(rb * g.ldw + ((l7 ^ ((rb >> 1) & 7)) << 3));
+    }
+    const size_t a_hi_b = (size_t)64 * g.lda * 2, b_h1_b = (size_t)128 * g.ldw * 2;
+    // destination of this wave's two DMA instructions inside a slot: A chunks [wr][64 rows][128 B], B chunks [128 rows]
+    const int a_wo = wr * 8192 + wc * 2048, b_wo = wave * 2048;
+    auto dma2 = [&](const char* src, unsigned o0, unsigned o1, int slot_off, int wo) {
+        unsigned char* dst = lds + slot_off + wo;
+        __builtin_amdgcn_global_load_lds((gbl_cvoid*)(src + o0), (lds_void*)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_cvoid*)(src + o1), (lds_void*)(dst + 1024), 16, 0, 0);
+    };
+    auto wrap = [&](int so) { return so >= NS * RS ? so - NS * RS : so; };
+
+    const unsigned lds_b = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const int sw = (r31 >> 1) & 7;
+    unsigned abase[4], bbase[4];      // lane addresses inside a chunk (k-step ks); + slot offset + immediate
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        abase[ks] = lds_b + (unsigned)(wr * 8192 + r31 * 128 + (((2 * ks + hi) ^ sw) << 4));
+        bbase[ks] = lds_b + (unsigned)(((wc & 1) * 64 + r31) * 128 + (((2 * ks + hi) ^ sw) << 4));
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][c][r] = 0.f;
+
+    // ---- prologue: k-tiles 0 and 1 in ring order (slots 0..7)
+    Cur c2{slot, 0, nullptr, nullptr};
+    set_cur(c2);
+#pragma unroll 1
+    for (int t = 0; t < 2; ++t) {
+        dma2(c2.pa, asrc[0], asrc[1], (4 * t) * RS, a_wo);
+        dma2(c2.pb, bsrc[0], bsrc[1], (4 * t + 1) * RS, b_wo);
+        dma2(c2.pb + b_h1_b, bsrc[0], bsrc[1], (4 * t + 2) * RS, b_wo);
+        dma2(c2.pa + a_hi_b, asrc[0], asrc[1], (4 * t + 3) * RS, a_wo);
+        advance(c2);
+    }
+    int s0 = 0;                        // slot byte offset of the consumed k-tile's first chunk; k-tile q + 2: + 8 slots
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    PP_BAR();
+    if (wr == 1) PP_BAR();
+
+    bf16x8 af[2][2], bf[2][4];
+    unsigned alo[4], ahi[4], bb[4];
+#define PP_WAIT4()                                                                                              \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]))
+#define PP_M8(R0, K0)                                                                     \
+    do {                                                                                  \
+        __builtin_amdgcn_s_setprio(1);                                                    \
+        _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                  \
+            _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                              \
+                _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_)                          \
+                    acc[R0 + i_][c_] = pp_mfma(bf[c_][K0 + s_], af[i_][s_], acc[R0 + i_][c_]);   \
+        __builtin_amdgcn_s_setprio(0);                                                    \
+    } while (0)
+
+    int it = slot, kt = 0;
+    for (int q = 0; q < total; ++q) {
+        const int sB = wrap(s0 + (1 + (wc >> 1)) * RS), sH = wrap(s0 + 3 * RS);   // this wave's B half, A-hi
+        const int p0 = wrap(s0 + 8 * RS);                                         // first chunk of k-tile q + 2
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { alo[ks] = abase[ks] + (unsigned)s0; ahi[ks] = abase[ks] + (unsigned)sH; bb[ks] = bbase[ks] + (unsigned)sB; }
+        // ---- L1 / M1
+        PP_RD128(af[0][0], alo[0], 0);    PP_RD128(af[0][1], alo[1], 0);
+        PP_RD128(af[1][0], alo[0], 4096); PP_RD128(af[1][1], alo[1], 4096);
+        PP_RD128(bf[0][0], bb[0], 0);     PP_RD128(bf[0][1], bb[1], 0);
+        PP_RD128(bf[1][0], bb[0], 4096);  PP_RD128(bf[1][1], bb[1], 4096);
+        dma2(c2.pa, asrc[0], asrc[1], p0, a_wo);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]),
+                     "+v"(bf[0][0]), "+v"(bf[0][1]), "+v"(bf[1][0]), "+v"(bf[1][1]));
+        PP_BAR();
+        PP_M8(0, 0);
+        PP_BAR();
+        // ---- L2 / M2
+        PP_RD128(af[0][0], alo[2], 0);    PP_RD128(af[0][1], alo[3], 0);
+        PP_RD128(af[1][0], alo[2], 4096); PP_RD128(af[1][1], alo[3], 4096);
+        PP_RD128(bf[0][2], bb[2], 0);     PP_RD128(bf[0][3], bb[3], 0);
+        PP_RD128(bf[1][2], bb[2], 4096);  PP_RD128(bf[1][3], bb[3], 4096);
+        dma2(c2.pb, bsrc[0], bsrc[1], wrap(p0 + RS), b_wo);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]),
+                     "+v"(bf[0][2]), "+v"(bf[0][3]), "+v"(bf[1][2]), "+v"(bf[1][3]));
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");    // A-hi of THIS k-tile (and everything older) has landed
+        PP_BAR();
+        PP_M8(0, 2);
+        PP_BAR();
+        // ---- L3 / M3
+        PP_RD128(af[0][0], ahi[0], 0);    PP_RD128(af[0][1], ahi[1], 0);
+        PP_RD128(af[1][0], ahi[0], 4096); PP_RD128(af[1][1], ahi[1], 4096);
+        dma2(c2.pb + b_h1_b, bsrc[0], bsrc[1], wrap(p0 + 2 * RS), b_wo);
+        PP_WAIT4();
+        PP_BAR();
+        PP_M8(2, 0);
+        PP_BAR();
+        // ---- L4 / M4
+        PP_RD128(af[0][0], ahi[2], 0);    PP_RD128(af[0][1], ahi[3], 0);
+        PP_RD128(af[1][0], ahi[2], 4096); PP_RD128(af[1][1], ahi[3], 4096);
+        dma2(c2.pa + a_hi_b, asrc[0], asrc[1], wrap(p0 + 3 * RS), a_wo);
+        PP_WAIT4();
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");    // A-lo and both B halves of k-tile q + 1 have landed
+        PP_BAR();
+        PP_M8(2, 2);
+        PP_BAR();
+        advance(c2);
+        s0 = wrap(s0 + 4 * RS);
+        if (++kt < nk) continue;
+
+        // ---- epilogue of output tile `it`: row-major C, MFMA operands swapped (a lane holds 4 consecutive columns)
+        kt = 0;
+        const int m0 = ((it / ntn) * 8 + xcd) << 8, n0 = (it % ntn) << 8;
+        it += nslot;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = m0 + wr * 128 + 32 * i + r31;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const size_t o = (size_t)row * g.ldc + n0 + wc * 64 + 32 * c + 4 * hi;
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    float v0 = acc[i][c][4 * qd], v1 = acc[i][c][4 * qd + 1], v2 = acc[i][c][4 * qd + 2],
+                          v3 = acc[i][c][4 * qd + 3];
+                    if (g.drop_p > 0.f) {
+                        float d0, d1, d2, d3;
+                        lob_dropout_scale2(g.seed, (uint64_t)(o + 8 * qd), g.drop_p, d0, d1);
+                        lob_dropout_scale2(g.seed, (uint64_t)(o + 8 * qd) + 2, g.drop_p, d2, d3);
+                        v0 *= d0; v1 *= d1; v2 *= d2; v3 *= d3;
+                    }
+                    if (g.out_bf16) {
+                        bf16x4 v = {(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
+                        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(g.C) + o + 8 * qd) = v;
+                    } else {
+                        f32x4 v = {v0, v1, v2, v3};
+                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + o + 8 * qd) = v;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][c][r] = 0.f;
+            }
+        }
+    }
+    if (wr == 0) PP_BAR();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef PP_WAIT4
+#undef PP_M8
+}
+
+// TN ring: 20 slots of 8 KB (a k-quarter of one operand: 16 k-rows x 512 B); the pair (A, B) of k-quarter kq of k-tile
+// q + 2 is requested in segment kq of k-tile q (its slots were read two and a half k-tiles earlier); every segment ends
+// with the same s_waitcnt vmcnt(14): the pair the NEXT segment reads was issued 8 segments ago, 7 x 2 DMAs are younger.
+constexpr int TS = 8192;
+
+__global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(TNPPArgs g) {
+    constexpr int NS = 20;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * TS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int ntn = g.N >> 8;
+    const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+    const int tile = rest % g.tiles, chunk = (rest / g.tiles) * 8 + xcd;
+    const int m0 = (tile / ntn) << 8, n0 = (tile % ntn) << 8;
+    const int kbeg = chunk * g.kchunk, kend = min(g.Kc, kbeg + g.kchunk);
+    if (kbeg >= kend) return;
+    const int total = (kend - kbeg) >> 6;
+
+    const int kr2 = 2 * wave + (lane >> 5), ch = lane & 31;
+    const unsigned asrc = 2u * (unsigned)(kr2 * g.lda + ((ch ^ ((kr2 & 3) << 2)) << 3));
+    const unsigned bsrc = 2u * (unsigned)(kr2 * g.ldb + ((ch ^ ((kr2 & 3) << 2)) << 3));
+    const char* const a_base = reinterpret_cast<const char*>(g.A + m0);
+    const char* const b_base = reinterpret_cast<const char*>(g.B + n0);
+    unsigned char* const w_dst = lds + wave * 1024;
+    auto wrap = [&](int so) { return so >= NS * TS ? so - NS * TS : so; };
+    auto stage = [&](int p, int kq, int slot_off) {        // (A, B) k-quarter kq of k-tile p -> slots slot_off, slot_off + TS
+        const int pp = p < total ? p : total - 1;
+        const int k0 = kbeg + 64 * pp;
+        const bool ex = k0 >= g.ex_lo && k0 < g.ex_hi;
+        const char* pa = a_base + ((size_t)(k0 + 16 * kq) * g.lda) * 2;
+        const char* pb = b_base + ((size_t)(k0 + 16 * kq + (ex ? 0 : g.shift)) * g.ldb) * 2;
+        __builtin_amdgcn_global_load_lds((gbl_cvoid*)(pa + asrc), (lds_void*)(w_dst + slot_off), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_cvoid*)(pb + bsrc), (lds_void*)(w_dst + wrap(slot_off + TS)), 16, 0, 0);
+    };
+
+    const int fh = lane >> 5, fmh = (lane >> 4) & 1, fq = (lane >> 2) & 3, fp = lane & 3;
+    const unsigned lds_b = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const unsigned frow = (unsigned)((8 * fh + fq) * 512 + 2 * (16 * fmh + 4 * fp));
+    const unsigned a0 = lds_b + frow + 2u * (unsigned)(wr * 128 + 32 * fq);
+    const unsigned b0 = lds_b + frow + 2u * (unsigned)((wc * 64) ^ (32 * fq));
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][c][r] = 0.f;
+
+    // prologue: k-tiles 0 and 1 (slots 0..15), then the pair the first segment reads must have landed
+#pragma unroll 1
+    for (int t = 0; t < 2; ++t)
+#pragma unroll 1
+        for (int kq = 0; kq < 4; ++kq) stage(t, kq, (8 * t + 2 * kq) * TS);
+    int s0 = 0;
+    asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+    PP_BAR();
+    if (wr == 1) PP_BAR();
+
+    bf16x4 al[4], ah[4], bl[2], bh[2];
+#define PP_FRAG(l, h) bf16x8{l[0], l[1], l[2], l[3], h[0], h[1], h[2], h[3]}
+    for (int q = 0; q < total; ++q) {
+        const int k0 = kbeg + 64 * q;
+        const bool on = !(k0 >= g.ex_lo && k0 < g.ex_hi);
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {
+            const int sa = wrap(s0 + 2 * kq * TS), sb = wrap(sa + TS);
+            const unsigned va = a0 + (unsigned)sa, vb = b0 + (unsigned)sb;
+            unsigned av[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) av[i] = va ^ (unsigned)(i << 6);
+            const unsigned bv0 = vb, bv1 = vb ^ 64u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { PP_TR(al[i], av[i], 0); PP_TR(ah[i], av[i], 2048); }
+            PP_TR(bl[0], bv0, 0); PP_TR(bh[0], bv0, 2048);
+            PP_TR(bl[1], bv1, 0); PP_TR(bh[1], bv1, 2048);
+            stage(q + 2, kq, wrap(s0 + (16 + 2 * kq) * TS));
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(al[0]), "+v"(ah[0]), "+v"(al[1]), "+v"(ah[1]), "+v"(al[2]), "+v"(ah[2]),
+                         "+v"(al[3]), "+v"(ah[3]), "+v"(bl[0]), "+v"(bh[0]), "+v"(bl[1]), "+v"(bh[1]));
+            asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+            PP_BAR();
+            if (on) {
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) acc[i][c] = pp_mfma(PP_FRAG(al[i], ah[i]), PP_FRAG(bl[c], bh[c]), acc[i][c]);
+                __builtin_amdgcn_s_setprio(0);
+            }
+            PP_BAR();
+        }
+        s0 = wrap(s0 + 8 * TS);
+    }
+    if (wr == 0) PP_BAR();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef PP_FRAG
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int col = n0 + wc * 64 + 32 * c + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wr * 128 + 32 * i + acc_row(r, lane);
+                atomicAdd(g.C + (size_t)row * g.ldc + col, acc[i][c][r]);
+            }
+        }
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 inline int pp_grid(int M, int N) {          // persistent: one workgroup per CU, a multiple of 8 for the XCD map
@@ -471,7 +798,25 @@ int lob_gemm_nt_pp(const void* A, int lda, const void* Wt, int ldw, void* C, int
     // 32-bit lane offsets of the DMA sources
     if ((long)256 * lda * 2 >= (1L << 31) || (long)256 * ldw * 2 >= (1L << 31)) return LOB_E_SHAPE;
     PPArgs g{(const __bf16*)A, (const __bf16*)Wt, C, nullptr, lda, ldw, ldc, M, N, K, 0, 0, 0, out_bf16, drop_p, seed};
-    hipLaunchKernelGGL((gemm_nt_pp_kernel<0>), dim3((unsigned)pp_grid(M, N)), dim3(512), 0, s, g);
+    if (lob_variant(LOB_VAR_GEMM_PP) & 8) hipLaunchKernelGGL(gemm_nt_ring_kernel, dim3((unsigned)pp_grid(M, N)), dim3(512), 0, s, g);
+    else {
+        const dim3 gr((unsigned)pp_grid(M, N)), bl(512);
+        switch ((lob_variant(LOB_VAR_GEMM_PP) >> 4) & 7) {         // diagnostic ablations (tools/pp_bench.py abl)
+            case 1: hipLaunchKernelGGL((gemm_nt_pp_kernel<0, 1>), gr, bl, 0, s, g); break;
+            case 2: hipLaunchKernelGGL((gemm_nt_pp_kernel<0, 2>), gr, bl, 0, s, g); break;
+            case 3: hipLaunchKernelGGL((gemm_nt_pp_kernel<0, 3>), gr, bl, 0, s, g); break;
+            case 4: hipLaunchKernelGGL((gemm_nt_pp_kernel<0, 4>), gr, bl, 0, s, g); break;
+            case 5: hipLaunchKernelGGL((gemm_nt_pp_kernel<0, 5>), gr, bl, 0, s, g); break;
+            case 6: hipLaunchKernelGGL((gemm_nt_pp_kernel<0, 6>), gr, bl, 0, s, g); break;
+            case 7: hipLaunchKernelGGL((gemm_nt_pp_kernel<0, 7>), gr, bl, 0, s, g); break;
+            default:
+                switch ((lob_variant(LOB_VAR_GEMM_PP) >> 7) & 3) {
+                    case 1: hipLaunchKernelGGL((gemm_nt_pp_kernel<0, 0, 1>), gr, bl, 0, s, g); break;
+                    case 2: hipLaunchKernelGGL((gemm_nt_pp_kernel<0, 0, 2>), gr, bl, 0, s, g); break;
+                    default: hipLaunchKernelGGL((gemm_nt_pp_kernel<0>), gr, bl, 0, s, g);
+                }
+        }
+    }
     LOB_CHECK_LAUNCH();
     return 0;
 }
@@ -508,7 +853,8 @@ int lob_gemm_tn_pp(const void* A, int lda, const void* B, int ldb, float* C, int
     nchunk = (int)((Kc + kchunk - 1) / kchunk);
     const int nchunk8 = ((nchunk + 7) / 8) * 8;
     TNPPArgs g{(const __bf16*)A, (const __bf16*)B, C, lda, ldb, ldc, M, N, Kc, (int)kchunk, tiles, shift, ex_lo, ex_hi};
-    hipLaunchKernelGGL(gemm_tn_pp_kernel, dim3((unsigned)(tiles * nchunk8)), dim3(512), 0, s, g);
+    if (lob_variant(LOB_VAR_GEMM_PP) & 8) hipLaunchKernelGGL(gemm_tn_ring_kernel, dim3((unsigned)(tiles * nchunk8)), dim3(512), 0, s, g);
+    else                                  hipLaunchKernelGGL(gemm_tn_pp_kernel, dim3((unsigned)(tiles * nchunk8)), dim3(512), 0, s, g);
     LOB_CHECK_LAUNCH();
     return 0;
 }

@@ -106,6 +106,16 @@ __device__ __forceinline__ void lob_dropout_scale2(uint64_t seed, uint64_t idx_e
     s1 = (h >> 16) >= thr ? keep : 0.0f;
 }
 
+// Power-of-two pre-scale of an fp32 operand tensor for the two-way fp16 split (gate_gemm_ws_split.hip,
+// lstm_rec_f32_split.hip): the largest 2^k with amax * 2^k < 2^14, k clamped to [-60, 20].  hi = fp16(s) then has
+// |hi| <= 2^14 and lo = (s - hi) 2^11 has |lo| <= 2^14 as well: both halves inside fp16's range for ANY finite operand.
+__device__ __forceinline__ float lob_split_scale(float amax) {
+    const int e = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 255u) - 127;      // floor(log2(amax)), normal numbers
+    int k = 13 - e;
+    k = k < -60 ? -60 : (k > 20 ? 20 : k);
+    return __builtin_bit_cast(float, (unsigned)(k + 127) << 23);
+}
+
 // LDS read that the compiler cannot see (inline asm): used next to in-flight LDS-DMA (global_load_lds),
 // where an ordinary LDS read of ANOTHER region makes hipcc drain the whole DMA queue (s_waitcnt vmcnt(0))
 // because it cannot prove the regions disjoint.  The caller guarantees the word is not a DMA target.

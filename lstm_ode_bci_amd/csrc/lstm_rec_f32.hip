@@ -20,7 +20,8 @@
 
 // H = 128 on 16-row sub-tiles / v_mfma_f32_16x16x4_f32 (lstm_rec_f32_s16.hip)
 int lob_rec_fwd_s16(float* P, const float* Whh, float* Y, float* Csave, int T, int Bp, int D, int save, hipStream_t s);
-int lob_rec_fwd_split(float* P, const float* Whh, float* Y, float* Csave, int T, int Bp, int D, int save, hipStream_t s);
+int lob_rec_fwd_split(float* P, const float* Whh, float* Y, float* Csave, int T, int Bp, int D, int save, const float* range,
+                      hipStream_t s);
 // H = 32 / 64 / 256: W_hh streamed from L2 (lstm_rec_stream.hip)
 int lob_stream_supports(int H);
 int lob_stream_fwd(float* P, const float* Whh, float* Y, float* Csave, int T, int Bp, int H, int D, int save, hipStream_t s);
@@ -453,7 +454,7 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_generic_kernel(
 }  // namespace
 
 extern "C" int lob_lstm_rec_fwd_f32(float* P, const float* Whh, float* Y, float* Csave,
-                                    int T, int Bp, int H, int D, int save, void* stream) {
+                                    int T, int Bp, int H, int D, int save, const float* range, void* stream) {
     if (!P || !Whh || !Y || T <= 0 || Bp <= 0 || H <= 0 || (D != 1 && D != 2)) return LOB_E_ARG;
     if (save && !Csave) return LOB_E_ARG;
     hipStream_t s = (hipStream_t)stream;
@@ -465,7 +466,7 @@ extern "C" int lob_lstm_rec_fwd_f32(float* P, const float* Whh, float* Y, float*
         // B = 4096; LOB_REC_FWD=32 selects the 32-row kernel below (kept for A/B measurements)
         // default: the fp32-accurate split kernel on the 16-bit matrix pipe (lstm_rec_f32_split.hip);
         // LOB_VAR_F32_SPLIT = 0 selects the exact-fp32 MFMA kernels (16-row, or 32-row with LOB_VAR_REC_FWD_ROWS = 32)
-        if (lob_variant(LOB_VAR_F32_SPLIT) != 0) return lob_rec_fwd_split(P, Whh, Y, Csave, T, Bp, D, save, s);
+        if (lob_variant(LOB_VAR_F32_SPLIT) != 0) return lob_rec_fwd_split(P, Whh, Y, Csave, T, Bp, D, save, range, s);
         const bool rows32 = lob_variant(LOB_VAR_REC_FWD_ROWS) == 32;
         if (!rows32) return lob_rec_fwd_s16(P, Whh, Y, Csave, T, Bp, D, save, s);
         const dim3 grid(Bp / 32, D), block(256);

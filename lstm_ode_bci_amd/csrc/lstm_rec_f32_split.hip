@@ -29,11 +29,9 @@ constexpr int HB_LD = 136;     // fp16 h tile row stride (272 B = 17 x 16 B, odd
 constexpr int YF_LD = 132;     // fp32 h staging row stride (528 B = 33 x 16 B)
 constexpr float S_OP = 256.f;              // operand pre-scale 2^8
 constexpr float S_LO = 2048.f;             // residual scale 2^11
-constexpr float R_HH = 1.f / 65536.f;      // 2^-16
-constexpr float R_SM = 1.f / 134217728.f;  // 2^-27
 
-__device__ __forceinline__ void split2(float x, _Float16& hi, _Float16& lo) {
-    const float s = x * S_OP;
+__device__ __forceinline__ void split2(float x, _Float16& hi, _Float16& lo, float scale = S_OP) {
+    const float s = x * scale;
     hi = (_Float16)s;
     lo = (_Float16)((s - (float)hi) * S_LO);
 }
@@ -44,7 +42,8 @@ __device__ __forceinline__ f32x4 mfma16_f16(f16x8 a, f16x8 b, f32x4 c) {
 
 template <bool SAVE>
 __global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h128_split_kernel(
-    float* __restrict__ P, const float* __restrict__ Whh, float* __restrict__ Y, float* __restrict__ Csave, int T, int Bp) {
+    float* __restrict__ P, const float* __restrict__ Whh, float* __restrict__ Y, float* __restrict__ Csave, int T, int Bp,
+    const float* __restrict__ range) {
     __shared__ __attribute__((aligned(16))) _Float16 hs[2 * 2 * 16 * HB_LD];      // [buf][split][16 rows][HB_LD]
     __shared__ __attribute__((aligned(16))) float yfs[2 * 16 * YF_LD];            // fp32 h of the step, for wide stores
     const int tid = threadIdx.x, lane = tid & 63;
@@ -55,6 +54,10 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h128_split_kernel(
     const int bt = blockIdx.x >> 1, s0 = blockIdx.x & 1;      // 32-row fragment block, 16-row half
     const int col = 32 * wcol + 16 * cbu + c16;               // this lane's hidden column
 
+    // weight pre-scale from the range of this direction's W_hh (lob.h; h keeps 2^8: |h| < 1);
+    // h w = R_HH hi hi + R_SM (hi lo + lo hi)
+    const float sw = range ? lob_split_scale(range[d]) : S_OP;
+    const float R_HH = 1.f / (S_OP * sw), R_SM = R_HH * (1.f / S_LO);
     // B fragments: W_hh[g*128 + col][32 ks + 8 rq .. + 7], split
     f16x8 whi[4][4], wlo[4][4];
     {
@@ -69,8 +72,8 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h128_split_kernel(
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     _Float16 hh, ll;
-                    split2(a[j], hh, ll); h8[j] = hh; l8[j] = ll;
-                    split2(b[j], hh, ll); h8[4 + j] = hh; l8[4 + j] = ll;
+                    split2(a[j], hh, ll, sw); h8[j] = hh; l8[j] = ll;
+                    split2(b[j], hh, ll, sw); h8[4 + j] = hh; l8[4 + j] = ll;
                 }
                 whi[g][ks] = h8; wlo[g][ks] = l8;
                 __builtin_amdgcn_sched_barrier(0);
@@ -166,10 +169,11 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h128_split_kernel(
 }  // namespace
 
 // Internal entry point used by lob_lstm_rec_fwd_f32 (lstm_rec_f32.hip): 16-row tiles, eight waves, grid Bp/16 x D.
-int lob_rec_fwd_split(float* P, const float* Whh, float* Y, float* Csave, int T, int Bp, int D, int save, hipStream_t s) {
+int lob_rec_fwd_split(float* P, const float* Whh, float* Y, float* Csave, int T, int Bp, int D, int save, const float* range,
+                      hipStream_t s) {
     const dim3 grid(Bp / 16, D), block(512);
-    if (save) hipLaunchKernelGGL((lstm_rec_fwd_h128_split_kernel<true>), grid, block, 0, s, P, Whh, Y, Csave, T, Bp);
-    else      hipLaunchKernelGGL((lstm_rec_fwd_h128_split_kernel<false>), grid, block, 0, s, P, Whh, Y, Csave, T, Bp);
+    if (save) hipLaunchKernelGGL((lstm_rec_fwd_h128_split_kernel<true>), grid, block, 0, s, P, Whh, Y, Csave, T, Bp, range);
+    else      hipLaunchKernelGGL((lstm_rec_fwd_h128_split_kernel<false>), grid, block, 0, s, P, Whh, Y, Csave, T, Bp, range);
     LOB_CHECK_LAUNCH();
     return 0;
 }

@@ -23,6 +23,20 @@ class _Plan:
     def __init__(self, dev):
         self.dev, self.items, self.keep = dev, [], []
 
+    def add_range(self, dst, off, src=None, src2=None, lnbound=False, factor=1.0):
+        """dst[off] <- max |src| (lnbound=False) or the LayerNorm-derived activation bound (lnbound=True; src = gain,
+        src2 = bias, both may be None: bound = factor) -- the operand ranges of the fp16-split kernels (include/lob.h)."""
+        rows = cols = 1
+        if src is not None:
+            src = src.detach()
+            assert src.is_contiguous() and src.dtype == torch.float32 and src.dim() <= 2
+            rows, cols = (1, src.shape[0]) if src.dim() == 1 else src.shape
+        kind = _lib.PREP_LNBOUND if lnbound else _lib.PREP_ABSMAX
+        op = _lib.PrepOp(0 if src is None else src.data_ptr(), 0 if src2 is None else src2.detach().data_ptr(),
+                         dst.data_ptr() + off * 4, rows, cols, cols, 1, 0, kind, 0, int(round(factor * 1000)))
+        self.items.append(op)
+        self.keep.append((src, src2, dst))
+
     def add(self, src, dst, dst_ptr_off=0, ld_dst=None, src2=None, transpose=False, pad_to=0):
         """dst (a fresh tensor; dst_ptr_off in ELEMENTS selects a row / column block of it) <- src [rows, cols]."""
         src = src.detach()
@@ -57,7 +71,7 @@ def act_is_bf16(layer, cfg, frag):
 
 def build(ps, cfg, x_shape, need_grad):
     """ps: parameters in ``autograd._collect`` order (fp32, contiguous, detached).  Returns {key: tensor}."""
-    L, D, H, _, _, mixed = cfg
+    L, D, H, (p_in, p_lstm, _p_cls), _, mixed = cfg
     B, T, Cc = x_shape
     Bp = ops.ceil32(B)
     rows = T * Bp
@@ -75,6 +89,13 @@ def build(ps, cfg, x_shape, need_grad):
         Cp = (Cc + 7) // 8 * 8
         img["wpad"] = new((proj_w.shape[0], Cp))
         plan.add(proj_w, img["wpad"], pad_to=Cp)
+    # fp32 path at H = 128: the fp16-split kernels take the range of each operand tensor (max |W_ih| / |W_hh| per
+    # direction, a bound on the activations) and choose their pre-scales from it -- a checkpoint with a large weight or
+    # LayerNorm gain stays finite and accurate.  Layer 0's activations are dropout(GELU(LayerNorm(.))): bounded by
+    # sqrt(H) max|gain| + max|bias| (no bound with nn.Identity in its place: that layer's GEMM runs exact); the other
+    # layers see |h| < 1 (times the dropout scale in train mode).
+    want_range = bool(not mixed and frag and H == 128 and _lib.get_variant("F32_SPLIT") != 0)
+    rng = new((L * (2 * D + 1),)) if want_range else None
     base = 4
     for layer in range(L):
         dirs = [ps[base + 4 * d: base + 4 * d + 4] for d in range(D)]
@@ -91,6 +112,20 @@ def build(ps, cfg, x_shape, need_grad):
         if need_grad:
             wt16 = bool(mixed and ops.dma_ok(N, K, rows))
             wt = new((K, N), bf16 if wt16 else f32)
+        if rng is not None:
+            r0 = layer * (2 * D + 1)
+            for d, (w_ih, w_hh, _bi, _bh) in enumerate(dirs):
+                plan.add_range(rng, r0 + d, w_ih)
+                plan.add_range(rng, r0 + D + 1 + d, w_hh)
+            if layer == 0:
+                if ps[2] is not None:
+                    plan.add_range(rng, r0 + D, ps[2], ps[3], lnbound=True, factor=1.0 / (1.0 - p_in) if p_in < 1 else 1.0)
+                    img[("gate_range", 0)] = rng[r0:r0 + D + 1]
+                # else: no LayerNorm in front (ablation variant) -> no bound -> autograd runs this GEMM exact
+            else:
+                plan.add_range(rng, r0 + D, lnbound=True, factor=1.0 / (1.0 - p_lstm) if p_lstm < 1 else 1.0)
+                img[("gate_range", layer)] = rng[r0:r0 + D + 1]
+            img[("rec_range", layer)] = rng[r0 + D + 1:r0 + 2 * D + 1]
         for d, (w_ih, w_hh, b_ih, b_hh) in enumerate(dirs):
             plan.add(w_ih, wih, dst_ptr_off=d * 4 * H * K)
             if w16 is not None:

@@ -217,9 +217,13 @@ def bf16_rec(H, p16=True):
     return H == 128 or (H == 256 and bool(p16))
 
 
-def gate_gemm_x(x, wih, bias, T, Bp, H, D, frag, mixed=False):
+def gate_gemm_x(x, wih, bias, T, Bp, H, D, frag, mixed=False, range=None, exact=False):
     """P = x[T*Bp,K] @ wih[D*4H,K]^T + bias, fragment order when frag.  In mixed mode at H == 128 / 256 P is
-    bf16 when ``ops.PG_BF16`` (it is only ever read by the bf16 recurrent kernel)."""
+    bf16 when ``ops.PG_BF16`` (it is only ever read by the bf16 recurrent kernel).
+    fp32 path, H == 128: ``range`` (D + 1 floats on the device: max |W_ih| per direction, a bound on |x|; see
+    ``images.build``) lets the fp16-split kernel choose its operand pre-scales; ``exact=True`` keeps the exact-fp32 MFMA
+    kernel (activations without a known bound)."""
+    _chk(range, "range")
     x16 = x.dtype == torch.bfloat16
     w16 = wih.dtype == torch.bfloat16
     _chk(x, "x", x.dtype if x16 else torch.float32); _chk(wih, "wih", wih.dtype if w16 else torch.float32)
@@ -239,7 +243,7 @@ def gate_gemm_x(x, wih, bias, T, Bp, H, D, frag, mixed=False):
     if x16:
         raise _lib.LobError("gate_gemm_x: bf16 input with a shape the bf16 kernel does not support")
     rc = _lib.lib().lob_gate_gemm_x_f32(_ptr(x), K, _ptr(wih), _ptr(bias), _ptr(P), T, Bp, H, D, K,
-                                        1 if frag else 0, _stream())
+                                        (1 if frag else 0) | (2 if exact else 0), _ptr(range), _stream())
     _lib.check(rc, "lob_gate_gemm_x_f32")
     return P
 
@@ -250,11 +254,14 @@ def can_fuse_dropout(H, mixed):
     return bool(mixed) and bf16_rec(H, PG_BF16)
 
 
-def lstm_rec_fwd(P, whh, T, Bp, H, D, save, mixed=False, drop_p=0.0, seed=0, want_f32=True, want_bf16=False, nvalid=0):
+def lstm_rec_fwd(P, whh, T, Bp, H, D, save, mixed=False, drop_p=0.0, seed=0, want_f32=True, want_bf16=False, nvalid=0,
+                 range=None):
     """Runs the persistent recurrent kernel; returns (Y fp32 or None, Csave or None, Y16 or None, Yd or None).
     mixed: h W_hh^T on bf16 MFMA (H == 128), everything else fp32.  With can_fuse_dropout: want_bf16 adds
     Y16 = bf16(Y); drop_p > 0 adds Yd = bf16(dropout(Y)); want_f32=False skips the fp32 Y.
-    nvalid: how many of the Bp rows carry windows (0 = all): lets a one-window inference call skip the padding rows."""
+    nvalid: how many of the Bp rows carry windows (0 = all): lets a one-window inference call skip the padding rows.
+    range (fp32 path, H == 128): D floats on the device, max |W_hh| per direction (the fp16-split kernel's pre-scale)."""
+    _chk(range, "range")
     p16 = P.dtype == torch.bfloat16
     _chk(P, "P", P.dtype if p16 else torch.float32); _chk(whh, "whh")
     assert whh.shape == (D, 4 * H, H)
@@ -281,7 +288,7 @@ def lstm_rec_fwd(P, whh, T, Bp, H, D, save, mixed=False, drop_p=0.0, seed=0, wan
         assert drop_p == 0 and not p16 and not want_bf16
         Y = torch.empty((T * Bp, D * H), device=dev, dtype=torch.float32)
         rc = _lib.lib().lob_lstm_rec_fwd_f32(_ptr(P), _ptr(whh), _ptr(Y), _ptr(Cs), T, Bp, H, D, 1 if save else 0,
-                                             _stream())
+                                             _ptr(range), _stream())
     _lib.check(rc, "lob_lstm_rec_fwd")
     return Y, Cs, Y16, Yd
 

@@ -21,24 +21,39 @@ def shard_bounds(n, world, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def all_gather_rows(local, n_total, group=None):
-    """Collate per-rank row blocks (split as in ``shard_bounds``) into the full (n_total, ...)
-    tensor on every rank.  Uneven shards are padded to the largest shard for the collective."""
+def all_gather_rows(local, n_total, group=None, bounds=None):
+    """Collate per-rank row blocks into the full (n_total, ...) tensor on every rank.  The blocks are split as in
+    ``shard_bounds`` unless ``bounds`` ([(lo, hi)] per rank, contiguous, in rank order) says otherwise.  Uneven shards
+    are padded to the largest shard for the collective."""
     world = dist.get_world_size(group)
     if world == 1:
         return local
-    per = (n_total + world - 1) // world
+    if bounds is None:
+        bounds = [shard_bounds(n_total, world, r) for r in range(world)]
+    per = max(h - l for l, h in bounds)
     pad = per - local.shape[0]
     buf = local if pad == 0 else torch.cat([local, local.new_zeros((pad,) + tuple(local.shape[1:]))], 0)
     out = local.new_empty((world * per,) + tuple(local.shape[1:]))
     dist.all_gather_into_tensor(out, buf.contiguous(), group=group)
-    if n_total % world == 0:
+    if all(h - l == per for l, h in bounds):
         return out
-    parts = []
-    for r in range(world):
-        lo, hi = shard_bounds(n_total, world, r)
-        parts.append(out[r * per:r * per + (hi - lo)])
-    return torch.cat(parts, 0)
+    return torch.cat([out[r * per:r * per + (h - l)] for r, (l, h) in enumerate(bounds)], 0)
+
+
+def gather_shard_sizes(n_local, group=None, device=None):
+    """[(lo, hi)] of every rank's shard in the concatenation of all shards (rank order), from each rank's own count."""
+    world = dist.get_world_size(group)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    t = torch.tensor([int(n_local)], dtype=torch.int64, device=device)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t, group=group)
+    sizes = [int(o.item()) for o in out]
+    bounds, lo = [], 0
+    for sz in sizes:
+        bounds.append((lo, lo + sz))
+        lo += sz
+    return bounds
 
 
 def sharded_apply(X, fn, group=None):
@@ -54,10 +69,15 @@ def sharded_apply(X, fn, group=None):
 
 
 def predict_batch_sharded(integ, X_batch, forecast_steps=20, batch_size=512, gather_trajectories=True, group=None,
-                          overlap=True):
+                          overlap=True, local_shard=False):
     """``LSTMODEIntegration.predict_batch`` over all ranks of the default process group.
     Returns device tensors (trajectories (N,steps,3) f64 | None, probs (N,2) f32, predictions (N,) i64),
     identical on every rank and bit-identical to the single-GPU result.
+
+    ``local_shard=False``: every rank passes ALL N windows and takes its slice (``shard_bounds``) -- simple, but each
+    rank's host holds the whole array (4 GB at N = 65,536).  ``local_shard=True``: every rank passes ONLY ITS OWN windows
+    (any count, also 0); the result rows are the concatenation of the shards in rank order; per-rank host memory is the
+    shard alone (512 MB at 8,192 windows per rank).
 
     What overlaps what (``overlap=True``, device tensors): the shard is processed in device chunks; the all-gather of
     chunk c's trajectories -- the only message that is bandwidth-relevant (29.5 MB per rank and 4096 windows at 300
@@ -67,8 +87,14 @@ def predict_batch_sharded(integ, X_batch, forecast_steps=20, batch_size=512, gat
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return integ.predict_batch_device(X_batch, forecast_steps, batch_size, want_traj=gather_trajectories)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    n = len(X_batch)
-    bounds = [shard_bounds(n, world, r) for r in range(world)]
+    if local_shard:
+        bounds = gather_shard_sizes(len(X_batch), group)
+        n = bounds[-1][1]
+        x_off = bounds[rank][0]                                  # X_batch holds global rows [x_off, x_off + len)
+    else:
+        n = len(X_batch)
+        bounds = [shard_bounds(n, world, r) for r in range(world)]
+        x_off = 0
     lo, hi = bounds[rank]
     per = max(h - l for l, h in bounds)                          # largest shard: every rank walks the same chunk grid
     chunk = integ._chunk(batch_size, False) if hasattr(integ, "_chunk") else max(int(batch_size), 1)
@@ -80,8 +106,8 @@ def predict_batch_sharded(integ, X_batch, forecast_steps=20, batch_size=512, gat
         len_c = min(chunk, per - c)
         a, b = min(lo + c, hi), min(lo + c + len_c, hi)
         if b > a:
-            traj, probs, pred = integ.predict_batch_device(X_batch[a:b], forecast_steps, max(len_c, int(batch_size)),
-                                                           want_traj=gather_trajectories)
+            traj, probs, pred = integ.predict_batch_device(X_batch[a - x_off:b - x_off], forecast_steps,
+                                                           max(len_c, int(batch_size)), want_traj=gather_trajectories)
             probs_loc.append(probs)
             pred_loc.append(pred)
         else:
@@ -126,7 +152,7 @@ def predict_batch_sharded(integ, X_batch, forecast_steps=20, batch_size=512, gat
         dev = _traj_proto(integ, X_batch, forecast_steps).device
         probs_l = torch.empty((0, 2), dtype=torch.float32, device=dev)
         pred_l = torch.empty((0,), dtype=torch.int64, device=dev)
-    return traj_full, all_gather_rows(probs_l, n, group), all_gather_rows(pred_l, n, group)
+    return traj_full, all_gather_rows(probs_l, n, group, bounds), all_gather_rows(pred_l, n, group, bounds)
 
 
 def _traj_proto(integ, X_batch, forecast_steps):

@@ -121,3 +121,34 @@ def test_data_parallel_train_model_syncs_start_state_and_class_weights(tmp_path)
     assert np.array_equal(r0["train_loss"], r1["train_loss"]) and np.array_equal(r0["val_f1"], r1["val_f1"])
     assert np.isfinite(r0["w1"]).all() and not np.array_equal(r0["w1"], r0["w0"])
     assert int(r0["pickled"]) > 0
+
+
+@pytest.mark.parametrize("mode", ["train", "fwd"])
+def test_bench_py_two_ranks_under_torch_distributed_run(tmp_path, mode):
+    """The command the driver launches for N > 1 (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N
+    ...`), rehearsed on a one-GPU box: a fresh child (started before it touches the GPU), both ranks on cuda:0
+    (LOB_SHARE_GPU=1), collectives through gloo.  Checks the contract line: n_gpus, global batch, the collective the
+    step ends with, a finite whole-job value, weak scaling."""
+    import json
+    import math
+    port = _free_port()
+    env = dict(os.environ, LOB_DIST_BACKEND="gloo", LOB_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--mode", mode]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                  # rank 0 prints ONE JSON line
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 2 and res["warmup"] == 1
+    assert res["scaling"] == "weak" and res["higher_is_better"] is True and res["unit"] == "windows/s"
+    cfg = res["config"]
+    assert cfg["global_batch"] == 2 * cfg["batch_per_gpu"] == 2 * 4096
+    assert cfg["collective"] == ("all_reduce(grads 4.55MB)" if mode == "train" else "all_gather(logits)")
+    assert math.isfinite(res["value"]) and res["value"] > 0
+    # whole-job value: both ranks' windows over the slowest rank's time
+    assert abs(res["value"] - 2 * 4096 * 2 / (res["ms_per_step"] * 2 * 1e-3)) <= 1e-6 * res["value"]
+    assert "cpu_baseline" not in res and "roofline" in res

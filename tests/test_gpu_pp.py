@@ -34,12 +34,14 @@ def _ref_nt(a, w):
 @pytest.mark.parametrize("M,N,K", [(256, 256, 2048), (512, 512, 2048), (2304, 512, 1024), (256 * 70, 256, 2048),
                                    (256 * 9, 768, 1152)])
 @pytest.mark.parametrize("out_bf16", [True, False])
-def test_nt_pp_small_shapes_vs_float64(dev, M, N, K, out_bf16):
-    """dX-shaped products through lob_gemm_nt_bf16 (K >= 1024 routes to the ping-pong kernel)."""
+@pytest.mark.parametrize("PP", [7, 15])
+def test_nt_pp_small_shapes_vs_float64(dev, M, N, K, out_bf16, PP):
+    """dX-shaped products through lob_gemm_nt_bf16 (K >= 1024 routes to the ping-pong kernel; PP = 15: the schedule with
+    16-MFMA segments and the triple-buffered A half)."""
     from lstm_ode_bci_amd import _lib, ops
     a = _rand((M, K), dev, 1, 1.0, torch.bfloat16)
     w = _rand((N, K), dev, 2, 0.05, torch.bfloat16)
-    with _lib.variant(GEMM_PP=7):
+    with _lib.variant(GEMM_PP=PP):
         c = ops.gemm_nt(a, w, mixed=True, out_bf16=out_bf16)
         c2 = ops.gemm_nt(a, w, mixed=True, out_bf16=out_bf16)
     ref = _ref_nt(a, w)
@@ -68,7 +70,8 @@ def test_nt_pp_dropout_epilogue_matches_standalone_mask(dev):
 
 
 @pytest.mark.parametrize("T,Bp,K", [(8, 32, 512), (8, 64, 256), (24, 96, 512), (256, 32, 512)])
-def test_gate_pp_small_shapes_vs_weight_stationary(dev, T, Bp, K):
+@pytest.mark.parametrize("PP", [7, 15])
+def test_gate_pp_small_shapes_vs_weight_stationary(dev, T, Bp, K, PP):
     """Fragment-order P of the H = 256 gate GEMM: ping-pong kernel against the weight-stationary twin (bit-identical:
     same MFMA, same k order, bias added last) and against a float64 product through the recurrent kernel's layout."""
     from lstm_ode_bci_amd import _lib, ops
@@ -76,7 +79,7 @@ def test_gate_pp_small_shapes_vs_weight_stationary(dev, T, Bp, K):
     x = _rand((T * Bp, K), dev, 5, 1.0, torch.bfloat16)
     w = _rand((D * 4 * H, K), dev, 6, 0.05, torch.bfloat16)
     bias = _rand((D * 4 * H,), dev, 7, 0.1)
-    with _lib.variant(GEMM_PP=7):
+    with _lib.variant(GEMM_PP=PP):
         p_pp = ops.gate_gemm_x(x, w, bias, T, Bp, H, D, True, mixed=True)
     with _lib.variant(GEMM_PP=0, GATE_WS=1):
         p_ws = ops.gate_gemm_x(x, w, bias, T, Bp, H, D, True, mixed=True)
@@ -97,11 +100,12 @@ def test_gate_pp_small_shapes_vs_weight_stationary(dev, T, Bp, K):
 
 
 @pytest.mark.parametrize("M,N,Kc", [(256, 256, 1024), (512, 256, 2048 + 128), (1024, 512, 4096), (2048, 512, 16384)])
-def test_tn_pp_small_shapes_vs_float64(dev, M, N, Kc):
+@pytest.mark.parametrize("PP", [7, 15])
+def test_tn_pp_small_shapes_vs_float64(dev, M, N, Kc, PP):
     from lstm_ode_bci_amd import _lib, ops
     a = _rand((Kc, M), dev, 8, 1e-2, torch.bfloat16)
     b = _rand((Kc, N), dev, 9, 1.0, torch.bfloat16)
-    with _lib.variant(GEMM_PP=7):
+    with _lib.variant(GEMM_PP=PP):
         c = ops.gemm_tn(a, b, torch.zeros((M, N), device=dev))
     ref = a.double().t() @ b.double()
     err = float((c.double() - ref).abs().max())
@@ -109,13 +113,14 @@ def test_tn_pp_small_shapes_vs_float64(dev, M, N, Kc):
     # column slices of wider tensors (the per-direction dW_hh call of backward.py)
     wide_a = _rand((Kc, 2 * M), dev, 10, 1e-2, torch.bfloat16)
     wide_b = _rand((Kc, 2 * N), dev, 11, 1.0, torch.bfloat16)
-    with _lib.variant(GEMM_PP=7):
+    with _lib.variant(GEMM_PP=PP):
         c2 = ops.gemm_tn(wide_a[:, M:], wide_b[:, N:], torch.zeros((M, N), device=dev))
     ref2 = wide_a[:, M:].double().t() @ wide_b[:, N:].double()
     assert float((c2.double() - ref2).abs().max()) <= 2e-5 * float(ref2.abs().max()) + 1e-7
 
 
-def test_pp_full_size_against_twins(dev):
+@pytest.mark.parametrize("PP", [7, 15])
+def test_pp_full_size_against_twins(dev, PP):
     """rows = 256 * 4096 (the bench's H = 256 step): dX bit-identical to the tiled LDS-DMA kernel, the gate GEMM
     bit-identical to the weight-stationary kernel, the weight gradients equal to fp32 rounding of split-k sums; every
     ping-pong result reproduces itself (a stale-LDS read under load would not)."""
@@ -125,7 +130,7 @@ def test_pp_full_size_against_twins(dev):
     dP = _rand((rows, D * 4 * H), dev, 12, 1e-2, torch.bfloat16)
     for N in (512, 256):
         wt = _rand((N, D * 4 * H), dev, 13, 0.05, torch.bfloat16)
-        with _lib.variant(GEMM_PP=7):
+        with _lib.variant(GEMM_PP=PP):
             a = ops.gemm_nt(dP, wt, mixed=True, out_bf16=True, drop_p=0.4, seed=77)
             a2 = ops.gemm_nt(dP, wt, mixed=True, out_bf16=True, drop_p=0.4, seed=77)
         with _lib.variant(GEMM_PP=0):
@@ -136,21 +141,21 @@ def test_pp_full_size_against_twins(dev):
     for K in (512, 256):
         x = _rand((rows, K), dev, 15, 1.0, torch.bfloat16)
         w = _rand((D * 4 * H, K), dev, 16, 0.05, torch.bfloat16)
-        with _lib.variant(GEMM_PP=7):
+        with _lib.variant(GEMM_PP=PP):
             p = ops.gate_gemm_x(x, w, bias, T, Bp, H, D, True, mixed=True)
             p2 = ops.gate_gemm_x(x, w, bias, T, Bp, H, D, True, mixed=True)
         with _lib.variant(GEMM_PP=0, GATE_WS=1):
             q = ops.gate_gemm_x(x, w, bias, T, Bp, H, D, True, mixed=True)
         assert torch.equal(p, p2) and torch.equal(p, q)
         del p, p2, q
-        with _lib.variant(GEMM_PP=7):
+        with _lib.variant(GEMM_PP=PP):
             dw = ops.gemm_tn(dP, x, torch.zeros((D * 4 * H, K), device=dev))
         with _lib.variant(GEMM_PP=0):
             dw0 = ops.gemm_tn(dP, x, torch.zeros((D * 4 * H, K), device=dev))
         scale = float(dw0.abs().max())
         assert float((dw - dw0).abs().max()) <= 2e-5 * scale
     y = _rand((rows, D * H), dev, 17, 1.0, torch.bfloat16)
-    with _lib.variant(GEMM_PP=7):
+    with _lib.variant(GEMM_PP=PP):
         dwh = ops.gemm_tn(dP[Bp:, :4 * H], y[:(T - 1) * Bp, :H], torch.zeros((4 * H, H), device=dev))
     with _lib.variant(GEMM_PP=0):
         dwh0 = ops.gemm_tn(dP[Bp:, :4 * H], y[:(T - 1) * Bp, :H], torch.zeros((4 * H, H), device=dev))

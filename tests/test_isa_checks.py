@@ -19,3 +19,9 @@ def test_dma_bptt_kernel_isa_has_no_queue_drains_and_no_early_register_use():
 def test_dma_weight_gradient_gemms_keep_their_ring_in_flight():
     import isa_check
     assert isa_check.check_dma_gemms() == []
+
+
+@pytest.mark.skipif(not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")), reason="needs hipcc")
+def test_ping_pong_gemms_keep_matrix_and_read_segments_apart():
+    import isa_check
+    assert isa_check.check_gemm_pp() == []

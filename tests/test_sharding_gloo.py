@@ -116,6 +116,17 @@ def _pbs_worker(rank, world, port, n, q):
         out = sharding.predict_batch_sharded(integ, X, forecast_steps=5, batch_size=2, gather_trajectories=want_traj)
         ok &= (out[0] is None) == (not want_traj)
         ok &= all(a is None or torch.equal(a, b) for a, b in zip(out, ref))
+    # local_shard=True: every rank passes ONLY its own windows (unequal counts, possibly none): the result is the
+    # concatenation in rank order -- the same rows as one process over the concatenated array
+    cut = (2 * n) // 3                                  # rank 0 holds [0, cut), rank 1 [cut, n)
+    mine = X[:cut] if rank == 0 else X[cut:]
+    for want_traj in (True, False):
+        out = sharding.predict_batch_sharded(integ, mine, forecast_steps=5, batch_size=2, gather_trajectories=want_traj,
+                                             local_shard=True)
+        ok &= all(a is None or torch.equal(a, b) for a, b in zip(out, ref))
+    ok &= sharding.gather_shard_sizes(len(mine)) == [(0, cut), (cut, n)]
+    t0 = sharding.dp_broadcast_(torch.tensor([float(rank + 5)]), 0)
+    ok &= float(t0) == 5.0
     # control-flow helpers of the data-parallel train loop
     try:
         sharding.dp_assert_equal((4 + rank, 2), None, "batches")

@@ -183,6 +183,68 @@ def check_dx_ksplit(path=None):
     return problems
 
 
+def check_gemm_pp(path=None):
+    """gemm_pp.hip (the 8-wave ping-pong GEMMs of the H = 256 step): two wave groups run the same stream one barrier
+    apart, so between two s_barriers a wave must do EITHER its 8 MFMAs OR its fragment reads + exactly 2 LDS-DMA
+    instructions -- an MFMA that hipcc moved into a read segment would collide with the other group's matrix segment,
+    and the one hand-counted `s_waitcnt vmcnt(N)` per k-tile (N = 4: NT, 6: TN) assumes 8 DMA instructions per k-tile and
+    no other VMEM wait, spill or register load inside the loop."""
+    src = os.path.join(ROOT, "lstm_ode_bci_amd", "csrc", "gemm_pp.hip")
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    out = path or os.path.join(tempfile.mkdtemp(prefix="lob_isa_"), "pp.s")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"),
+                    "-I", os.path.dirname(src), "-S", "--cuda-device-only", src, "-o", out],
+                   check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    lines = open(out).read().split("\n")
+    problems = []
+    for pat, vm in (("gemm_nt_pp_kernelILi0ELi0ELi0EE", 4), ("gemm_nt_pp_kernelILi1ELi0ELi0EE", 4), ("gemm_tn_pp_kernel", 6)):
+        body = _function(lines, pat)
+        ins = _instrs(body)
+        loops = [(a, b) for a, b in _inner_loops(body) if any(a <= x[0] <= b and x[1].startswith("v_mfma") for x in ins)]
+        if len(loops) != 1:
+            problems.append(f"{pat}: k-tile loop not found")
+            continue
+        loop = [x for x in ins if loops[0][0] <= x[0] <= loops[0][1]]
+        waits = [t for _, t, a in loop if a and t.startswith("s_waitcnt vmcnt(")]
+        if set(waits) != {f"s_waitcnt vmcnt({vm})"}:
+            problems.append(f"{pat}: hand-written VMEM waits in the loop {sorted(set(waits))}, expected vmcnt({vm})")
+        for _, t, a in loop:
+            if not a and re.search(r"s_waitcnt.*vmcnt\(", t):
+                problems.append(f"{pat}: compiler-generated VMEM wait in the loop: {t}")
+            if t.startswith("scratch_"):
+                problems.append(f"{pat}: spill traffic in the loop: {t}")
+            if not a and t.startswith("global_load") and not t.startswith("global_load_lds"):
+                problems.append(f"{pat}: register load in the loop: {t}")
+        # segments between barriers, from the first barrier of the loop body that is followed by MFMAs
+        segs, cur = [], {"mfma": 0, "dma": 0, "rd": 0, "st": 0}
+        for _, t, a in loop:
+            if t.startswith("s_barrier"):
+                segs.append(cur)
+                cur = {"mfma": 0, "dma": 0, "rd": 0, "st": 0}
+            elif t.startswith("v_mfma"):
+                cur["mfma"] += 1
+            elif t.startswith("global_load_lds"):
+                cur["dma"] += 1
+            elif t.startswith("ds_read"):
+                cur["rd"] += 1
+            elif t.startswith("global_store") or t.startswith("global_atomic"):
+                cur["st"] += 1
+        segs.append(cur)
+        hot = [sg for sg in segs if not sg["st"]]          # the epilogue's stores sit in segments of their own
+        n_m = sum(1 for sg in hot if sg["mfma"])
+        for sg in hot:
+            if sg["mfma"] and (sg["mfma"] != 8 or sg["dma"] or sg["rd"]):
+                problems.append(f"{pat}: a matrix segment holds {sg}")
+            if not sg["mfma"] and sg["dma"] not in (0, 2):
+                problems.append(f"{pat}: a read segment issues {sg['dma']} DMA instructions (2 expected)")
+        if n_m == 0 or n_m % 4:
+            problems.append(f"{pat}: {n_m} matrix segments in the loop body (a multiple of 4 expected)")
+        n_dma = sum(sg["dma"] for sg in hot)
+        if n_dma != 2 * n_m:
+            problems.append(f"{pat}: {n_dma} DMA instructions for {n_m} matrix segments (2 per segment expected)")
+    return problems
+
+
 def _inner_loops(body):
     """[(first_line, last_line)] of every loop hipcc annotates: from the first block tagged with the loop's header to the
     last branch that targets one of the loop's own labels."""
@@ -293,6 +355,7 @@ def main(path=None):
 
 
 if __name__ == "__main__":
-    probs = main(sys.argv[1] if len(sys.argv) > 1 else None) + check_dma_gemms() + check_gate_ws() + check_dx_ksplit()
+    probs = (main(sys.argv[1] if len(sys.argv) > 1 else None) + check_dma_gemms() + check_gate_ws() + check_dx_ksplit() +
+             check_gemm_pp())
     print("\n".join(probs) if probs else "isa_check: ok")
     sys.exit(1 if probs else 0)

@@ -36,7 +36,7 @@ def ab(name, fn, flop, variants, rounds=6):
         print(f"{name:34s} {k:10s} {med:7.3f} ms (min {mn:7.3f})  {flop / med / 1e9:7.0f} TFLOP/s", flush=True)
 
 
-V = {"pingpong": dict(GEMM_PP=7), "twin": dict(GEMM_PP=0)}
+V = {"pp 8-mfma": dict(GEMM_PP=7), "pp ring": dict(GEMM_PP=15), "twin": dict(GEMM_PP=0)}
 want = set(sys.argv[1:])
 dP = rnd((rows, D * 4 * H), 1e-2, torch.bfloat16)
 if not want or "dx" in want:
@@ -58,3 +58,16 @@ if not want or "dw" in want:
     y = rnd((rows, D * H), 1.0, torch.bfloat16)
     out = torch.zeros((4 * H, H), device=dev)
     ab("dW_hh one direction", lambda: ops.gemm_tn(dP[Bp:, :4 * H], y[:(T - 1) * Bp, :H], out), 2.0 * rows * H * 4 * H, V)
+
+if "abl" in want:
+    wt = rnd((512, D * 4 * H), 0.05, torch.bfloat16)
+    VA = {"full": dict(GEMM_PP=7)}
+    for a, nm in ((1, "no DMA"), (2, "no ds_read"), (4, "no MFMA"), (3, "no DMA+read"), (5, "no DMA+MFMA"), (6, "no read+MFMA"),
+                  (7, "barriers only")):
+        VA[nm] = dict(GEMM_PP=7 | (a << 4))
+    ab("dX N=512 ablation", lambda: ops.gemm_nt(dP, wt, mixed=True, out_bf16=True), 2.0 * rows * 512 * D * 4 * H, VA, rounds=4)
+
+if "prio" in want:
+    wt = rnd((512, D * 4 * H), 0.05, torch.bfloat16)
+    VP = {"mfma prio1": dict(GEMM_PP=7), "no setprio": dict(GEMM_PP=7 | (1 << 7)), "load prio1": dict(GEMM_PP=7 | (2 << 7))}
+    ab("dX N=512 priority", lambda: ops.gemm_nt(dP, wt, mixed=True, out_bf16=True), 2.0 * rows * 512 * D * 4 * H, VP, rounds=6)
