@@ -60,6 +60,11 @@ def parse():
     ap.add_argument("--batch", type=int, default=4096, help="windows per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra BASELINE-config legs")
+    ap.add_argument("--no-roofline", action="store_true",
+                    help="skip the per-kernel HIP-event timings (profiler passes that must contain the steps only)")
+    ap.add_argument("--detail", default=None, help="also write the verbose result (every kernel, every leg) to this file")
+    ap.add_argument("--strict-storage", action="store_true",
+                    help="mixed path with fp32 saved cell states / gradient carries / last-layer output (configs[2] read strictly)")
     ap.add_argument("--hidden", type=int, default=128, help="hidden size (128 = BASELINE configs; 256 = real checkpoints)")
     ap.add_argument("--forecast-steps", type=int, default=300)
     ap.add_argument("--precision", default=None, choices=["fp32", "mixed"],
@@ -89,11 +94,17 @@ def kernel_roofline(dev, B, mode, precision, H):
     train = mode == "train"
     out = {}
 
-    def timeit(fn, n=4):
+    def timeit(fn, n=4, before=None):
+        """Mean duration of fn() between two HIP events on the launch stream; `before` (untimed) runs ahead of the start
+        event of every repetition (restores an operand the kernel overwrites)."""
+        if before is not None:
+            before()
         fn()
         torch.cuda.synchronize()
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
         for s, e in evs:
+            if before is not None:
+                before()
             s.record()
             fn()
             e.record()
@@ -128,10 +139,11 @@ def kernel_roofline(dev, B, mode, precision, H):
         Pk = P.clone()
 
         def rec_fwd():
-            Pk.copy_(P)                       # the save-mode kernel overwrites P with the activated gates
             return ops.lstm_rec_fwd(Pk, whh, T, Bp, H, D, True, mixed=mixed)
-        t_copy = timeit(lambda: Pk.copy_(P))
-        sec = timeit(rec_fwd, n=3) - t_copy
+        # the save-mode kernel overwrites P with the activated gates: P is restored AHEAD of the start event (round 2
+        # timed copy + kernel and subtracted a separately timed copy: noise of the order of the difference)
+        sec = timeit(rec_fwd, n=4, before=lambda: Pk.copy_(P))
+        Pk.copy_(P)
         Y, Cs, _, _ = rec_fwd()
         out["lstm_rec_fwd(save)"] = {"sec": sec, "flop": 2.0 * rows * N * H, "per_step": L,
                                      "mfma": "bf16" if bf16_rec else f32k,
@@ -293,10 +305,14 @@ def cpu_baseline(mode, sd, forecast_steps=300, H=128, budget_s=100.0):
 class Leg:
     """One workload: model + inputs resident in HBM, a step() closure, and its JSON description."""
 
-    def __init__(self, dev, mode, precision, B, H, forecast_steps, world=1, rank=0, dist=None, api_level=False):
+    def __init__(self, dev, mode, precision, B, H, forecast_steps, world=1, rank=0, dist=None, api_level=False,
+                 strict_storage=False, exact_fp32=False):
         from lstm_ode_bci_amd import CognitiveStateODE, LSTMODEIntegration
         from lstm_ode_bci_amd import synthetic as syn
         self.mode, self.precision, self.B, self.H, self.world, self.dist = mode, precision, B, H, world, dist
+        # strict_storage: the three storage choices beyond "bf16 gate GEMMs + fp32 recurrence" switched back to fp32;
+        # exact_fp32: the exact-fp32 MFMA kernels instead of the two-way fp16 split (LOB_VAR_F32_SPLIT = 0)
+        self.strict_storage, self.exact_fp32 = bool(strict_storage), bool(exact_fp32)
         self.forecast_steps, self.api_level, self.dev = forecast_steps, api_level, dev
         self.model, self.sd = build_model(dev, H)
         # rank r owns global windows [r*B, (r+1)*B): independent shards, no data-path collective
@@ -314,6 +330,27 @@ class Leg:
             from lstm_ode_bci_amd.training import FusedAdamW, WeightedCrossEntropy
             self.criterion = WeightedCrossEntropy(torch.tensor([1.0, 1.0], device=dev)).to(dev)
             self.opt = FusedAdamW(self.model.parameters(), lr=3e-4, weight_decay=1e-4, model=self.model)
+
+    def _switches(self):
+        """Context of one leg: storage switches of ops.py and the test-only variant table, restored afterwards."""
+        import contextlib
+        from lstm_ode_bci_amd import _lib, ops
+        leg = self
+
+        @contextlib.contextmanager
+        def cm():
+            old = (ops.C_BF16, ops.DY_BF16_CARRY, ops.LN_X_BF16)
+            if leg.strict_storage:
+                ops.C_BF16 = ops.DY_BF16_CARRY = ops.LN_X_BF16 = False
+            try:
+                if leg.exact_fp32:
+                    with _lib.variant(F32_SPLIT=0):
+                        yield
+                else:
+                    yield
+            finally:
+                ops.C_BF16, ops.DY_BF16_CARRY, ops.LN_X_BF16 = old
+        return cm()
 
     def step(self):
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(self.precision == "mixed")):
@@ -348,6 +385,10 @@ class Leg:
 
     def run(self, steps, warmup):
         """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
+        with self._switches():
+            return self._run(steps, warmup)
+
+    def _run(self, steps, warmup):
         for _ in range(warmup):
             self.step()
         if self.world > 1:
@@ -367,9 +408,22 @@ class Leg:
         return dt
 
     def describe(self, steps, warmup, dt, with_roofline=True):
+        with self._switches():
+            return self._describe(steps, warmup, dt, with_roofline)
+
+    def _describe(self, steps, warmup, dt, with_roofline=True):
         mode, precision, B, H, world = self.mode, self.precision, self.B, self.H, self.world
         value = world * B * steps * self.api_chunks / dt
         mf = fp32_mfma_kind(H) if precision == "fp32" else "bf16"
+        if precision == "mixed":
+            storage = ("; storage: bf16 P / saved gates / dP / inter-layer activations" +
+                       ("; saved cell states, gradient carries between layers and the last layer's output fp32 (strict)"
+                        if self.strict_storage else
+                        ", and ALSO bf16 saved cell states, bf16 gradient carries between layers / LayerNorms and a bf16-only "
+                        "last-layer output (the carried state, accumulation and all parameter gradients stay fp32)")
+                       if mode == "train" else "; storage: bf16 P and inter-layer activations")
+        else:
+            storage = ""
         flop_per_window = gate_flop_fwd(H) * (3 if mode == "train" else 1)
         res = {
             "metric": {"train": "eeg_windows_per_sec_fwd_bwd", "fwd": "eeg_windows_per_sec_fwd",
@@ -381,7 +435,7 @@ class Leg:
                                    (("fp32 (matrix products as two-way fp16 splits on the 16-bit MFMA pipe: 22-bit products, "
                                      "fp32 accumulate / state; parity <= 1e-5)" if mf == "f16x2" else "fp32 exact-MFMA")
                                     if precision == "fp32" else
-                                    "bf16 gate GEMMs + fp32 recurrence/accumulate (autocast)")
+                                    "bf16 gate GEMMs + fp32 recurrence/accumulate (autocast)" + storage)
                                    + (f", RK4 ODE {self.forecast_steps} points" if mode == "coupled" else "")
                                    + (f", numpy in -> numpy out through predict_batch ({self.api_chunks} x {B} windows per call, PCIe "
                                       "inside the step)" if self.api_level else ""),
@@ -402,7 +456,16 @@ class Leg:
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # HBM bytes per launch from rocprofv3 --pmc
             if os.path.exists(tpath):
                 try:
-                    roof["traffic"] = json.load(open(tpath)).get(f"{roof['kernel']}|{precision}|B{B}" + ("" if H == 128 else f"|H{H}"))
+                    table = json.load(open(tpath))
+                    sfx = f"|{precision}|B{B}" + ("" if H == 128 else f"|H{H}")
+                    roof["traffic"] = table.get(roof["kernel"] + sfx)
+                    # whole step: HBM bytes of ALL kernels of one step from the same PMC passes (tools/pmc_traffic.py),
+                    # over this run's measured step time
+                    sb = table.get("step" + sfx) if (mode == "train" and not self.strict_storage) else None
+                    if sb:
+                        gbps = sb / (dt / steps) / 1e9
+                        roof["step"] = {"bytes": sb, "achieved": gbps, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+                                        "bytes_per_window": sb / B}
                 except Exception:
                     pass
             res["roofline"] = roof
@@ -415,10 +478,14 @@ class Leg:
         torch.cuda.empty_cache()
 
 
-def extra_legs(dev, forecast_steps):
+def extra_legs(dev, forecast_steps, cpu=True):
     """Short legs over the BASELINE.json configurations the headline does not cover (N = 1 only)."""
     specs = [
+        ("configs[2] strict storage: training step, mixed, B=4096, fp32 cell states / gradient carries / last-layer output",
+         dict(mode="train", precision="mixed", B=4096, H=128, strict_storage=True), 5, 2),
         ("configs[1] fp32 forward, B=1024", dict(mode="fwd", precision="fp32", B=1024, H=128), 8, 3),
+        ("configs[1] fp32 forward, B=1024, exact-fp32 MFMA kernels (LOB_VAR_F32_SPLIT=0)",
+         dict(mode="fwd", precision="fp32", B=1024, H=128, exact_fp32=True), 5, 2),
         ("configs[3] coupled LSTM->ODE, B=4096, device-resident", dict(mode="coupled", precision="fp32", B=4096, H=128), 5, 2),
         ("configs[3] coupled LSTM->ODE, B=4096, numpy in -> numpy out (predict_batch)",
          dict(mode="coupled", precision="fp32", B=4096, H=128, api_level=True), 3, 1),
@@ -434,10 +501,54 @@ def extra_legs(dev, forecast_steps):
         t0 = time.perf_counter()
         leg = Leg(dev, forecast_steps=forecast_steps, **kw)
         dt = leg.run(steps, warmup)
-        r = leg.describe(steps, warmup, dt, with_roofline=not kw.get("api_level", False))
+        r = leg.describe(steps, warmup, dt, with_roofline=not (kw.get("api_level", False) or kw.get("strict_storage", False)
+                                                                 or kw.get("exact_fp32", False)))
+        if cpu and kw.get("mode") == "coupled" and not kw.get("api_level", False):
+            # the reference's coupled path on this host: LSTM chunk loop + one odeint per window (06:343-401)
+            r["cpu_baseline"] = cpu_baseline("coupled", leg.sd, forecast_steps, kw["H"], budget_s=25.0)
+            r["speedup_vs_cpu_baseline"] = r["value"] / r["cpu_baseline"]["value"]
         r["leg_wall_s"] = round(time.perf_counter() - t0, 1)
         leg.free()
         out[name] = r
+    return out
+
+
+def compact(res):
+    """The ONE line the contract asks for, small enough to survive a log tail: every leg keeps its rate, step time,
+    workload and dominant-kernel roofline; the per-kernel tables go to --detail."""
+    def roof(r):
+        if not r:
+            return None
+        out = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "bytes_per_launch",
+                                     "flop_per_launch", "sec_per_launch", "step") if r.get(k) is not None or k == "traffic"}
+        if "all" in r:      # [ms per launch, launches per step, fraction of HBM peak, fraction of its MFMA peak]
+            out["all"] = {k: [v["ms"], v["launches_per_step"], v["frac_of_hbm_peak"], v["frac_of_mfma_peak"]]
+                          for k, v in r["all"].items()}
+        return out
+
+    def cpu(c):
+        if not c:
+            return None
+        return {k: c[k] for k in ("value", "median", "unit", "cores", "kind", "host_cpus", "cpu_model", "n1_value",
+                                  "lstm_windows_per_s", "ode_solves_per_s_1thread", "sample") if k in c}
+    out = {k: v for k, v in res.items() if k not in ("roofline", "cpu_baseline", "extra_configs")}
+    if res.get("roofline"):
+        out["roofline"] = roof(res.get("roofline"))
+    if "cpu_baseline" in res:
+        out["cpu_baseline"] = cpu(res["cpu_baseline"])
+    if "extra_configs" in res:
+        legs = {}
+        for name, r in res["extra_configs"].items():
+            e = {"value": round(r["value"], 1), "ms_per_step": round(r["ms_per_step"], 3), "workload": r["config"]["workload"]}
+            if r.get("roofline"):
+                e["roofline"] = {k: r["roofline"][k] for k in ("bound", "kernel", "frac", "sec_per_launch") if k in r["roofline"]}
+            if r.get("cpu_baseline"):
+                e["cpu_baseline"] = cpu(r["cpu_baseline"])
+                e["speedup_vs_cpu_baseline"] = r["speedup_vs_cpu_baseline"]
+            legs[name] = e
+        out["extra_configs"] = legs
+        # the same numbers where a key whitelist cannot drop them
+        out["config"]["also_measured_windows_per_s"] = {n.split(",")[0][:60]: round(r["value"]) for n, r in res["extra_configs"].items()}
     return out
 
 
@@ -469,19 +580,22 @@ def main():
     default_run = a.mode is None and a.precision is None and a.batch == 4096 and H == 128
     mode = a.mode or "train"
     precision = a.precision or ("mixed" if mode == "train" else "fp32")
-    leg = Leg(dev, mode, precision, a.batch, H, a.forecast_steps, world, rank, dist)
+    leg = Leg(dev, mode, precision, a.batch, H, a.forecast_steps, world, rank, dist, strict_storage=a.strict_storage)
     dt = leg.run(a.steps, a.warmup)
 
     if rank == 0:
-        res = leg.describe(a.steps, a.warmup, dt)
+        res = leg.describe(a.steps, a.warmup, dt, with_roofline=not a.no_roofline)
         sd = leg.sd
         leg.free()
         if world == 1 and default_run and not a.no_extra:
-            res["extra_configs"] = extra_legs(dev, a.forecast_steps)
+            res["extra_configs"] = extra_legs(dev, a.forecast_steps, cpu=not a.no_cpu_baseline)
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(mode, sd, a.forecast_steps, H)
+            res["cpu_baseline"] = cpu_baseline(mode, sd, a.forecast_steps, H, budget_s=60.0)
             res["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]
-        print(json.dumps(res))
+        if a.detail:
+            with open(a.detail, "w") as f:
+                json.dump(res, f, indent=1)
+        print(json.dumps(compact(res)))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

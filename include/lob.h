@@ -40,7 +40,7 @@ extern "C" {
                                * the result C / dx is stored as bf16 (row-major, same leading dimension in elements)   */
 #define LOB_DY_BF16 0x800     /* OR into `act` of lob_layernorm_act_bwd_f32: dy is read as bf16                          */
 #define LOB_X_BF16 0x1000     /* OR into `act` of lob_layernorm_act_f32 / lob_layernorm_act_bwd_f32: the input rows x are
-                               * bf16 (width 256 only; the backward then also needs LOB_DY_BF16 | LOB_OUT_BF16): in the mixed
+                               * bf16 (widths 256 / 512; the backward then also needs LOB_DY_BF16 | LOB_OUT_BF16): in the mixed
                                * path the last LSTM layer hands its output over as bf16 only                             */
 #define LOB_LN_IDENTITY 0x200 /* OR into `act` of lob_layernorm_act(_bwd)_f32: skip the normalisation and the
                                * affine (nn.Identity in place of nn.LayerNorm: the no-LayerNorm ablation,

@@ -334,6 +334,185 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(PPArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// The same NT schedule on v_mfma_f32_16x16x32_bf16 (row-major epilogue only).  Why: these kernels run the chip into
+// its power limit -- SQ_WAVE_CYCLES / wall time of the 32x32x16 kernel is 1.37-1.40 GHz (profiles/r03_*), i.e. the
+// matrix pipe is ~78 % busy at the clock the chip holds -- and MI355X_MICROARCH.md ('DVFS give-back' item 7) measures
+// the 16x16x32 shape at ~1.15 x the FLOP/s of 32x32x16 at equal cycles per FLOP (it holds a higher clock).  Same tile,
+// same LDS images, same DMA, same segment structure (8 / 8 / 4 / 4 ds_read_b128, 16 MFMAs of 16 cycles per matrix
+// segment); a fragment is 16 rows x 32 k (lane: row l & 15, 16-B chunk 4 kstep + (l >> 4)), and the same source-side
+// swizzle (chunk ^ ((row >> 1) & 7)) is conflict-free for that read pattern too.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void gemm_nt_pp16_kernel(PPArgs g) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * PP_OP];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int r15 = lane & 15, c4 = lane >> 4;
+    const int ntn = g.N >> 8, ntm = g.M >> 8;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+    const int panels = (ntm - xcd + 7) / 8, ntile = panels * ntn;
+    if (slot >= ntile) return;
+    const int nk = g.K >> 6;
+    const int my_tiles = (ntile - slot + nslot - 1) / nslot;
+    const int last_it = slot + (my_tiles - 1) * nslot;
+    const int total = my_tiles * nk;
+
+    struct Cur { int it, kt; const char* pa; const char* pb; };
+    auto set_cur = [&](Cur& c) {
+        const int m0 = ((c.it / ntn) * 8 + xcd) << 8, n0 = (c.it % ntn) << 8;
+        c.pa = reinterpret_cast<const char*>(g.A) + ((size_t)m0 * g.lda + (size_t)c.kt * 64) * 2;
+        c.pb = reinterpret_cast<const char*>(g.W) + ((size_t)n0 * g.ldw + (size_t)c.kt * 64) * 2;
+    };
+    auto advance = [&](Cur& c) {
+        if (c.kt + 1 < nk) { ++c.kt; c.pa += 128; c.pb += 128; }
+        else if (c.it < last_it) { c.it += nslot; c.kt = 0; set_cur(c); }
+    };
+    const int l3 = lane >> 3, l7 = lane & 7;
+    unsigned asrc[2], bsrc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int ra = wr * 128 + wc * 16 + j * 8 + l3;
+        asrc[j] = 2u * (unsigned)(ra * g.lda + ((l7 ^ ((ra >> 1) & 7)) << 3));
+        const int rb = wave * 16 + j * 8 + l3;
+        bsrc[j] = 2u * (unsigned)(rb * g.ldw + ((l7 ^ ((rb >> 1) & 7)) << 3));
+    }
+    const size_t a_hi_b = (size_t)64 * g.lda * 2, b_h1_b = (size_t)128 * g.ldw * 2;
+    unsigned char* const a_dst = lds + wr * 16384 + wc * 2048;
+    unsigned char* const b_dst = lds + 2 * PP_OP + wave * 2048;
+    auto dma2 = [&](const char* src, unsigned o0, unsigned o1, unsigned char* dst) {
+        __builtin_amdgcn_global_load_lds((gbl_cvoid*)(src + o0), (lds_void*)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_cvoid*)(src + o1), (lds_void*)(dst + 1024), 16, 0, 0);
+    };
+    auto stage_a = [&](const Cur& c, int buf, int hi_half) {
+        dma2(c.pa + (hi_half ? a_hi_b : 0), asrc[0], asrc[1], a_dst + buf * PP_OP + hi_half * 8192);
+    };
+    auto stage_b = [&](const Cur& c, int buf, int half) {
+        dma2(c.pb + (half ? b_h1_b : 0), bsrc[0], bsrc[1], b_dst + buf * PP_OP + half * 16384);
+    };
+
+    const unsigned lds_b = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const int sw = (r15 >> 1) & 7;
+    unsigned aoff[2], boff[2];       // k-step 0 / 1 (32 k each): 16-B chunk 4 kstep + c4
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        aoff[ks] = lds_b + (unsigned)((wr * 128 + r15) * 128 + (((4 * ks + c4) ^ sw) << 4));
+        boff[ks] = lds_b + (unsigned)(2 * PP_OP + (wc * 64 + r15) * 128 + (((4 * ks + c4) ^ sw) << 4));
+    }
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[i][c] = z; }
+
+    Cur c1{slot, 0, nullptr, nullptr};
+    set_cur(c1);
+    stage_a(c1, 0, 0); stage_b(c1, 0, 0); stage_a(c1, 0, 1); stage_b(c1, 0, 1);
+    advance(c1);
+    stage_a(c1, 1, 0); stage_b(c1, 1, 0);
+    Cur c2 = c1;
+    advance(c2);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    PP_BAR();
+    if (wr == 1) PP_BAR();
+
+    bf16x8 af[4], bf[4][2];
+#define PP_W4A() asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]))
+#define PP_M16(R0, KS)                                                                                       \
+    do {                                                                                                     \
+        __builtin_amdgcn_s_setprio(1);                                                                       \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                     \
+            _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_)                                                 \
+                acc[R0 + i_][c_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[c_][KS], af[i_], acc[R0 + i_][c_], 0, 0, 0);   \
+        __builtin_amdgcn_s_setprio(0);                                                                       \
+    } while (0)
+    auto ktile = [&](auto bufc) {
+        constexpr int BUF = decltype(bufc)::value, BO = BUF * PP_OP, NB = BUF ^ 1;
+        // ---- L1 / M1: rows 0-63, k 0-31
+#pragma unroll
+        for (int i = 0; i < 4; ++i) PP_RD128(af[i], aoff[0], BO + i * 2048);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) PP_RD128(bf[c][0], boff[0], BO + c * 2048);
+        stage_a(c1, NB, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]),
+                     "+v"(bf[0][0]), "+v"(bf[1][0]), "+v"(bf[2][0]), "+v"(bf[3][0]));
+        PP_BAR();
+        PP_M16(0, 0);
+        PP_BAR();
+        // ---- L2 / M2: rows 0-63, k 32-63
+#pragma unroll
+        for (int i = 0; i < 4; ++i) PP_RD128(af[i], aoff[1], BO + i * 2048);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) PP_RD128(bf[c][1], boff[1], BO + c * 2048);
+        stage_b(c1, NB, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]),
+                     "+v"(bf[0][1]), "+v"(bf[1][1]), "+v"(bf[2][1]), "+v"(bf[3][1]));
+        PP_BAR();
+        PP_M16(0, 1);
+        PP_BAR();
+        // ---- L3 / M3: rows 64-127, k 0-31
+#pragma unroll
+        for (int i = 0; i < 4; ++i) PP_RD128(af[i], aoff[0], BO + 8192 + i * 2048);
+        stage_a(c2, BUF, 0);
+        PP_W4A();
+        PP_BAR();
+        PP_M16(4, 0);
+        PP_BAR();
+        // ---- L4 / M4: rows 64-127, k 32-63
+#pragma unroll
+        for (int i = 0; i < 4; ++i) PP_RD128(af[i], aoff[1], BO + 8192 + i * 2048);
+        stage_b(c2, BUF, 0);
+        PP_W4A();
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        PP_BAR();
+        PP_M16(4, 1);
+        PP_BAR();
+        c1 = c2;
+        advance(c2);
+    };
+
+    int it = slot, kt = 0;
+    for (int q = 0; q < total; q += 2) {
+        ktile(std::integral_constant<int, 0>{});
+        ktile(std::integral_constant<int, 1>{});
+        kt += 2;
+        if (kt < nk) continue;
+        kt = 0;
+        const int m0 = ((it / ntn) * 8 + xcd) << 8, n0 = (it % ntn) << 8;
+        it += nslot;
+        // operands swapped (D[n][m]): lane = row m0 + .. + r15, columns 4 c4 .. + 3 of each 16-column block
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = m0 + wr * 128 + 16 * i + r15;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const size_t o = (size_t)row * g.ldc + n0 + wc * 64 + 16 * c + 4 * c4;
+                float v0 = acc[i][c][0], v1 = acc[i][c][1], v2 = acc[i][c][2], v3 = acc[i][c][3];
+                if (g.drop_p > 0.f) {
+                    float d0, d1, d2, d3;
+                    lob_dropout_scale2(g.seed, (uint64_t)o, g.drop_p, d0, d1);
+                    lob_dropout_scale2(g.seed, (uint64_t)o + 2, g.drop_p, d2, d3);
+                    v0 *= d0; v1 *= d1; v2 *= d2; v3 *= d3;
+                }
+                if (g.out_bf16) {
+                    bf16x4 v = {(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
+                    *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(g.C) + o) = v;
+                } else {
+                    f32x4 v = {v0, v1, v2, v3};
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + o) = v;
+                }
+                f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                acc[i][c] = z;
+            }
+        }
+    }
+    if (wr == 0) PP_BAR();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef PP_W4A
+#undef PP_M16
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // TN: C[i][j] += sum_k A[k][i] B[k][j] over this workgroup's contraction chunk, fp32 atomics at the end (split-k).
 // One (256 x 256 output tile, chunk) per workgroup.  LDS images [64 k][256 columns] (512-B rows), 64-B granule g of
 // k-row kr stored at granule g ^ (kr & 3) (on the DMA source address and on the tr read: the four k-rows of a
@@ -773,6 +952,51 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(TNPPArgs g) {
         }
 }
 
+// Diagnostic: the operand DMA of gemm_nt_pp_kernel ALONE -- same tile walk, same source addresses, same 1-KB
+// global_load_lds_dwordx4 instructions into LDS, but no barriers, no reads, no MFMAs, DEPTH instructions in flight per wave.
+// What the L2 -> LDS path delivers for this traffic mix (A once from HBM and once from L2 / MALL, B from L2) is the floor
+// of any 256 x 256 tiling of these GEMMs (tools/pp_bench.py dma).
+template <int DEPTH>
+__global__ __launch_bounds__(512, 2) void dma_probe_kernel(PPArgs g) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * PP_OP];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int ntn = g.N >> 8, ntm = g.M >> 8;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+    const int panels = (ntm - xcd + 7) / 8, ntile = panels * ntn;
+    if (slot >= ntile) return;
+    const int nk = g.K >> 6;
+    const int l3 = lane >> 3, l7 = lane & 7;
+    unsigned asrc[2], bsrc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int ra = wr * 128 + wc * 16 + j * 8 + l3;
+        asrc[j] = 2u * (unsigned)(ra * g.lda + ((l7 ^ ((ra >> 1) & 7)) << 3));
+        const int rb = wave * 16 + j * 8 + l3;
+        bsrc[j] = 2u * (unsigned)(rb * g.ldw + ((l7 ^ ((rb >> 1) & 7)) << 3));
+    }
+    const size_t a_hi_b = (size_t)64 * g.lda * 2, b_h1_b = (size_t)128 * g.ldw * 2;
+    unsigned char* const dst = lds + wave * 16384;
+    int n = 0;
+    for (int it = slot; it < ntile; it += nslot) {
+        const int m0 = ((it / ntn) * 8 + xcd) << 8, n0 = (it % ntn) << 8;
+        const char* pa = reinterpret_cast<const char*>(g.A) + (size_t)m0 * g.lda * 2;
+        const char* pb = reinterpret_cast<const char*>(g.W) + (size_t)n0 * g.ldw * 2;
+        for (int kt = 0; kt < nk; ++kt, pa += 128, pb += 128) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                __builtin_amdgcn_global_load_lds((gbl_cvoid*)(pa + asrc[j]), (lds_void*)(dst + ((n++ & 15) << 10)), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gbl_cvoid*)(pa + a_hi_b + asrc[j]), (lds_void*)(dst + ((n++ & 15) << 10)), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gbl_cvoid*)(pb + bsrc[j]), (lds_void*)(dst + ((n++ & 15) << 10)), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gbl_cvoid*)(pb + b_h1_b + bsrc[j]), (lds_void*)(dst + ((n++ & 15) << 10)), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEPTH) : "memory");
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 inline int pp_grid(int M, int N) {          // persistent: one workgroup per CU, a multiple of 8 for the XCD map
@@ -801,6 +1025,12 @@ int lob_gemm_nt_pp(const void* A, int lda, const void* Wt, int ldw, void* C, int
     if (lob_variant(LOB_VAR_GEMM_PP) & 8) hipLaunchKernelGGL(gemm_nt_ring_kernel, dim3((unsigned)pp_grid(M, N)), dim3(512), 0, s, g);
     else {
         const dim3 gr((unsigned)pp_grid(M, N)), bl(512);
+        if (lob_variant(LOB_VAR_GEMM_PP) & 1024) {                 // diagnostic: the operand DMA alone (tools/pp_bench.py dma)
+            if (lob_variant(LOB_VAR_GEMM_PP) & 2048) hipLaunchKernelGGL(dma_probe_kernel<24>, gr, bl, 0, s, g);
+            else                                     hipLaunchKernelGGL(dma_probe_kernel<8>, gr, bl, 0, s, g);
+            LOB_CHECK_LAUNCH();
+            return 0;
+        }
         switch ((lob_variant(LOB_VAR_GEMM_PP) >> 4) & 7) {         // diagnostic ablations (tools/pp_bench.py abl)
             case 1: hipLaunchKernelGGL((gemm_nt_pp_kernel<0, 1>), gr, bl, 0, s, g); break;
             case 2: hipLaunchKernelGGL((gemm_nt_pp_kernel<0, 2>), gr, bl, 0, s, g); break;
@@ -810,6 +1040,7 @@ int lob_gemm_nt_pp(const void* A, int lda, const void* Wt, int ldw, void* C, int
             case 6: hipLaunchKernelGGL((gemm_nt_pp_kernel<0, 6>), gr, bl, 0, s, g); break;
             case 7: hipLaunchKernelGGL((gemm_nt_pp_kernel<0, 7>), gr, bl, 0, s, g); break;
             default:
+                if (lob_variant(LOB_VAR_GEMM_PP) & 512) { hipLaunchKernelGGL(gemm_nt_pp16_kernel, gr, bl, 0, s, g); break; }
                 switch ((lob_variant(LOB_VAR_GEMM_PP) >> 7) & 3) {
                     case 1: hipLaunchKernelGGL((gemm_nt_pp_kernel<0, 0, 1>), gr, bl, 0, s, g); break;
                     case 2: hipLaunchKernelGGL((gemm_nt_pp_kernel<0, 0, 2>), gr, bl, 0, s, g); break;

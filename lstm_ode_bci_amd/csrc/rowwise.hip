@@ -711,10 +711,21 @@ extern "C" int lob_layernorm_act_f32(const float* in, const float* gamma, const 
     if (width > 64 * LN_MAX_PER_LANE) return LOB_E_SHAPE;
     if (drop_p < 0.f || drop_p >= 1.f) return LOB_E_ARG;
     if (remap_T > 0 && (remap_B <= 0 || remap_Bp < remap_B || rows != remap_T * remap_B)) return LOB_E_SHAPE;
-    if (x16) {       // bf16 input rows: the post-LSTM LayerNorm of the mixed path (width 256), vectorised kernel only
-        if (width != 256 || ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) |
-                              reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15)) return LOB_E_SHAPE;
+    if (x16) {       // bf16 input rows: the post-LSTM LayerNorm of the mixed path (width 256 / 512), vectorised kernel only
+        if ((width != 256 && width != 512) || remap_T > 0 ||
+            ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) |
+              reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15)) return LOB_E_SHAPE;
         const __bf16* inb = reinterpret_cast<const __bf16*>(in);
+        if (width == 512) {                // H = 256: 64 lanes x 8 values: 16 B per lane in, 16 B (bf16) / 32 B out
+            int nb = (rows + 3) / 4;
+            if (nb > 256 * 16) nb = 256 * 16;
+            if (out_bf16) hipLaunchKernelGGL((layernorm_act_vec_kernel<8, true, 64, __bf16>), dim3(nb), dim3(256), 0, (hipStream_t)stream,
+                                             inb, gamma, beta, out, rows, eps, act, remap_T, remap_B, remap_Bp, drop_p, seed);
+            else hipLaunchKernelGGL((layernorm_act_vec_kernel<8, false, 64, __bf16>), dim3(nb), dim3(256), 0, (hipStream_t)stream,
+                                    inb, gamma, beta, out, rows, eps, act, remap_T, remap_B, remap_Bp, drop_p, seed);
+            LOB_CHECK_LAUNCH();
+            return 0;
+        }
         if (out_bf16 && ln_lpr16()) {      // bf16 in and out: 32 lanes per row, 16 B per lane and stream
             int nb = (rows + 15) / 16;     // RPW 2 x GPW 2 rows per wave pass, 4 waves
             if (nb > 256 * 16) nb = 256 * 16;
@@ -827,7 +838,7 @@ extern "C" int lob_layernorm_act_bwd_f32(const float* x, const float* gamma, con
     const bool ident = (act & LOB_LN_IDENTITY) != 0;
     const bool dy16 = (act & LOB_DY_BF16) != 0, dx16 = (act & LOB_OUT_BF16) != 0, x16 = (act & LOB_X_BF16) != 0;
     act &= ~(LOB_DY_BF16 | LOB_OUT_BF16 | LOB_X_BF16);
-    if (x16 && !(dy16 && dx16 && width == 256)) return LOB_E_SHAPE;   // bf16 x: with bf16 dy / dx at width 256 only
+    if (x16 && !(dy16 && dx16 && (width == 256 || width == 512))) return LOB_E_SHAPE;   // bf16 x: with bf16 dy / dx, width 256 / 512
     if (!x || !dy || !dx || rows <= 0 || width <= 0) return LOB_E_ARG;
     if (!ident && (!gamma || !beta || !dgamma || !dbeta)) return LOB_E_ARG;
     if (width > 64 * LN_MAX_PER_LANE) return LOB_E_SHAPE;
@@ -871,7 +882,12 @@ extern "C" int lob_layernorm_act_bwd_f32(const float* x, const float* gamma, con
             else                    LOB_LNB_T(8, 16, __bf16, float, dyb, dx);
         } else if (width == 512) {       // post-LSTM LayerNorm at H = 256
             if (blocks > 256 * 8) blocks = 256 * 8;
-            if (dy16 && dx16)       LOB_LNB_T(8, 64, __bf16, __bf16, dyb, dxb);
+            if (x16)                // all three streams bf16 (the last layer's output arrives as bf16 only)
+                hipLaunchKernelGGL((layernorm_act_bwd_vec_kernel<8, 64, __bf16, __bf16, __bf16>), dim3(blocks), dim3(256), 0,
+                                   (hipStream_t)stream, reinterpret_cast<const __bf16*>(x), gamma, beta, dyb, dxb, dgamma, dbeta,
+                                   rows, eps, act, remap_T, remap_B, remap_Bp, drop_p, seed, pool_attn, pool_dctx, pool_T, pool_B,
+                                   pool_Bp, dx_colsum);
+            else if (dy16 && dx16)  LOB_LNB_T(8, 64, __bf16, __bf16, dyb, dxb);
             else if (dx16)          LOB_LNB_T(8, 64, float, __bf16, dy, dxb);
             else                    LOB_LNB_T(8, 64, __bf16, float, dyb, dx);
         } else {

@@ -304,7 +304,7 @@ def layernorm_act(x, gamma, beta, act=ACT_NONE, eps=1e-5, remap=None, drop_p=0.0
     rows, width = x.shape
     if x16:
         if not ln_x_bf16_ok(width) or remap is not None:
-            raise _lib.LobError("layernorm_act: bf16 input rows are read at width 256 (no relayout) only")
+            raise _lib.LobError("layernorm_act: bf16 input rows are read at width 256 / 512 (no relayout) only")
         act = act | X_BF16
     out_bf16 = bool(out_bf16) and width in (128, 256, 512)
     odt = torch.bfloat16 if out_bf16 else torch.float32
@@ -462,7 +462,7 @@ def layernorm_act_bwd(x, gamma, beta, dy, act=ACT_NONE, eps=1e-5, remap=None, dr
     rows, width = x.shape
     if x16:
         if not (ln_x_bf16_ok(width) and dy16 and dx_bf16):
-            raise _lib.LobError("layernorm_act_bwd: bf16 input rows need width 256 and bf16 dy / dx")
+            raise _lib.LobError("layernorm_act_bwd: bf16 input rows need width 256 / 512 and bf16 dy / dx")
         act = act | X_BF16
     rT, rB, rBp = (0, 0, 0) if remap is None else remap
     dx = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16 if dx_bf16 else torch.float32)
@@ -490,8 +490,8 @@ LN_X_BF16 = True
 
 
 def ln_x_bf16_ok(width):
-    """Width at which the LayerNorm kernels read bf16 input rows (the post-LSTM LayerNorm at H = 128, D = 2)."""
-    return width == 256
+    """Widths at which the LayerNorm kernels read bf16 input rows (the post-LSTM LayerNorm at H = 128 / 256, D = 2)."""
+    return width in (256, 512)
 
 
 def can_fuse_colsum(width):

@@ -34,7 +34,7 @@ def _ref_nt(a, w):
 @pytest.mark.parametrize("M,N,K", [(256, 256, 2048), (512, 512, 2048), (2304, 512, 1024), (256 * 70, 256, 2048),
                                    (256 * 9, 768, 1152)])
 @pytest.mark.parametrize("out_bf16", [True, False])
-@pytest.mark.parametrize("PP", [7, 15])
+@pytest.mark.parametrize("PP", [7, 15, 7 | 512])
 def test_nt_pp_small_shapes_vs_float64(dev, M, N, K, out_bf16, PP):
     """dX-shaped products through lob_gemm_nt_bf16 (K >= 1024 routes to the ping-pong kernel; PP = 15: the schedule with
     16-MFMA segments and the triple-buffered A half)."""
@@ -51,7 +51,10 @@ def test_nt_pp_small_shapes_vs_float64(dev, M, N, K, out_bf16, PP):
     assert err <= tol, (err, tol)
     with _lib.variant(GEMM_PP=0):
         ct = ops.gemm_nt(a, w, mixed=True, out_bf16=out_bf16)
-    assert torch.equal(c, ct)            # same MFMA, same k order as the tiled kernel
+    if PP & 512:                         # v_mfma_f32_16x16x32_bf16: 32 products per instruction, another summation tree
+        assert (c.double() - ct.double()).abs().max().item() <= tol
+    else:
+        assert torch.equal(c, ct)        # same MFMA, same k order as the tiled kernel
 
 
 def test_nt_pp_dropout_epilogue_matches_standalone_mask(dev):

@@ -2,7 +2,11 @@
 """Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (collected SEPARATELY, as
 MI355X_MICROARCH.md prescribes) into per-launch HBM traffic of the bench's hot kernels.
 
-    python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <tag> [B]
+    python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <tag> [B] [H] [nsteps]
+
+nsteps (steps + warm-up of a `bench.py --no-roofline --no-extra --no-cpu-baseline` pass: nothing but the steps ran under
+the profiler): adds the HBM bytes of ONE WHOLE STEP (all kernels) as `step|<precision>|B<B>[|H<H>]` -- what bench.py
+reports as roofline.step.
 
 gfx950 corrections (MI355X_MICROARCH.md §HBM): FETCH_SIZE counts 64 B per 128-B request, i.e. exactly
 half of the bytes of wide coalesced reads (checked here on kernels with a known byte count: the bf16
@@ -40,6 +44,9 @@ def load(path, counter):
 def main():
     fetch, write, tag = sys.argv[1], sys.argv[2], sys.argv[3]
     B = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
+    H = int(sys.argv[5]) if len(sys.argv) > 5 else 128
+    nsteps = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+    sfx = "" if H == 128 else f"|H{H}"
     f, w = load(fetch, "FETCH_SIZE"), load(write, "WRITE_SIZE")
     rows = []
     for k in sorted(set(f) | set(w), key=lambda k: -(sum(f.get(k, [0])) + sum(w.get(k, [0])))):
@@ -58,8 +65,11 @@ def main():
         for prec, sub in alts:
             for r in rows:
                 if sub in r["kernel"]:
-                    table[f"{label}|{prec}|B{B}"] = r["hbm_bytes_per_launch_corrected"]
+                    table[f"{label}|{prec}|B{B}{sfx}"] = r["hbm_bytes_per_launch_corrected"]
                     break
+    if nsteps > 0:      # every kernel of the pass, launches x bytes, over the steps that ran
+        total = sum((2 * sum(f.get(k, [0.0])) + sum(w.get(k, [0.0]))) * 1024 for k in set(f) | set(w))
+        table[f"step|mixed|B{B}{sfx}"] = int(total / nsteps)
     json.dump(table, open(jpath, "w"), indent=1, sort_keys=True)
     print(out)
     print(json.dumps(table, indent=1))

@@ -36,7 +36,7 @@ def ab(name, fn, flop, variants, rounds=6):
         print(f"{name:34s} {k:10s} {med:7.3f} ms (min {mn:7.3f})  {flop / med / 1e9:7.0f} TFLOP/s", flush=True)
 
 
-V = {"pp 8-mfma": dict(GEMM_PP=7), "pp ring": dict(GEMM_PP=15), "twin": dict(GEMM_PP=0)}
+V = {"pp 32x32x16": dict(GEMM_PP=7), "pp 16x16x32": dict(GEMM_PP=7 | 512), "pp ring": dict(GEMM_PP=15), "twin": dict(GEMM_PP=0)}
 want = set(sys.argv[1:])
 dP = rnd((rows, D * 4 * H), 1e-2, torch.bfloat16)
 if not want or "dx" in want:
@@ -71,3 +71,10 @@ if "prio" in want:
     wt = rnd((512, D * 4 * H), 0.05, torch.bfloat16)
     VP = {"mfma prio1": dict(GEMM_PP=7), "no setprio": dict(GEMM_PP=7 | (1 << 7)), "load prio1": dict(GEMM_PP=7 | (2 << 7))}
     ab("dX N=512 priority", lambda: ops.gemm_nt(dP, wt, mixed=True, out_bf16=True), 2.0 * rows * 512 * D * 4 * H, VP, rounds=6)
+
+if "dma" in want:
+    for N in (512, 256):
+        wt = rnd((N, D * 4 * H), 0.05, torch.bfloat16)
+        VD = {"full kernel": dict(GEMM_PP=7), "DMA only, 8 in flight/wave": dict(GEMM_PP=7 | 1024),
+              "DMA only, 24 in flight/wave": dict(GEMM_PP=7 | 1024 | 2048)}
+        ab(f"dX N={N} operand DMA", lambda: ops.gemm_nt(dP, wt, mixed=True, out_bf16=True), 2.0 * rows * N * D * 4 * H, VD, rounds=5)
