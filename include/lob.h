@@ -191,7 +191,9 @@ int lob_gemm_tn_bf16(const void* A, int a_bf16, int lda, const void* B, int b_bf
  *   lstm.weight_ih_l* / weight_hh_l*, 04_lstm_model.py:490) from ONE pass over the bf16 gate gradients:
  *   dWih[D*4H][nx] += dP^T X and dWhh[D][4H][H] += dP[:, d]^T h_prev_d, where h_prev is Y one step (Bp rows)
  *   earlier (d = 0) or later (d = 1).  dP [T*Bp][ldp], X [T*Bp][ldx], Y [T*Bp][ldy] bf16 time-major; outputs
- *   fp32, zeroed by the caller.  H == 128, nx in {128, 256}, Bp % 32 == 0, T >= 2; else LOB_E_SHAPE.   */
+ *   fp32, zeroed by the caller.  H == 128, nx in {128, 256}, Bp % 32 == 0, T >= 2; or H == 256 (the size the reference
+ *   trains at 61 channels, 04_lstm_model.py:877), D == 2, nx in {256, 512}, Bp % 64 == 0, (T * Bp) % 128 == 0; else
+ *   LOB_E_SHAPE.                                                                                        */
 int lob_lstm_dw_bf16(const void* dP, int ldp, const void* X, int ldx, int nx, const void* Y, int ldy,
                      float* dWih, float* dWhh, int T, int Bp, int H, int D, void* stream);
 

@@ -984,6 +984,9 @@ int lob_gate_gemm_pp(const void* X, int ldx, const void* Wih, const float* bias,
                      hipStream_t s);
 int lob_gemm_tn_pp(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int Kc, int shift,
                    int ex_lo, int ex_hi, hipStream_t s);
+bool lob_dw_pp_ok(int T, int Bp, int H, int D, int nx);
+int lob_lstm_dw_pp(const void* dP, int ldp, const void* X, int ldx, int nx, const void* Y, int ldy, float* dWih, float* dWhh,
+                   int T, int Bp, int H, int D, hipStream_t s);
 
 // A: fp32 (a_bf16 = 0) or bf16 (a_bf16 = 1) row-major [M][lda]; W fp32 [N][ldw]; C fp32.
 inline int nt_stagger() {       // tuning knob LOB_NT_STAGGER (units of s_sleep(32) = 2048 clocks per group step)
@@ -1164,10 +1167,17 @@ extern "C" int lob_gemm_tn_bf16(const void* A, int a_bf16, int lda, const void* 
 }
 
 // dW_ih (D*4H x nx) and dW_hh (D x 4H x H) of one layer from one pass over dP; both outputs must be zeroed by the
-// caller (split-k partial sums are added atomically).  H = 128, nx in {128, 256}, Bp % 32 == 0, T >= 2.
+// caller (split-k partial sums are added atomically).  H = 128, nx in {128, 256}, Bp % 32 == 0, T >= 2; or H = 256,
+// D = 2, nx in {256, 512}, Bp % 64 == 0, (T * Bp) % 128 == 0.
 extern "C" int lob_lstm_dw_bf16(const void* dP, int ldp, const void* X, int ldx, int nx, const void* Y, int ldy,
                                 float* dWih, float* dWhh, int T, int Bp, int H, int D, void* stream) {
     if (!dP || !X || !Y || !dWih || !dWhh || T < 2 || Bp <= 0 || (D != 1 && D != 2)) return LOB_E_ARG;
+    if (H == 256) {        // the reference's checkpoint size: 256 x 384 / 256 x 256 ping-pong tiles (gemm_pp.hip)
+        if (!lob_dw_pp_ok(T, Bp, H, D, nx)) return LOB_E_SHAPE;
+        if (ldp < D * 4 * H || ldx < nx || ldy < D * H) return LOB_E_SHAPE;
+        if ((ldp % 8) || (ldx % 8) || (ldy % 8) || !al16(dP) || !al16(X) || !al16(Y)) return LOB_E_ALIGN;
+        return lob_lstm_dw_pp(dP, ldp, X, ldx, nx, Y, ldy, dWih, dWhh, T, Bp, H, D, (hipStream_t)stream);
+    }
     if (H != 128 || (nx != 128 && nx != 256) || (Bp % 32)) return LOB_E_SHAPE;
     if (ldp < D * 4 * H || ldx < nx || ldy < D * H) return LOB_E_SHAPE;
     if ((ldp % 8) || (ldx % 8) || (ldy % 8) || !al16(dP) || !al16(X) || !al16(Y)) return LOB_E_ALIGN;

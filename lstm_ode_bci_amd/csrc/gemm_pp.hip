@@ -952,6 +952,184 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(TNPPArgs g) {
         }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Both weight gradients of one H = 256 LSTM layer from ONE pass over dP (04_lstm_model.py:490 loss.backward() through
+// nn.LSTM, hidden_size = 256: 04:877):
+//     dW_ih[d] (4H x NX)  = sum_rows dP[row, d]^T X[row]
+//     dW_hh[d] (4H x H)   = sum_rows dP[row, d]^T h_prev_d[row],   h_prev_0[t] = Y[t-1, 0:H], h_prev_1[t] = Y[t+1, H:2H]
+// The ping-pong TN schedule above with a WIDER output tile: 256 dP-columns x 32 NCB x 4 columns of [X | h_prev_d]
+// (NCB = 3: 384 columns at NX = 512, NCB = 2: 256 at NX = 256), 8 waves as 2 x 4, 128 x 32 NCB accumulators per wave
+// (192 registers at NCB = 3).  Per dP-column tile the operand [X | h_prev_d] (NX + 256 columns) is exactly TWO such
+// tiles, so a layer is 8 x 2 = 16 tiles x 16 contraction chunks = 256 workgroups, the two chunks' worth of tiles that
+// share an XCD read each dP tile twice and each [X | h_prev] tile eight times out of ONE L2.  Against three launches of
+// the 256 x 256 kernel: dP crosses HBM once instead of twice, and a workgroup moves (256 + 384) x 2 B through L2 -> LDS
+// per 256 x 384 MFMA columns instead of (256 + 256) per 256 x 256: -17 % of the bytes that bound these kernels
+// (the CU's 39 B/clk LDS-DMA path, tools/pp_bench.py dma).
+// The B tile is two LDS images: 128 columns (256-B rows: NCB = 3 only) + 256 columns (512-B rows); tile 1 of a
+// dP-column tile takes its 256-column image from Y, shifted by one time step (Bp rows) -- k-tiles of the step without
+// a predecessor are fetched unshifted and their h_prev products skipped (Bp % 64 == 0: a k-tile never straddles steps).
+// LDS: A[2] 2 x 32 KB | B256[2] 2 x 32 KB | B128[2] 2 x 16 KB = 160 KB.
+// DMA per k-quarter and wave: one instruction for A, one for B256, and (waves 0-3, NCB = 3) one for B128: the one
+// counted wait per k-tile is vmcnt(9) for waves 0-3 and vmcnt(6) for waves 4-7.
+// ------------------------------------------------------------------------------------------------------------------
+struct DWPPArgs {
+    const __bf16* dP; const __bf16* X; const __bf16* Y; float* dWih; float* dWhh;
+    int ldp, ldx, ldy, nx, H, T, Bp, kchunk;
+};
+
+template <int NCB>
+__global__ __launch_bounds__(512, 2) void lstm_dw_pp_kernel(DWPPArgs g) {
+    constexpr int OA = 0, OB = 65536, OS = 131072;                    // LDS byte offsets: A[2], B256[2], B128[2]
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NCB == 3 ? 163840 : 131072];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+    const int tile = rest & 15, chunk = (rest >> 4) * 8 + xcd;        // 8 dP-column tiles x 2 operand tiles
+    const int mt = tile >> 1, nt = tile & 1;
+    const int m0 = mt << 8, d = m0 / (4 * g.H);
+    const int Kc = g.T * g.Bp;
+    const int kbeg = chunk * g.kchunk, kend = min(Kc, kbeg + g.kchunk);
+    if (kbeg >= kend) return;
+    const int total = (kend - kbeg) >> 6;
+    // rows [ex_lo, ex_hi) of dP have no h_prev
+    const int ex_lo = d == 0 ? 0 : (g.T - 1) * g.Bp, ex_hi = ex_lo + g.Bp;
+    const int yshift = d == 0 ? -g.Bp : g.Bp;
+
+    // ---- the two B images of this operand tile: source, leading dimension, time shift; and where their products go
+    const bool y256 = nt == 1;                                          // the 256-column image comes from h_prev
+    const __bf16* s256 = y256 ? g.Y + d * g.H : g.X + (NCB == 3 ? 128 : 0);
+    const int ld256 = y256 ? g.ldy : g.ldx;
+    const __bf16* s128 = g.X + (nt == 0 ? 0 : 384);                    // NCB = 3 only: X columns 0-127 / 384-511
+    float* o256 = y256 ? g.dWhh : g.dWih + (NCB == 3 ? 128 : 0);
+    const int lo256 = y256 ? g.H : g.nx;
+    float* o128 = g.dWih + (nt == 0 ? 0 : 384);
+
+    // ---- producer
+    const int kr2 = 2 * wave + (lane >> 5), ch = lane & 31;            // 512-B rows: 2 k-rows per instruction
+    const unsigned asrc = 2u * (unsigned)(kr2 * g.ldp + ((ch ^ ((kr2 & 3) << 2)) << 3));
+    const unsigned bsrc = 2u * (unsigned)(kr2 * ld256 + ((ch ^ ((kr2 & 3) << 2)) << 3));
+    const int kr4 = 4 * (wave & 3) + (lane >> 4), c16 = lane & 15;      // 256-B rows: 4 k-rows per instruction (waves 0-3)
+    const unsigned ssrc = 2u * (unsigned)(kr4 * g.ldx + ((c16 ^ ((kr4 & 3) << 2)) << 3));
+    const char* const a_base = reinterpret_cast<const char*>(g.dP + m0);
+    const char* const b_base = reinterpret_cast<const char*>(s256);
+    const char* const s_base = reinterpret_cast<const char*>(s128);
+    unsigned char* const w_dst = lds + wave * 1024;
+    const bool seg_wave = NCB == 3 && wave < 4;
+    auto stage = [&](int p, int buf, int kq) {
+        const int pp = p < total ? p : total - 1;
+        const int k0 = kbeg + 64 * pp;
+        const bool ex = k0 >= ex_lo && k0 < ex_hi;
+        const size_t kr = (size_t)(k0 + 16 * kq);
+        const char* pa = a_base + kr * g.ldp * 2;
+        const char* pb = b_base + (size_t)((long)kr + ((y256 && !ex) ? yshift : 0)) * ld256 * 2;
+        __builtin_amdgcn_global_load_lds((gbl_cvoid*)(pa + asrc), (lds_void*)(w_dst + OA + buf * 32768 + kq * 8192), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_cvoid*)(pb + bsrc), (lds_void*)(w_dst + OB + buf * 32768 + kq * 8192), 16, 0, 0);
+        if (seg_wave) {
+            const char* ps = s_base + kr * g.ldx * 2;
+            __builtin_amdgcn_global_load_lds((gbl_cvoid*)(ps + ssrc), (lds_void*)(w_dst + OS + buf * 16384 + kq * 4096), 16, 0, 0);
+        }
+    };
+
+    // ---- consumer: tr-read addresses.  256-column images: element (k-row 8 h + q, column 32 b + 16 mh + 4 p) at byte
+    //      (8 h + q) 512 + 64 (b ^ q) + 32 mh + 8 p; 128-column image: (8 h + q) 256 + 64 (b ^ q) + 32 mh + 8 p
+    const int fh = lane >> 5, fmh = (lane >> 4) & 1, fq = (lane >> 2) & 3, fp = lane & 3;
+    const unsigned lds_b = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const unsigned in512 = (unsigned)((8 * fh + fq) * 512 + 32 * fmh + 8 * fp), in256 = (unsigned)((8 * fh + fq) * 256 + 32 * fmh + 8 * fp);
+    unsigned av[4], bv[NCB];
+    bool b_small[NCB];                      // this wave's column block cb lives in the 128-column image
+#pragma unroll
+    for (int i = 0; i < 4; ++i) av[i] = lds_b + OA + in512 + 64u * (unsigned)((4 * wr + i) ^ fq);
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) {
+        const int jb = wc * NCB + c;                                   // 32-column block of the B tile
+        b_small[c] = NCB == 3 && jb < 4;
+        if (b_small[c]) bv[c] = lds_b + OS + in256 + 64u * (unsigned)(jb ^ fq);
+        else            bv[c] = lds_b + OB + in512 + 64u * (unsigned)((jb - (NCB == 3 ? 4 : 0)) ^ fq);
+    }
+
+    f32x16 acc[4][NCB];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < NCB; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][c][r] = 0.f;
+
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) stage(0, 0, kq);
+#pragma unroll
+    for (int kq = 0; kq < 3; ++kq) stage(1, 1, kq);
+    if (seg_wave) asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    PP_BAR();
+    if (wr == 1) PP_BAR();
+
+    bf16x4 al[4], ah[4], bl[NCB], bh[NCB];
+#define PP_FRAG(l, h) bf16x8{l[0], l[1], l[2], l[3], h[0], h[1], h[2], h[3]}
+    auto phase = [&](auto bufc, auto ksc, int q, bool on) {
+        constexpr int BUF = decltype(bufc)::value, KS = decltype(ksc)::value;
+        constexpr int O5 = BUF * 32768 + KS * 8192, O2 = BUF * 16384 + KS * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { PP_TR(al[i], av[i], O5); PP_TR(ah[i], av[i], O5 + 2048); }
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) {
+            if (b_small[c]) { PP_TR(bl[c], bv[c], O2); PP_TR(bh[c], bv[c], O2 + 1024); }
+            else            { PP_TR(bl[c], bv[c], O5); PP_TR(bh[c], bv[c], O5 + 2048); }
+        }
+        if constexpr (KS == 0) stage(q + 1, BUF ^ 1, 3);
+        else                   stage(q + 2, BUF, KS - 1);
+        if constexpr (NCB == 3)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(al[0]), "+v"(ah[0]), "+v"(al[1]), "+v"(ah[1]), "+v"(al[2]), "+v"(ah[2]),
+                         "+v"(al[3]), "+v"(ah[3]), "+v"(bl[0]), "+v"(bh[0]), "+v"(bl[1]), "+v"(bh[1]), "+v"(bl[NCB - 1]),
+                         "+v"(bh[NCB - 1]));
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(al[0]), "+v"(ah[0]), "+v"(al[1]), "+v"(ah[1]), "+v"(al[2]), "+v"(ah[2]),
+                         "+v"(al[3]), "+v"(ah[3]), "+v"(bl[0]), "+v"(bh[0]), "+v"(bl[1]), "+v"(bh[1]));
+        if constexpr (KS == 3) {          // k-tile q + 1 complete (this wave's share)
+            if (seg_wave) asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        }
+        PP_BAR();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) {
+            if (!on && y256 && !b_small[c]) continue;                  // h_prev products of the step without a predecessor
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][c] = pp_mfma(PP_FRAG(al[i], ah[i]), PP_FRAG(bl[c], bh[c]), acc[i][c]);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        PP_BAR();
+    };
+    auto ktile = [&](auto bufc, int q) {
+        const int k0 = kbeg + 64 * q;
+        const bool on = !(k0 >= ex_lo && k0 < ex_hi);
+        phase(bufc, std::integral_constant<int, 0>{}, q, on);
+        phase(bufc, std::integral_constant<int, 1>{}, q, on);
+        phase(bufc, std::integral_constant<int, 2>{}, q, on);
+        phase(bufc, std::integral_constant<int, 3>{}, q, on);
+    };
+    for (int q = 0; q < total; q += 2) {
+        ktile(std::integral_constant<int, 0>{}, q);
+        ktile(std::integral_constant<int, 1>{}, q + 1);
+    }
+    if (wr == 0) PP_BAR();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef PP_FRAG
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) {
+        const int jb = wc * NCB + c;
+        float* out = b_small[c] ? o128 : o256;
+        const int ldo = b_small[c] ? g.nx : lo256;
+        const int col = 32 * (b_small[c] ? jb : jb - (NCB == 3 ? 4 : 0)) + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wr * 128 + 32 * i + acc_row(r, lane);
+                atomicAdd(out + (size_t)row * ldo + col, acc[i][c][r]);
+            }
+    }
+}
+
 // Diagnostic: the operand DMA of gemm_nt_pp_kernel ALONE -- same tile walk, same source addresses, same 1-KB
 // global_load_lds_dwordx4 instructions into LDS, but no barriers, no reads, no MFMAs, DEPTH instructions in flight per wave.
 // What the L2 -> LDS path delivers for this traffic mix (A once from HBM and once from L2 / MALL, B from L2) is the floor
@@ -1086,6 +1264,32 @@ int lob_gemm_tn_pp(const void* A, int lda, const void* B, int ldb, float* C, int
     TNPPArgs g{(const __bf16*)A, (const __bf16*)B, C, lda, ldb, ldc, M, N, Kc, (int)kchunk, tiles, shift, ex_lo, ex_hi};
     if (lob_variant(LOB_VAR_GEMM_PP) & 8) hipLaunchKernelGGL(gemm_tn_ring_kernel, dim3((unsigned)(tiles * nchunk8)), dim3(512), 0, s, g);
     else                                  hipLaunchKernelGGL(gemm_tn_pp_kernel, dim3((unsigned)(tiles * nchunk8)), dim3(512), 0, s, g);
+    LOB_CHECK_LAUNCH();
+    return 0;
+}
+
+// dW_ih (D*4H x nx) and dW_hh (D x 4H x H) of one H = 256 layer from one pass over dP (outputs zeroed / accumulated into
+// by the caller; fp32 atomics).  nx in {256, 512}, D = 2, Bp % 64 == 0, (T * Bp) % 128 == 0, T >= 2.
+bool lob_dw_pp_ok(int T, int Bp, int H, int D, int nx) {
+    return H == 256 && D == 2 && (nx == 256 || nx == 512) && T >= 2 && (Bp % 64) == 0 && ((long)T * Bp) % 128 == 0 &&
+           (long)T * Bp >= 128;
+}
+int lob_lstm_dw_pp(const void* dP, int ldp, const void* X, int ldx, int nx, const void* Y, int ldy, float* dWih, float* dWhh,
+                   int T, int Bp, int H, int D, hipStream_t s) {
+    if (!lob_dw_pp_ok(T, Bp, H, D, nx)) return LOB_E_SHAPE;
+    if ((long)16 * ldp * 2 >= (1L << 31)) return LOB_E_SHAPE;
+    const long Kc = (long)T * Bp;
+    int nchunk = 16;                                             // 16 tiles x 16 chunks = one workgroup per CU
+    long kchunk = (Kc + nchunk - 1) / nchunk;
+    kchunk = ((kchunk + 127) / 128) * 128;
+    if (kchunk < 1024) kchunk = 1024;
+    if (kchunk > Kc) kchunk = Kc;
+    nchunk = (int)((Kc + kchunk - 1) / kchunk);
+    const int nchunk8 = ((nchunk + 7) / 8) * 8;
+    DWPPArgs g{(const __bf16*)dP, (const __bf16*)X, (const __bf16*)Y, dWih, dWhh, ldp, ldx, ldy, nx, H, T, Bp, (int)kchunk};
+    const dim3 grid((unsigned)(16 * nchunk8)), block(512);
+    if (nx == 512) hipLaunchKernelGGL(lstm_dw_pp_kernel<3>, grid, block, 0, s, g);
+    else           hipLaunchKernelGGL(lstm_dw_pp_kernel<2>, grid, block, 0, s, g);
     LOB_CHECK_LAUNCH();
     return 0;
 }

@@ -33,7 +33,8 @@ const VarDef kVars[LOB_VAR_COUNT] = {
     {"LOB_H256_LDSW", 1},     // LOB_VAR_H256_LDSW
     {"LOB_DX_KSPLIT", 1},     // LOB_VAR_DX_KSPLIT
     {"LOB_REC_FEW", 1},       // LOB_VAR_REC_FEW
-    {"LOB_GEMM_PP", 5},       // LOB_VAR_GEMM_PP (dX + weight gradients; the gate GEMM stays weight-stationary: measured faster)
+    {"LOB_GEMM_PP", 517},     // LOB_VAR_GEMM_PP: dX (bit 0, on v_mfma_16x16x32: bit 9) + weight gradients (bit 2); the gate GEMM
+                              // (bit 1) stays weight-stationary: measured faster
 };
 std::atomic<int> g_vals[LOB_VAR_COUNT];
 std::atomic<int> g_init{0};

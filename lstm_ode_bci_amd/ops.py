@@ -168,8 +168,10 @@ def fused_dw_enabled():
 
 def can_fuse_dw(dP, inp, Y, T, Bp, H, D):
     bf = torch.bfloat16
-    return (fused_dw_enabled() and H == 128 and T >= 2 and Bp % 32 == 0 and dP.dtype == bf and inp.dtype == bf and Y.dtype == bf
-            and inp.shape[1] in (128, 256) and dP.shape[1] == D * 4 * H and Y.shape[1] == D * H
+    shape_ok = ((H == 128 and Bp % 32 == 0 and inp.shape[1] in (128, 256)) or
+                (H == 256 and D == 2 and Bp % 64 == 0 and (T * Bp) % 128 == 0 and inp.shape[1] in (256, 512)))
+    return (fused_dw_enabled() and shape_ok and T >= 2 and dP.dtype == bf and inp.dtype == bf and Y.dtype == bf
+            and dP.shape[1] == D * 4 * H and Y.shape[1] == D * H
             and dP.stride(1) == 1 and inp.stride(1) == 1 and Y.stride(1) == 1
             and dP.stride(0) % 8 == 0 and inp.stride(0) % 8 == 0 and Y.stride(0) % 8 == 0
             and dP.data_ptr() % 16 == 0 and inp.data_ptr() % 16 == 0 and Y.data_ptr() % 16 == 0)

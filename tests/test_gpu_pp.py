@@ -163,3 +163,51 @@ def test_pp_full_size_against_twins(dev, PP):
     with _lib.variant(GEMM_PP=0):
         dwh0 = ops.gemm_tn(dP[Bp:, :4 * H], y[:(T - 1) * Bp, :H], torch.zeros((4 * H, H), device=dev))
     assert float((dwh - dwh0).abs().max()) <= 2e-5 * float(dwh0.abs().max())
+
+
+@pytest.mark.parametrize("T,Bp,nx", [(2, 64, 512), (4, 64, 256), (9, 128, 512), (6, 192, 256), (256, 64, 512), (33, 256, 512)])
+def test_fused_h256_layer_weight_gradients_vs_float64(dev, T, Bp, nx):
+    """lstm_dw_pp_kernel (256 x 384 / 256 x 256 ping-pong tiles): dW_ih and dW_hh of an H = 256 layer from one pass over
+    dP == the exact products of the same bf16 operands, including the time shift of h_prev (t - 1 forward, t + 1
+    reverse), the step without a predecessor, operands that are column slices of wider tensors, several contraction
+    chunks per tile and a ragged last chunk."""
+    from lstm_ode_bci_amd import ops
+    H, D = 256, 2
+    bf = torch.bfloat16
+    dP = _rand((T * Bp, D * 4 * H), dev, T * Bp + nx, 1.0, bf)
+    Xw = _rand((T * Bp, nx + 64), dev, 1 + nx, 1.0, bf)
+    X = Xw[:, :nx]
+    Y = _rand((T * Bp, D * H), dev, 2 + T, 1.0, bf)
+    assert ops.can_fuse_dw(dP, X, Y, T, Bp, H, D)
+    dwih, dwhh = ops.lstm_dw(dP, X, Y, T, Bp, H, D)
+    dwih2, dwhh2 = ops.lstm_dw(dP, X, Y, T, Bp, H, D)
+    p64, x64, y64 = dP.double(), X.double(), Y.double()
+    tol = 2e-5 * (T * Bp) ** 0.5 * 4
+    assert (dwih.double() - p64.T @ x64).abs().max().item() < tol
+    for d in range(D):
+        a = p64[:, d * 4 * H:(d + 1) * 4 * H]
+        y = y64[:, d * H:(d + 1) * H]
+        ref = a[Bp:].T @ y[:(T - 1) * Bp] if d == 0 else a[:(T - 1) * Bp].T @ y[Bp:]
+        assert (dwhh[d].double() - ref).abs().max().item() < tol, d
+    assert (dwih - dwih2).abs().max().item() <= 1e-4 * dwih.abs().max().item()      # atomics: order only
+    assert not ops.can_fuse_dw(dP, X, Y, T, 32, H, D) and not ops.can_fuse_dw(dP.float(), X, Y, T, Bp, H, D)
+
+
+def test_fused_h256_dw_full_size_against_separate_gemms(dev):
+    """rows = 256 * 4096: the fused kernel against three launches of the 256 x 256 TN kernel (split-k + atomics on both
+    sides: fp32 rounding of 1M-term sums)."""
+    from lstm_ode_bci_amd import _lib, ops
+    T, Bp, H, D = 256, 4096, 256, 2
+    rows = T * Bp
+    dP = _rand((rows, D * 4 * H), dev, 41, 1e-2, torch.bfloat16)
+    Y = _rand((rows, D * H), dev, 42, 1.0, torch.bfloat16)
+    for nx in (512, 256):
+        X = _rand((rows, nx), dev, 43, 1.0, torch.bfloat16)
+        dwih, dwhh = ops.lstm_dw(dP, X, Y, T, Bp, H, D)
+        ref_ih = ops.gemm_tn(dP, X, torch.zeros_like(dwih))
+        ref_hh = torch.zeros_like(dwhh)
+        ops.gemm_tn(dP[Bp:, :4 * H], Y[:(T - 1) * Bp, :H], ref_hh[0])
+        ops.gemm_tn(dP[:(T - 1) * Bp, 4 * H:], Y[Bp:, H:], ref_hh[1])
+        for got, ref, nm in ((dwih, ref_ih, "dW_ih"), (dwhh, ref_hh, "dW_hh")):
+            err = (got - ref).abs().max().item()
+            assert err <= 2e-4 * ref.abs().max().item(), (nx, nm, err, ref.abs().max().item())

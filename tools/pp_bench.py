@@ -78,3 +78,18 @@ if "dma" in want:
         VD = {"full kernel": dict(GEMM_PP=7), "DMA only, 8 in flight/wave": dict(GEMM_PP=7 | 1024),
               "DMA only, 24 in flight/wave": dict(GEMM_PP=7 | 1024 | 2048)}
         ab(f"dX N={N} operand DMA", lambda: ops.gemm_nt(dP, wt, mixed=True, out_bf16=True), 2.0 * rows * N * D * 4 * H, VD, rounds=5)
+
+if "fused" in want or not want:
+    Y = rnd((rows, D * H), 1.0, torch.bfloat16)
+    for nx in (512, 256):
+        X = rnd((rows, nx), 1.0, torch.bfloat16)
+        o1 = torch.zeros((D * 4 * H, nx), device=dev)
+        o2 = torch.zeros((D, 4 * H, H), device=dev)
+
+        def separate():
+            ops.gemm_tn(dP, X, o1)
+            ops.gemm_tn(dP[Bp:, :4 * H], Y[:(T - 1) * Bp, :H], o2[0])
+            ops.gemm_tn(dP[:(T - 1) * Bp, 4 * H:], Y[Bp:, H:], o2[1])
+        fl = 2.0 * rows * D * 4 * H * (nx + H)
+        ab(f"layer dW nx={nx}: fused", lambda: ops.lstm_dw(dP, X, Y, T, Bp, H, D, out=(o1, o2)), fl, {"fused 1 launch": dict(GEMM_PP=5)})
+        ab(f"layer dW nx={nx}: separate", separate, fl, {"3 launches pp": dict(GEMM_PP=5), "3 launches twin": dict(GEMM_PP=0)})
