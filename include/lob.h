@@ -78,13 +78,15 @@ const char* lob_build_id(void);
 #define LOB_VAR_FUSED_DW     13  /* read by the Python host: 1 = dW_ih and dW_hh from one pass (lob_lstm_dw_bf16)  */
 #define LOB_VAR_F32_SPLIT    14  /* 1: fp32 gate GEMMs / recurrent forward (H=128) carry each operand as two fp16 halves
                                   *    (22 bits) on the 16-bit matrix pipe; 0: exact-fp32 MFMA                     */
-#define LOB_VAR_REC_F32_HALF 15  /* 1: fp32 recurrent forward may split the gate columns over two workgroups       */
-#define LOB_VAR_H256_LDSW    16  /* H=256 recurrent kernels: 0 = all W_hh fragments streamed; 1 = part of them resident in LDS      */
-#define LOB_VAR_DX_KSPLIT    17  /* 1: dX = dP W_ih on the k-split weight-stationary kernel; 0: tiled LDS-DMA NT GEMM          */
-#define LOB_VAR_REC_FEW      18  /* 1: mixed inference forward with fewer than 4 windows skips the padding registers' cell update */
-#define LOB_VAR_GEMM_PP      19  /* bit mask, H=256 mixed step: 1 = dX, 2 = gate GEMM, 4 = weight gradients on the 8-wave
-                                  *    ping-pong 256x256x64 kernels (csrc/gemm_pp.hip); 0 bits: the tiled / weight-stationary twins */
-#define LOB_VAR_COUNT        20
+#define LOB_VAR_H256_LDSW    15  /* H=256 recurrent kernels: 0 = all W_hh fragments streamed; 1 = part of them resident in LDS      */
+#define LOB_VAR_DX_KSPLIT    16  /* 1: dX = dP W_ih on the k-split weight-stationary kernel; 0: tiled LDS-DMA NT GEMM          */
+#define LOB_VAR_REC_FEW      17  /* 1: mixed inference forward with fewer than 4 windows skips the padding registers' cell update */
+#define LOB_VAR_GEMM_PP      18  /* bit mask, H=256 mixed step: 1 = dX, 2 = gate GEMM, 4 = weight gradients on the 8-wave
+                                  *    ping-pong 256x256x64 kernels (csrc/gemm_pp.hip); 0 bits: the tiled / weight-stationary
+                                  *    twins.  512 = dX on v_mfma_f32_16x16x32_bf16 (default: 1 | 4 | 512).  Diagnostic builds
+                                  *    (garbage results, tools/pp_bench.py): 8 = ring schedule, 16..64 = ablations,
+                                  *    128 / 256 = priority protocol, 1024 / 2048 = operand DMA alone                          */
+#define LOB_VAR_COUNT        19
 int lob_debug_set_variant(int which, int value);
 int lob_debug_get_variant(int which);
 

@@ -121,7 +121,7 @@ def _check_build_id(l):
 # kernel-variant switches (include/lob.h LOB_VAR_*): test-only
 VAR = {"REC_BWD_DMA": 0, "NT_DMA": 1, "DMA_TILE": 2, "DMA_KT": 3, "NT_ADEEP": 4, "GATE_WS": 5, "REC_BF16_ROWS": 6,
        "F32_DMA": 7, "REC_FWD_ROWS": 8, "LN_LPR": 9, "NT_WGS": 10, "NT_TK": 11, "NT_STAGGER": 12, "FUSED_DW": 13,
-       "F32_SPLIT": 14, "REC_F32_HALF": 15, "H256_LDSW": 16, "DX_KSPLIT": 17, "REC_FEW": 18, "GEMM_PP": 19}
+       "F32_SPLIT": 14, "H256_LDSW": 15, "DX_KSPLIT": 16, "REC_FEW": 17, "GEMM_PP": 18}
 
 
 def get_variant(name):

@@ -72,6 +72,11 @@ def build(force=False, verbose=True, check_isa=True):
         raise RuntimeError("hipcc not found: cannot build liblob.so")
     objdir = os.path.join(PKG, "build")
     os.makedirs(objdir, exist_ok=True)
+    # objects of sources that no longer exist (a dropped kernel) must not linger next to the ones that are linked
+    live = {os.path.basename(src)[:-4] + ".o" for src in sources()}
+    for f in os.listdir(objdir):
+        if f.endswith(".o") and f not in live:
+            os.remove(os.path.join(objdir, f))
     objs = []
     procs = []
     bid = source_id()

@@ -29,7 +29,6 @@ const VarDef kVars[LOB_VAR_COUNT] = {
     {"LOB_NT_STAGGER", 0},    // LOB_VAR_NT_STAGGER
     {"LOB_FUSED_DW", 1},      // LOB_VAR_FUSED_DW (host-side choice, kept here so that one table lists them all)
     {"LOB_F32_SPLIT", 1},     // LOB_VAR_F32_SPLIT
-    {"LOB_REC_F32_HALF", 1},  // LOB_VAR_REC_F32_HALF
     {"LOB_H256_LDSW", 1},     // LOB_VAR_H256_LDSW
     {"LOB_DX_KSPLIT", 1},     // LOB_VAR_DX_KSPLIT
     {"LOB_REC_FEW", 1},       // LOB_VAR_REC_FEW

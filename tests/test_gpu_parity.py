@@ -123,6 +123,8 @@ def test_attention_pool_vs_oracle(dev):
     att = Attention(Wd).to(dev)
     v = rng.standard_normal((B, T, Wd), dtype=np.float32)
     ctx, w = att(torch.from_numpy(v).to(dev))
+    assert ctx.requires_grad and w.requires_grad          # an ordinary trainable nn.Module, as 04_lstm_model.py:112-128
+    ctx, w = ctx.detach(), w.detach()
     sd = {k: p.detach().cpu().numpy().astype(np.float64) for k, p in att.state_dict().items()}
     u = np.tanh(v @ sd["attention.0.weight"].T + sd["attention.0.bias"])
     s = u @ sd["attention.2.weight"].T + sd["attention.2.bias"]

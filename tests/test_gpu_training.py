@@ -464,7 +464,8 @@ def test_gradient_sink_equals_autograd_accumulation(dev, mixed, kw):
     crit = WeightedCrossEntropy(torch.tensor([0.8, 1.2])).to(dev)
     o1 = FusedAdamW(m1.parameters(), lr=3e-4, weight_decay=1e-4, model=m1)          # sink
     o2 = FusedAdamW(m2.parameters(), lr=3e-4, weight_decay=1e-4)                    # plain autograd accumulation
-    assert m1._lob_grad_sink() is o1 and getattr(m2, "_lob_grad_sink", None) is None
+    from lstm_ode_bci_amd.training import grad_sink_of
+    assert grad_sink_of(m1) is o1 and grad_sink_of(m2) is None and not hasattr(m1, "_lob_grad_sink")
 
     def run(m, o, drop_grads=False):
         o.zero_grad()
@@ -490,4 +491,4 @@ def test_gradient_sink_equals_autograd_accumulation(dev, mixed, kw):
     # detaching restores autograd's own accumulation
     o1.detach_model()
     g1 = run(m1, o1)
-    assert m1._lob_grad_sink is None and all(torch.isfinite(v).all() for v in g1.values())
+    assert grad_sink_of(m1) is None and all(torch.isfinite(v).all() for v in g1.values())

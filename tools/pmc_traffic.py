@@ -31,6 +31,14 @@ KERNELS = {
     "gemm_nt(dX)": [("mixed", "dx_ksplit_kernel<4>")],
     "lstm_dw(dW_ih+dW_hh)": [("mixed", "lstm_dw_h128_kernel<256>")],
 }
+# H = 256 (bench --hidden 256): the kernels of the reference's checkpoint size
+KERNELS_H256 = {
+    "lstm_rec_fwd(save)": [("mixed", "lstm_rec_fwd_h256_bf16_kernelILb1ELb0ELb1ELb1E")],
+    "lstm_rec_bwd": [("mixed", "lstm_rec_bwd_h256_bf16_kernel")],
+    "gate_gemm_x(K=512)": [("mixed", "gate_gemm_ws_kernel<512, 0, 256>")],
+    "gemm_nt(dX)": [("mixed", "gemm_nt_pp16_kernel")],
+    "lstm_dw(dW_ih+dW_hh)": [("mixed", "lstm_dw_pp_kernel<3>")],
+}
 
 
 def load(path, counter):
@@ -61,7 +69,7 @@ def main():
         wr.writerows(rows)
     jpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     table = json.load(open(jpath)) if os.path.exists(jpath) else {}
-    for label, alts in KERNELS.items():
+    for label, alts in (KERNELS if H == 128 else KERNELS_H256).items():
         for prec, sub in alts:
             for r in rows:
                 if sub in r["kernel"]:
