@@ -379,8 +379,9 @@ int lob_abs_colsum_f32(const float* gx, int64_t rows, int C, float scale, float*
 #define LOB_PREP_MAX 64
 #define LOB_PREP_TRANSPOSE 1
 #define LOB_PREP_BF16 2
-#define LOB_PREP_ABSMAX 4   /* dst[0] (fp32) = max |src[r][c]|: the operand range of the fp16-split kernels, see `range` of
-                             * lob_gate_gemm_x_f32 / lob_lstm_rec_fwd_f32 (one workgroup; no other field of the op is used) */
+#define LOB_PREP_ABSMAX 4   /* dst[0] (fp32, ZEROED by the caller) = max(dst[0], max |src[r][c]|): the operand range of the
+                             * fp16-split kernels, see `range` of lob_gate_gemm_x_f32 / lob_lstm_rec_fwd_f32 (atomic max
+                             * over blocks of 8192 elements; no other field of the op is used)                          */
 #define LOB_PREP_LNBOUND 8  /* dst[0] = (sqrt(cols) max|src| + max|src2|) * reserved / 1000: an upper bound on
                              * |dropout(GELU(LayerNorm(.)))| from the LayerNorm's gain (src) and bias (src2) -- what the
                              * first LSTM layer's gate GEMM can see as an activation; src == NULL: dst[0] = reserved / 1000 */

@@ -18,13 +18,12 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(PrepArgs a) {
     for (int i = 1; i < a.nop; ++i) if ((int)blockIdx.x >= a.op[i].blk0) o = i;
     const LobPrepOp& p = a.op[o];
     const int b = blockIdx.x - p.blk0;
-    if (p.kind & (LOB_PREP_ABSMAX | LOB_PREP_LNBOUND)) {      // one workgroup: operand ranges of the fp16-split kernels
+    if (p.kind & LOB_PREP_LNBOUND) {      // one workgroup: the LayerNorm-derived activation bound (or a constant)
         __shared__ float red[2][4];
         float m1 = 0.f, m2 = 0.f;
         if (p.src)
-            for (long i = threadIdx.x; i < (long)p.rows * p.cols; i += 256)
-                m1 = fmaxf(m1, fabsf(p.src[(i / p.cols) * p.ld_src + i % p.cols]));
-        if ((p.kind & LOB_PREP_LNBOUND) && p.src2)
+            for (int i = threadIdx.x; i < p.cols; i += 256) m1 = fmaxf(m1, fabsf(p.src[i]));
+        if (p.src2)
             for (int i = threadIdx.x; i < p.cols; i += 256) m2 = fmaxf(m2, fabsf(p.src2[i]));
         m1 = wave_max(m1); m2 = wave_max(m2);
         if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = m1; red[1][threadIdx.x >> 6] = m2; }
@@ -32,9 +31,25 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(PrepArgs a) {
         if (threadIdx.x == 0) {
             m1 = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
             m2 = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
-            float v = m1;
-            if (p.kind & LOB_PREP_LNBOUND) v = (p.src ? sqrtf((float)p.cols) * m1 + m2 : 1.0f) * (p.reserved * 1e-3f);
-            reinterpret_cast<float*>(p.dst)[0] = v;
+            reinterpret_cast<float*>(p.dst)[0] = (p.src ? sqrtf((float)p.cols) * m1 + m2 : 1.0f) * (p.reserved * 1e-3f);
+        }
+        return;
+    }
+    if (p.kind & LOB_PREP_ABSMAX) {       // max |src| of this block's 8192 elements -> atomic max on the (zeroed) slot:
+        __shared__ float red[4];           // non-negative floats order like their bit patterns
+        const long n = (long)p.rows * p.cols;
+        float m = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) {
+            const long i = (long)b * 8192 + k * 256 + threadIdx.x;
+            if (i < n) m = fmaxf(m, fabsf(p.src[(i / p.cols) * p.ld_src + i % p.cols]));
+        }
+        m = wave_max(m);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+            atomicMax(reinterpret_cast<unsigned*>(p.dst), __builtin_bit_cast(unsigned, m));
         }
         return;
     }
@@ -72,7 +87,7 @@ extern "C" int lob_prep_weights(const LobPrepOp* ops, int nop, void* stream) {
             if (!p.dst || ((p.kind & LOB_PREP_ABSMAX) && !p.src)) return LOB_E_ARG;
             if (p.src && (p.rows <= 0 || p.cols <= 0 || p.ld_src < p.cols)) return LOB_E_ARG;
             a.op[i].blk0 = blocks;
-            blocks += 1;
+            blocks += (p.kind & LOB_PREP_ABSMAX) ? (int)(((long)p.rows * p.cols + 8191) / 8192) : 1;
             continue;
         }
         if (!p.src || !p.dst || p.rows <= 0 || p.cols <= 0 || p.ld_src < p.cols) return LOB_E_ARG;

@@ -95,7 +95,7 @@ def build(ps, cfg, x_shape, need_grad):
     # sqrt(H) max|gain| + max|bias| (no bound with nn.Identity in its place: that layer's GEMM runs exact); the other
     # layers see |h| < 1 (times the dropout scale in train mode).
     want_range = bool(not mixed and frag and H == 128 and _lib.get_variant("F32_SPLIT") != 0)
-    rng = new((L * (2 * D + 1),)) if want_range else None
+    rng = torch.zeros((L * (2 * D + 1),), device=dev, dtype=f32) if want_range else None      # atomic-max targets
     base = 4
     for layer in range(L):
         dirs = [ps[base + 4 * d: base + 4 * d + 4] for d in range(D)]
