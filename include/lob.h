@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LOB_VERSION 202
+#define LOB_VERSION 203
 
 #define LOB_E_ARG   (-1)   /* null pointer / non-positive size                      */
 #define LOB_E_SHAPE (-2)   /* shape not supported by this kernel (see each entry)   */
@@ -86,7 +86,10 @@ const char* lob_build_id(void);
                                   *    twins.  512 = dX on v_mfma_f32_16x16x32_bf16 (default: 1 | 4 | 512).  Diagnostic builds
                                   *    (garbage results, tools/pp_bench.py): 8 = ring schedule, 16..64 = ablations,
                                   *    128 / 256 = priority protocol, 1024 / 2048 = operand DMA alone                          */
-#define LOB_VAR_COUNT        19
+#define LOB_VAR_H256_PAIR    19  /* H=256 mixed recurrent forward with a workspace (lob_lstm_rec_fwd_bf16_ws): 1 = the two-workgroup
+                                  *    kernel (W_hh resident, h halves exchanged; csrc/lstm_rec_h256_pair.hip), 0 (default) = the
+                                  *    single-workgroup kernel: the pair kernel measured only 3-6 % faster        */
+#define LOB_VAR_COUNT        20
 int lob_debug_set_variant(int which, int value);
 int lob_debug_get_variant(int which);
 
@@ -210,6 +213,18 @@ int lob_lstm_dw_bf16(const void* dP, int ldp, const void* X, int ldx, int nx, co
 int lob_lstm_rec_fwd_bf16(void* P, int pg_bf16, const float* Whh, const void* Whh16, float* Y, void* Csave, int c_bf16,
                           void* Y16, void* Yd, float drop_p, uint64_t seed,
                           int T, int Bp, int H, int D, int save, int nvalid, void* stream);
+/* The same with a caller-provided scratch buffer: at H == 256 and Bp % 64 == 0 a workspace of at least
+ * lob_rec_pair_ws_bytes(H, Bp, D) bytes (16-byte aligned, contents irrelevant, not shared between launches that may
+ * run concurrently) AND LOB_VAR_H256_PAIR = 1 select the two-workgroup kernel: each CU keeps HALF of W_hh resident and the two sides exchange
+ * their halves of h every step through the workspace (no per-step weight stream).  Same results up to fp32 rounding of
+ * the MFMA shape.  ws == NULL, a short workspace or any other shape: exactly lob_lstm_rec_fwd_bf16.
+ * lob_rec_pair_ws_bytes returns 0 where the kernel does not apply.  The first 32-bit word of the workspace is 0 after
+ * a good launch; non-zero = an exchange wait ran into its bound (seconds: the partner workgroup never arrived) and
+ * the launch's results are invalid -- the caller must check it.                                                       */
+size_t lob_rec_pair_ws_bytes(int H, int Bp, int D);
+int lob_lstm_rec_fwd_bf16_ws(void* P, int pg_bf16, const float* Whh, const void* Whh16, float* Y, void* Csave, int c_bf16,
+                             void* Y16, void* Yd, float drop_p, uint64_t seed,
+                             int T, int Bp, int H, int D, int save, int nvalid, void* ws, size_t ws_bytes, void* stream);
 /*   nvalid: how many of the Bp rows carry windows (rows >= nvalid are padding); 0 = unknown / all.  Only a hint: with
  *   save == 0, bf16 P, H == 128 and nvalid < 4 the padding rows' cell update is skipped and their outputs are zeros.  */
 /*   c_bf16 = 1 (H == 128, 16-row kernels, bf16 saved gates): the cell states saved for BPTT are stored as bf16, in the

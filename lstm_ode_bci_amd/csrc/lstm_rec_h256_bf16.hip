@@ -32,6 +32,11 @@
 #ifndef LOB_NT_P
 #define LOB_NT_P false
 #endif
+// Diagnostic builds only (tools/h256_ablate.sh; results are garbage): bit 0 = the per-step W_hh stream is not issued
+// (the MFMAs run on whatever the ring registers hold), bit 1 = the cell update's transcendentals are skipped.
+#ifndef LOB_ABL_H256
+#define LOB_ABL_H256 0
+#endif
 
 namespace {
 
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h256_bf16_kernel(
                 continue;
             }
             const int p = q - NQL, pn = (p + 3) % NSQ;  // three streamed groups ahead, cyclic over the steps
-            load_w(NQL + pn, wb[rb(pn)]);
+            if constexpr (!(LOB_ABL_H256 & 1)) load_w(NQL + pn, wb[rb(pn)]);
             __builtin_amdgcn_sched_barrier(0);          // pin the order: issue the prefetch, then consume group q
             const bf16x8 a = *reinterpret_cast<const bf16x8*>(hrow + 16 * q);
 #pragma unroll
@@ -159,12 +164,18 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h256_bf16_kernel(
         float* yrow = Y + ((size_t)t * Bp + bt * 32) * DH + d * HH + 32 * w;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+#if LOB_ABL_H256 & 2
+            const float ig = acc[0][r] * 0.25f, fg = acc[1][r] * 0.25f, gg = acc[2][r] * 0.25f, og = acc[3][r] * 0.25f;
+            c[r] = __builtin_fmaf(fg, c[r], ig * gg);
+            const float h = og * c[r];
+#else
             const float ig = fast_sigmoid(acc[0][r]);
             const float fg = fast_sigmoid(acc[1][r]);
             const float gg = fast_tanh(acc[2][r]);
             const float og = fast_sigmoid(acc[3][r]);
             c[r] = __builtin_fmaf(fg, c[r], ig * gg);
             const float h = og * fast_tanh(c[r]);
+#endif
             const int row = (r & 3) + 8 * (r >> 2);
             hnext[row * HB_LD] = (__bf16)h;
             if (YF32) (yrow + (size_t)row * DH)[y_off] = h;
@@ -342,7 +353,7 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_bwd_h256_bf16_kernel(
             const float ig = (float)graw.v[0 + g8][e8], fg = (float)graw.v[2 + g8][e8];
             const float gg = (float)graw.v[4 + g8][e8], og = (float)graw.v[6 + g8][e8];
             const float dh = dy[r] + dhrec[r];
-            const float tc = fast_tanh(cval(ct, r));
+            const float tc = (LOB_ABL_H256 & 2) ? cval(ct, r) * 0.5f : fast_tanh(cval(ct, r));
             const float dc = dcarry[r] + dh * og * (1.f - tc * tc);
             dcarry[r] = dc * fg;
             __bf16* p = dgw + ((r & 3) + 8 * (r >> 2)) * DGB_LD;
@@ -368,7 +379,7 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_bwd_h256_bf16_kernel(
                 continue;
             }
             const int p = q - NGL, pn = (p + NAH) % NSG;     // NAH streamed groups ahead, cyclic over the steps
-            load_w(NGL + pn, wb[pn % NRB]);
+            if constexpr (!(LOB_ABL_H256 & 1)) load_w(NGL + pn, wb[pn % NRB]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
