@@ -169,6 +169,17 @@ def solve_odeint(initial_state, t_span, n_points, p):
     return t, _post(sol)
 
 
+def solve_ivp_rk45(initial_state, t_span, n_points, p):
+    """The reference's other branch: scipy solve_ivp, RK45, default tolerances, t_eval = the output grid
+    (05_ode_model.py:157-163), then the same clip + renormalise."""
+    from scipy.integrate import solve_ivp
+    t = np.linspace(t_span[0], t_span[1], n_points)
+    y0 = np.array(initial_state, dtype=np.float64)
+    y0 = y0 / y0.sum()
+    sol = solve_ivp(lambda tt, y: ode_rhs(y, tt, p), t_span, y0, t_eval=t, method="RK45")
+    return t, _post(sol.y.T)
+
+
 def solve_expm(initial_state, t_span, n_points, p):
     """Closed form y(t) = expm(Q^T t) y0 (the clamp is inactive inside the simplex)."""
     from scipy.linalg import expm

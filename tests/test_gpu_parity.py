@@ -226,6 +226,13 @@ def test_ode_class_solve(dev):
     ss = CognitiveStateODE().get_steady_state()
     q = CognitiveStateODE().get_transition_matrix()
     assert np.abs(q.T @ np.array([ss["Active"], ss["Passive"], ss["Fatigued"]])).max() < 1e-8
+    # the reference's RK45 branch (05:157-163): same kernel, inside that solver's own tolerance (rtol 1e-3) of scipy's output
+    from oracle import restatement as R45
+    for y0_, span, n in (([0.5, 0.3, 0.2], (0, 7.5), 33), ([0.9, 0.05, 0.05], (0, 30), 100), ([1, 1, 2], (0, 2), 5)):
+        t5, s5 = ode.solve(y0_, span, n, method="solve_ivp")
+        tr, sr = R45.solve_ivp_rk45(y0_, span, n, syn.FITTED_RATES)
+        assert np.array_equal(t5, tr) and np.abs(s5 - sr).max() < 2e-3
+        assert np.array_equal(s5, ode.solve(y0_, span, n)[1])
     # n_points = 1 and ragged batch sizes
     t1, s1 = ode.solve([1, 1, 2], (0, 5), 1)
     assert np.allclose(s1, [[0.25, 0.25, 0.5]])

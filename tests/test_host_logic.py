@@ -227,10 +227,10 @@ def test_batch_size_is_a_lower_bound_by_default_and_an_upper_bound_on_request():
         integ._chunk(0, False)
 
 
-def test_solve_rejects_the_rk45_branch_instead_of_ignoring_it():
-    """05:137-163 `method='solve_ivp'` is not provided: raising beats silently returning another accuracy."""
+def test_solve_rejects_unknown_methods():
+    """05:137-163 knows 'odeint' and 'solve_ivp' (both served by the RK4 kernel); anything else raises before any GPU call."""
     with pytest.raises(ValueError, match="solve_ivp"):
-        CognitiveStateODE().solve([0.6, 0.2, 0.2], (0, 20), 20, method="solve_ivp")
+        CognitiveStateODE().solve([0.6, 0.2, 0.2], (0, 20), 20, method="lsoda")
 
 
 class _FakeDev:
