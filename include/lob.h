@@ -293,6 +293,17 @@ int lob_layernorm_act_f32(const float* in, const float* gamma, const float* beta
                           int remap_T, int remap_B, int remap_Bp,
                           float drop_p, uint64_t seed, void* stream);
 
+/* Fused input projection of the mixed path, H == 128 (input_proj = Linear(C -> H) -> LayerNorm -> GELU -> Dropout,
+ * 04_lstm_model.py:173-178), C <= 64: reads the fp32 windows x[B*T][C] (rows (b,t), 16-byte aligned base) once and writes
+ * the bf16 activations out[T*Bp][H] time-major (row t*Bp + b; pad rows b >= B untouched) -- the same numbers, bit for
+ * bit, as lob_pad_cast_bf16 + lob_gemm_nt_bf16(bias) + lob_layernorm_act_f32(remap, dropout) in a row.  W: fp32 [H][ldw]
+ * (nn.Linear weight), rounded to bf16 like the windows.  Training passes pre (fp32 [B*T][H], the LayerNorm's input, rows
+ * (b,t)) AND xb (bf16 [B*T][Cp], the padded windows: operand of the weight-gradient GEMM; Cp = C rounded up to 8); inference
+ * passes NULL for both.  act / drop_p / seed as lob_layernorm_act_f32 (LOB_LN_IDENTITY accepted).                     */
+int lob_input_proj_ln_bf16(const float* x, int C, const float* W, int ldw, const float* bias,
+                           const float* gamma, const float* beta, float* pre, void* xb, int Cp, void* out,
+                           int B, int T, int Bp, int H, float eps, int act, float drop_p, uint64_t seed, void* stream);
+
 /* nn.Dropout (04_lstm_model.py:177,186,199,202): out[i] = in[i] * keep_i / (1-p), where
  * keep_i is a counter-based hash of (seed, i): the backward pass applies the same call to the
  * gradient with the same seed instead of storing a mask.  in == out is allowed.           */

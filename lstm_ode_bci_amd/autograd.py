@@ -69,18 +69,23 @@ def _forward_impl(x, ps, cfg, save):
     # and, in the backward, its weight gradient -- nn.Linear under autocast (04:174, 04:487); the fp32 kernels walk the
     # unaligned 244-B rows at a third of the rate
     xb = None
-    if mixed and C % 8 != 0 and H % 8 == 0:
-        Cp = (C + 7) // 8 * 8
-        xb = ops.pad_cast_bf16(x2d, Cp)
-        wpad = img.get("wpad")
-        if wpad is None:
-            wpad = torch.zeros((proj_w.shape[0], Cp), device=x.device, dtype=torch.float32)
-            wpad[:, :C] = proj_w
-        pre = ops.gemm_nt(xb, wpad, proj_b, mixed=True)                      # (B*T, H), rows (b,t)
+    if mixed and frag and C % 8 != 0 and ops.input_proj_ok(x2d, H, C) and proj_w.stride(1) == 1:
+        # one launch from the fp32 windows to the first layer's bf16 activations (same bits as the sequence below)
+        a, pre, xb = ops.input_proj_ln(x2d, proj_w, proj_b, ln0_g, ln0_b, B, T, Bp, H, act=ACT_GELU, drop_p=p_in,
+                                       seed=_seed(seed, 0), save=save)
     else:
-        pre = ops.gemm_nt(x2d, proj_w, proj_b)                               # (B*T, H), rows (b,t)
-    a = ops.layernorm_act(pre, ln0_g, ln0_b, act=ACT_GELU, remap=(T, B, Bp), drop_p=p_in, seed=_seed(seed, 0),
-                          out_bf16=mixed and frag)   # (T*Bp, H) time-major; bf16 when only bf16 GEMMs read it
+        if mixed and C % 8 != 0 and H % 8 == 0:
+            Cp = (C + 7) // 8 * 8
+            xb = ops.pad_cast_bf16(x2d, Cp)
+            wpad = img.get("wpad")
+            if wpad is None:
+                wpad = torch.zeros((proj_w.shape[0], Cp), device=x.device, dtype=torch.float32)
+                wpad[:, :C] = proj_w
+            pre = ops.gemm_nt(xb, wpad, proj_b, mixed=True)                      # (B*T, H), rows (b,t)
+        else:
+            pre = ops.gemm_nt(x2d, proj_w, proj_b)                               # (B*T, H), rows (b,t)
+        a = ops.layernorm_act(pre, ln0_g, ln0_b, act=ACT_GELU, remap=(T, B, Bp), drop_p=p_in, seed=_seed(seed, 0),
+                              out_bf16=mixed and frag)   # (T*Bp, H) time-major; bf16 when only bf16 GEMMs read it
     if save:
         sv["x2d"], sv["pre"], sv["a"], sv["xb"] = x2d, pre, a, xb
         sv["layers"] = []

@@ -683,6 +683,165 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_vec_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Fused input projection of the mixed path at width 128 (round 3): input_proj = Linear(C -> 128) -> LayerNorm ->
+// GELU -> Dropout (04_lstm_model.py:173-178), one pass from the fp32 windows to the bf16 time-major activations of
+// the first LSTM layer.  Unfused it was three kernels and 1.9 GB: pad + cast of the windows to bf16 (lob_pad_cast_bf16),
+// the K = 64 GEMM writing fp32 pre-activations (lob_gemm_nt_bf16), the LayerNorm kernel reading them back.
+// A wave owns 32 consecutive (b, t) rows: their C floats each are one contiguous run (16-byte aligned: 128 C bytes per
+// tile), copied flat into the wave's LDS block (next tile's copy requested first), picked up as MFMA A fragments
+// (bf16(x), zero beyond C), multiplied with the whole weight matrix kept in registers as B fragments (16 x
+// v_mfma_f32_32x32x16_bf16: the SAME instruction and k order as the unfused GEMM, so the pre-activations are
+// bit-identical), + bias back into the LDS block row-major, and from there the LayerNorm walks them with the unfused
+// kernel's lane assignment (16 lanes x 8 columns per row, same reductions, same dropout hash): the activations are
+// bit-identical too.  SAVE (training): the bf16 padded windows (the dW GEMM's operand) and the fp32 pre-activations
+// (the LayerNorm backward's input) are written on the way; inference writes neither.
+// ------------------------------------------------------------------------------------------
+typedef __bf16 ip_bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int IP_LD = 132;             // fp32 row stride of a wave's output tile in LDS (528 B)
+
+template <bool SAVE>
+__global__ __launch_bounds__(256, 2) void input_proj_ln_kernel(
+    const float* __restrict__ x, int C, int Cp, const float* __restrict__ W, int ldw, const float* __restrict__ bias,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ pre, __bf16* __restrict__ xb,
+    __bf16* __restrict__ out, long rows, int T, int Bp, float eps, int act, float drop_p, uint64_t seed) {
+    constexpr int width = 128;
+    __shared__ __attribute__((aligned(16))) float tile[4][32 * IP_LD];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    float* tw = tile[wib];
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int sub = lane >> 4, sl = lane & 15;
+    // B fragments: W[32 cb + l31][16 ks + 8 hi + j], zero beyond C
+    ip_bf16x8 wf[4][4];
+    float bv[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        const float* wrow = W + (size_t)(32 * cb + l31) * ldw;
+        bv[cb] = bias ? bias[32 * cb + l31] : 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 16 * ks + 8 * hi + j;
+                wf[cb][ks][j] = (__bf16)(k < C ? wrow[k] : 0.f);
+            }
+    }
+    float gm[8], bt[8];
+    const bool norm = !(act & LOB_LN_IDENTITY);
+    act &= 0xff;
+    if (norm) { ldv<8>(gamma + sl * 8, gm); ldv<8>(beta + sl * 8, bt); }
+    else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { gm[i] = 1.f; bt[i] = 0.f; }
+    }
+    const float invw = 1.0f / (float)width;
+    const long ntile = (rows + 31) >> 5;
+    const long total = rows * (long)C;                 // floats in x
+    const int nch = 8 * C;                             // 16-byte chunks of a full tile (32 rows x C floats)
+    const long gw = (long)blockIdx.x * 4 + wib, nw = (long)gridDim.x * 4;
+
+    f32x4 pf[8];                                       // the next tile's chunks: lane + 64 i
+    auto fetch = [&](long tl) {
+        const long f0 = tl * 32 * C;                   // first float of the tile
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int ch = lane + 64 * i;
+            const long f = f0 + 4L * ch;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ch < nch) {
+                if (f + 4 <= total) v = *reinterpret_cast<const f32x4*>(x + f);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (f + e < total) v[e] = x[f + e];
+                }
+            }
+            pf[i] = v;
+        }
+    };
+    long tl = gw;
+    if (tl < ntile) fetch(tl);
+    for (; tl < ntile; tl += nw) {
+        const long r0 = tl * 32;
+        // the tile's floats, flat, into the wave's LDS block
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch < nch) *reinterpret_cast<f32x4*>(tw + 4 * ch) = pf[i];
+        }
+        if (tl + nw < ntile) fetch(tl + nw);
+        // A fragments: x[r0 + l31][16 ks + 8 hi + j] as bf16, zero beyond C
+        f32x16 acc[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+        ip_bf16x8 af[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 16 * ks + 8 * hi + j;
+                af[ks][j] = (__bf16)(k < C ? tw[l31 * C + k] : 0.f);
+            }
+        if (SAVE && r0 + l31 < rows) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                if (16 * ks + 8 * hi < Cp)
+                    *reinterpret_cast<ip_bf16x8*>(xb + (size_t)(r0 + l31) * Cp + 16 * ks + 8 * hi) = af[ks];
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], wf[cb][ks], acc[cb], 0, 0, 0);
+        // + bias, row-major into the same LDS block (this wave's reads of it are done: LDS operations of a wave are in order)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                tw[((r & 3) + 8 * (r >> 2) + 4 * hi) * IP_LD + 32 * cb + l31] = acc[cb][r] + bv[cb];
+        // LayerNorm + activation + dropout, four rows per pass on 16 lanes each (layernorm_act_vec_kernel<8, true, 16>)
+#pragma unroll 2
+        for (int ps = 0; ps < 8; ++ps) {
+            const int rt = 4 * ps + sub;
+            const long r = r0 + rt;
+            if (r >= rows) continue;
+            float v[8];
+            {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(tw + rt * IP_LD + 8 * sl);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(tw + rt * IP_LD + 8 * sl + 4);
+                v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+                if (SAVE) {
+                    *reinterpret_cast<f32x4*>(pre + (size_t)r * width + 8 * sl) = a;
+                    *reinterpret_cast<f32x4*>(pre + (size_t)r * width + 8 * sl + 4) = b;
+                }
+            }
+            const long bw = r / T;
+            const int orow = (int)(r - bw * T) * Bp + (int)bw;
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += v[i];
+            const float mean = norm ? row_sum<16>(s) * invw : 0.f;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float dl = v[i] - mean; q += dl * dl; }
+            const float rstd = norm ? rsqrtf(row_sum<16>(q) * invw + eps) : 1.f;
+            float ds[8];
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) {
+                if (drop_p > 0.f) lob_dropout_scale2(seed, (uint64_t)orow * width + sl * 8 + i, drop_p, ds[i], ds[i + 1]);
+                else { ds[i] = 1.f; ds[i + 1] = 1.f; }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float o = (v[i] - mean) * rstd * gm[i] + bt[i];
+                v[i] = apply_act(o, act) * ds[i];
+            }
+            stv_bf16<8>(out + (size_t)orow * width + sl * 8, v);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int lob_dropout_f32(const float* in, float* out, int64_t n, float p, uint64_t seed, void* stream) {
@@ -698,6 +857,33 @@ extern "C" int lob_dropout_f32(const float* in, float* out, int64_t n, float p, 
 static bool ln_lpr16() {
     const bool v = lob_variant(LOB_VAR_LN_LPR) != 64;
     return v;
+}
+
+extern "C" int lob_input_proj_ln_bf16(const float* x, int C, const float* W, int ldw, const float* bias,
+                                      const float* gamma, const float* beta, float* pre, void* xb, int Cp, void* out,
+                                      int B, int T, int Bp, int H, float eps, int act, float drop_p, uint64_t seed,
+                                      void* stream) {
+    if (!x || !W || !out || B <= 0 || T <= 0 || Bp < B || C <= 0 || ldw < C) return LOB_E_ARG;
+    if (!(act & LOB_LN_IDENTITY) && (!gamma || !beta)) return LOB_E_ARG;
+    if ((pre == nullptr) != (xb == nullptr)) return LOB_E_ARG;
+    if (H != 128 || C > 64 || (xb && (Cp < C || Cp > 64 || (Cp & 7)))) return LOB_E_SHAPE;
+    if (drop_p < 0.f || drop_p >= 1.f) return LOB_E_ARG;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(pre) | reinterpret_cast<uintptr_t>(xb) |
+         reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15)
+        return LOB_E_ALIGN;
+    const long rows = (long)B * T;
+    const long ntile = (rows + 31) / 32;
+    const int nb = (int)((ntile + 3) / 4 < 512 ? (ntile + 3) / 4 : 512);      // 2 workgroups per CU, persistent waves
+    if (pre)
+        hipLaunchKernelGGL((input_proj_ln_kernel<true>), dim3(nb), dim3(256), 0, (hipStream_t)stream, x, C, Cp, W, ldw, bias,
+                           gamma, beta, pre, reinterpret_cast<__bf16*>(xb), reinterpret_cast<__bf16*>(out), rows, T, Bp, eps,
+                           act, drop_p, seed);
+    else
+        hipLaunchKernelGGL((input_proj_ln_kernel<false>), dim3(nb), dim3(256), 0, (hipStream_t)stream, x, C, Cp, W, ldw, bias,
+                           gamma, beta, pre, reinterpret_cast<__bf16*>(xb), reinterpret_cast<__bf16*>(out), rows, T, Bp, eps,
+                           act, drop_p, seed);
+    LOB_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int lob_layernorm_act_f32(const float* in, const float* gamma, const float* beta,

@@ -367,6 +367,36 @@ def layernorm_act(x, gamma, beta, act=ACT_NONE, eps=1e-5, remap=None, drop_p=0.0
     return out
 
 
+#: mixed path, H == 128, C <= 64: Linear -> LayerNorm -> GELU -> Dropout of input_proj in ONE kernel (bit-identical to the
+#: three-kernel sequence it replaces; tests switch it off to compare)
+FUSE_INPUT_PROJ = True
+
+
+def input_proj_ok(x2d, H, C):
+    return bool(FUSE_INPUT_PROJ) and H == 128 and 0 < C <= 64 and x2d.is_contiguous() and x2d.data_ptr() % 16 == 0
+
+
+def input_proj_ln(x2d, w, b, gamma, beta, B, T, Bp, H, act=ACT_NONE, eps=1e-5, drop_p=0.0, seed=0, save=False):
+    """input_proj (04_lstm_model.py:173-178) of the mixed path in one launch: x2d fp32 [B*T, C] rows (b,t) -> bf16
+    activations [T*Bp, H] time-major.  save: also returns the fp32 pre-activations [B*T, H] and the bf16 padded windows
+    [B*T, Cp] that the backward reads.  Returns (a, pre | None, xb | None)."""
+    _chk(x2d, "x"); _chk(w, "w"); _chk(b, "b"); _chk(gamma, "gamma"); _chk(beta, "beta")
+    rows, Cc = x2d.shape
+    assert rows == B * T and w.shape == (H, Cc)
+    if gamma is None:
+        act = act | LN_IDENTITY
+    dev = x2d.device
+    a = (torch.zeros if Bp != B else torch.empty)((T * Bp, H), device=dev, dtype=torch.bfloat16)
+    Cp = (Cc + 7) // 8 * 8
+    pre = torch.empty((rows, H), device=dev, dtype=torch.float32) if save else None
+    xb = torch.empty((rows, Cp), device=dev, dtype=torch.bfloat16) if save else None
+    rc = _lib.lib().lob_input_proj_ln_bf16(_ptr(x2d), Cc, _ptr(w), w.stride(0), _ptr(b), _ptr(gamma), _ptr(beta), _ptr(pre),
+                                           _ptr(xb), Cp, _ptr(a), B, T, Bp, H, eps, act, float(drop_p), C.c_uint64(seed),
+                                           _stream())
+    _lib.check(rc, "lob_input_proj_ln_bf16")
+    return a, pre, xb
+
+
 def dropout(x, p, seed, out=None):
     _chk(x, "x")
     if out is None:

@@ -1,0 +1,99 @@
+"""The fused input projection of the mixed path (lob_input_proj_ln_bf16: Linear -> LayerNorm -> GELU -> Dropout of
+04_lstm_model.py:173-178 in one launch) against the three-kernel sequence it replaces (pad + cast, K = 64 GEMM,
+LayerNorm): same matrix instruction, same k order, same lane assignment in the LayerNorm, same dropout hash -- the
+activations, the saved pre-activations and the saved bf16 windows must be BIT-IDENTICAL, on ragged shapes too (B * T not a
+multiple of the 32-row tile, padded batch rows, C = 14 / 61 / 64-8), and so must the model's outputs and gradients."""
+import numpy as np
+import pytest
+import torch
+
+from lstm_ode_bci_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def _unfused(ops, x2d, w, b, g, be, B, T, Bp, act, p, seed):
+    C = x2d.shape[1]
+    Cp = (C + 7) // 8 * 8
+    xb = ops.pad_cast_bf16(x2d, Cp)
+    wpad = torch.zeros((w.shape[0], Cp), device=x2d.device)
+    wpad[:, :C] = w
+    pre = ops.gemm_nt(xb, wpad, b, mixed=True)
+    a = ops.layernorm_act(pre, g, be, act=act, remap=(T, B, Bp), drop_p=p, seed=seed, out_bf16=True)
+    return a, pre, xb
+
+
+@pytest.mark.parametrize("B,T,C", [(1, 1, 61), (3, 7, 61), (5, 256, 61), (40, 33, 14), (64, 64, 61), (9, 100, 56 - 3),
+                                   (130, 31, 61)])
+@pytest.mark.parametrize("p", [0.0, 0.3])
+@pytest.mark.parametrize("identity", [False, True])
+def test_fused_input_projection_is_bit_identical_to_the_sequence(dev, B, T, C, p, identity):
+    from lstm_ode_bci_amd import ops
+    H = 128
+    g = torch.Generator(device=dev).manual_seed(B * 1000 + T)
+    x2d = torch.randn((B * T, C), generator=g, device=dev) * 3.0
+    w = torch.randn((H, C), generator=g, device=dev) * 0.2
+    b = torch.randn((H,), generator=g, device=dev) * 0.1
+    gam = None if identity else torch.rand((H,), generator=g, device=dev) + 0.5
+    bet = None if identity else torch.randn((H,), generator=g, device=dev) * 0.1
+    Bp = ops.ceil32(B)
+    assert ops.input_proj_ok(x2d, H, C)
+    a, pre, xb = ops.input_proj_ln(x2d, w, b, gam, bet, B, T, Bp, H, act=ops.ACT_GELU, drop_p=p, seed=1234, save=True)
+    ar, prer, xbr = _unfused(ops, x2d, w, b, gam, bet, B, T, Bp, ops.ACT_GELU, p, 1234)
+    assert torch.equal(xb, xbr)
+    assert torch.equal(pre, prer)
+    assert torch.equal(a.view(torch.int16), ar.view(torch.int16))
+    a2, pre2, xb2 = ops.input_proj_ln(x2d, w, b, gam, bet, B, T, Bp, H, act=ops.ACT_GELU, drop_p=p, seed=1234, save=False)
+    assert pre2 is None and xb2 is None and torch.equal(a2.view(torch.int16), a.view(torch.int16))
+    # against float64 from the same bf16-rounded operands (not twin against twin)
+    pre64 = x2d.to(torch.bfloat16).double() @ w.to(torch.bfloat16).double().t() + b.double()
+    assert (pre.double() - pre64).abs().max().item() < 1e-4 * max(1.0, pre64.abs().max().item())
+
+
+def test_model_outputs_and_gradients_do_not_change_with_the_fused_head(dev):
+    from lstm_ode_bci_amd import EnhancedLSTMModel, ops
+    sd = {k: torch.from_numpy(v) for k, v in syn.make_state_dict(61, 128, 3, 2, True).items()}
+    x, y = syn.make_windows(24, 64, 61, seed=4)
+    xt = torch.from_numpy(x).to(dev)
+
+    def run(fused, train):
+        m = EnhancedLSTMModel(61, 128, 3, 2, 0.4, True).to(dev)
+        m.load_state_dict(sd)
+        m.train(train)
+        old = ops.FUSE_INPUT_PROJ
+        ops.FUSE_INPUT_PROJ = fused
+        try:
+            torch.manual_seed(3)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                if not train:
+                    with torch.no_grad():
+                        return m(xt), None
+                out = m(xt)
+                out.float().square().sum().backward()
+            return out.detach(), [p.grad.clone() for p in m.parameters()]
+        finally:
+            ops.FUSE_INPUT_PROJ = old
+
+    for train in (False, True):
+        o1, g1 = run(True, train)
+        o0, g0 = run(False, train)
+        assert torch.equal(o1, o0)
+        if train:       # the weight-gradient GEMMs sum their split-k partials with fp32 atomics: order-dependent last bits
+            for a, b in zip(g1, g0):
+                assert (a - b).abs().max().item() <= 2e-5 * max(1e-6, b.abs().max().item())
+
+
+def test_fused_head_refuses_what_it_does_not_cover(dev):
+    from lstm_ode_bci_amd import _lib, ops
+    x2d = torch.zeros((64, 80), device=dev)
+    assert not ops.input_proj_ok(x2d, 128, 80) and not ops.input_proj_ok(x2d[:, :61], 128, 61)     # C > 64; strided rows
+    assert not ops.input_proj_ok(torch.zeros((64, 61), device=dev), 256, 61)
+    L = _lib.lib()
+    assert L.lob_input_proj_ln_bf16(None, 61, None, 61, None, None, None, None, None, 64, None, 1, 1, 32, 128, 1e-5, 0, 0.0,
+                                    0, None) == -1
