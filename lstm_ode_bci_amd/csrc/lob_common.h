@@ -39,8 +39,25 @@ __device__ __forceinline__ float fast_tanh(float x) {
     // 1 - 2/(1+e^{2x}): saturates cleanly to +-1, no inf/inf.
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x));
 }
+// erf for the GELUs (04_lstm_model.py:176, 198, 201: nn.GELU() = the erf form).  The device library's erff is ~100
+// instructions with two data-dependent branches, and the input projection applies it to 134 M elements per step (the
+// LayerNorm kernels around it were VALU-bound on it).  Abramowitz & Stegun 7.1.26, branch-free: 1 - (a1 t + ... + a5 t^5)
+// e^{-z^2}, t = 1 / (1 + p |z|): |error| <= 1.5e-7 absolute (+ ~1e-7 from v_exp / v_rcp), i.e. <= 4e-7 |x| on a GELU
+// output -- fp32 rounding of values of order one; saturates exactly to +-1.  e2 (optional) returns e^{-z^2}, which
+// the GELU derivative needs as well.
+__device__ __forceinline__ float erf_as(float z, float* e2 = nullptr) {
+    const float az = fabsf(z);
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, az, 1.0f));
+    float p = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
+    p = __builtin_fmaf(p, t, 1.421413741f);
+    p = __builtin_fmaf(p, t, -0.284496736f);
+    p = __builtin_fmaf(p, t, 0.254829592f);
+    const float e = __expf(-az * az);
+    if (e2) *e2 = e;
+    return copysignf(1.0f - p * t * e, z);
+}
 __device__ __forceinline__ float gelu_erf(float x) {
-    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f));
 }
 __device__ __forceinline__ float apply_act(float x, int act) {
     if (act == LOB_ACT_TANH) return tanhf(x);

@@ -117,7 +117,9 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
 
 __device__ __forceinline__ float gelu_grad(float x) {
     // d/dx [0.5 x (1 + erf(x/sqrt2))] = 0.5 (1 + erf(x/sqrt2)) + x exp(-x^2/2) / sqrt(2 pi)
-    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * expf(-0.5f * x * x) * 0.39894228040143267794f;
+    float e;                   // e^{-x^2/2}: shared between the erf and the density term
+    const float er = erf_as(x * 0.70710678118654752440f, &e);
+    return 0.5f * (1.0f + er) + x * e * 0.39894228040143267794f;
 }
 
 __global__ __launch_bounds__(256) void act_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n, int act) {
