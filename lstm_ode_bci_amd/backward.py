@@ -243,8 +243,14 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad, sink=None):
     db_fused = need_w and ops.can_fuse_colsum(sv["pre"].shape[1])
     db0 = tgt.param(1, (sv["pre"].shape[1],)) if db_fused else None
     dg_t, db_t = affine(2)
+    # mixed path: dpre feeds only the bf16 TN GEMM below (which rounds it to bf16 on its way into the MFMA) and the column
+    # sums taken inside the LayerNorm backward from the fp32 values -> store it as bf16: the same operand bits, half the
+    # bytes written and read (an input gradient, if asked for, keeps the fp32 rows)
+    dpre16 = bool(ops.DPRE_BF16 and sv.get("xb") is not None and need_w and db_fused and not needs_input_grad[0]
+                  and dY.dtype == torch.bfloat16 and sv["pre"].shape[1] in (128, 256))
     dpre, g[2], g[3] = ops.layernorm_act_bwd(sv["pre"], ps[2], ps[3], dY, act=ACT_GELU, remap=(T, B, Bp),
-                                             drop_p=p_in, seed=_seed(seed, 0), dx_colsum=db0, dg=dg_t, db=db_t)
+                                             drop_p=p_in, seed=_seed(seed, 0), dx_colsum=db0, dg=dg_t, db=db_t,
+                                             dx_bf16=dpre16)
     if sv.get("xb") is not None and need_w:      # mixed: dW through the bf16 TN kernel on the padded bf16 windows
         xb = sv["xb"]
         dwp = zeros((ps[0].shape[0], xb.shape[1]))

@@ -557,6 +557,10 @@ def layernorm_act_bwd(x, gamma, beta, dy, act=ACT_NONE, eps=1e-5, remap=None, dr
     return dx, dg, db
 
 
+#: mixed path: the input projection's LayerNorm backward hands dpre to the weight-gradient GEMM as bf16 (that GEMM rounds it
+#: to bf16 anyway; the bias gradient is summed from the fp32 values inside the LayerNorm backward)
+DPRE_BF16 = True
+
 #: mixed path: the last LSTM layer hands its output to the LayerNorm as bf16 only (no fp32 copy of Y is written or read).
 LN_X_BF16 = True
 

@@ -89,6 +89,34 @@ def test_model_outputs_and_gradients_do_not_change_with_the_fused_head(dev):
                 assert (a - b).abs().max().item() <= 2e-5 * max(1e-6, b.abs().max().item())
 
 
+def test_bf16_dpre_gives_the_same_input_projection_gradients(dev):
+    """ops.DPRE_BF16: the input projection's LayerNorm backward stores dpre as bf16 for the weight-gradient GEMM, which
+    rounds its fp32 operand to bf16 itself -- same operand bits, so the gradients agree to the last bits the GEMM's fp32
+    atomics leave open; the bias gradient comes from the fp32 values either way."""
+    from lstm_ode_bci_amd import EnhancedLSTMModel, ops
+    sd = {k: torch.from_numpy(v) for k, v in syn.make_state_dict(61, 128, 3, 2, True).items()}
+    x, _ = syn.make_windows(40, 96, 61, seed=6)
+    xt = torch.from_numpy(x).to(dev)
+    grads = {}
+    for flag in (True, False):
+        m = EnhancedLSTMModel(61, 128, 3, 2, 0.4, True).to(dev)
+        m.load_state_dict(sd)
+        m.train()
+        old = ops.DPRE_BF16
+        ops.DPRE_BF16 = flag
+        try:
+            torch.manual_seed(11)                    # same dropout masks in both runs
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                m(xt).float().square().sum().backward()
+        finally:
+            ops.DPRE_BF16 = old
+        grads[flag] = {n: p.grad.clone() for n, p in m.named_parameters()}
+    for n in grads[True]:
+        a, b = grads[True][n], grads[False][n]
+        assert (a - b).abs().max().item() <= 2e-5 * max(1e-6, b.abs().max().item()), n
+    assert grads[True]["input_proj.0.weight"].abs().max().item() > 0
+
+
 def test_fused_head_refuses_what_it_does_not_cover(dev):
     from lstm_ode_bci_amd import _lib, ops
     x2d = torch.zeros((64, 80), device=dev)
