@@ -309,12 +309,23 @@ int lob_input_proj_ln_bf16(const float* x, int C, const float* W, int ldw, const
  * gradient with the same seed instead of storing a mask.  in == out is allowed.           */
 int lob_dropout_f32(const float* in, float* out, int64_t n, float p, uint64_t seed, void* stream);
 
+/* Fused tail of the mixed forward, H == 128 bidirectional (round 3): post-LSTM LayerNorm (04_lstm_model.py:192) and the
+ * attention's score layer (04:123-125) in one pass over the last LSTM layer's bf16 output Y16 [T*Bp][256] (time-major):
+ *   v = LN(Y16) (bf16, written to V [T*Bp][256]);  u = tanh(W1 v + b1);  S[b][t] = w2 . u + b2   (rows b < B)
+ * W1_16: bf16 [128][256] (attention.attention.0.weight); U: fp32 [T*Bp][128] for the backward, or NULL (inference).
+ * v, u and the scores are bit-identical to lob_layernorm_act_f32 + lob_gemm_nt_bf16(tanh) + the score sums of
+ * lob_attn_pool_fwd_f32.  The scores go to lob_attn_pool_fwd_f32 as U with W2 == 0.                                */
+int lob_attn_scores_bf16(const void* Y16, const float* gamma, const float* beta, const void* W1_16, const float* b1,
+                         const float* w2, const float* b2, void* V, float* U, float* S, int T, int B, int Bp, int H, int D,
+                         float eps, void* stream);
+
 /* Additive attention pooling over time (Attention.forward, 04_lstm_model.py:123-128):
  *   s[t,b] = U[t*Bp+b,:] . w2 + b2   (U = tanh(W1 v + b1), computed by lob_gemm_nt_f32)
  *   a[b,:] = softmax_t(s[:,b]);   ctx[b,:] = sum_t a[b,t] * V[t*Bp+b,:]
  *   V [T*Bp][W], U [T*Bp][W2], attn [B][T], ctx [B][W].
  *   U == NULL: all scores equal, a = 1/T -- mean pooling over time, the no-attention ablation
- *   (torch.mean(lstm_out, dim=1), 09_sensitivity_analysis.py:236); w2, b2, W2 are then ignored.   */
+ *   (torch.mean(lstm_out, dim=1), 09_sensitivity_analysis.py:236); w2, b2, W2 are then ignored.
+ *   U != NULL with W2 == 0 (bf16 V, W == 256): U holds the finished scores S [B][T] of lob_attn_scores_bf16.   */
 int lob_attn_pool_fwd_f32(const void* V, int v_bf16, const float* U, const float* w2, const float* b2,
                           float* ctx, float* attn, int T, int B, int Bp, int W, int W2,
                           void* stream);

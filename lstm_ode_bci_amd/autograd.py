@@ -143,18 +143,27 @@ def _forward_impl(x, ps, cfg, save):
     a0w, a0b, a2w, a2b = next(it), next(it), next(it), next(it)
     c0w, c0b, c3w, c3b, c6w, c6b = (next(it) for _ in range(6))
     # mixed mode: the normalised sequence v only feeds bf16 MFMA GEMMs and the pooling sums -> bf16
-    v = ops.layernorm_act(inp, ln_g, ln_b, out_bf16=mixed)                   # (T*Bp, W)
-    if a0w is None:            # no-attention ablation: mean pooling over time (09:236)
-        u = None
-        ctx, attn = ops.attn_pool_fwd(v, None, None, None, T, B, Bp)
+    w1 = None
+    if a0w is not None and mixed and ln_g is not None and ops.attn_scores_ok(inp, H, D, Bp, a0w):
+        # one launch: LayerNorm + score layer of the attention (same bits as the three kernels of the branch below)
+        w1 = img.get("a0w16")
+        if w1 is None:
+            w1 = a0w.to(bf16)
+        v, u, S = ops.attn_scores(inp, ln_g, ln_b, w1, a0b, a2w.reshape(-1), a2b, T, B, Bp, H, D, save=save)
+        ctx, attn = ops.attn_pool_fwd_scores(v, S, T, B, Bp)
     else:
-        w1 = a0w
-        if v.dtype == bf16 and ops.dma_ok(v.shape[1], a0w.shape[0], v.shape[0]):
-            w1 = img.get("a0w16")
-            if w1 is None:
-                w1 = a0w.to(bf16)
-        u = ops.gemm_nt(v, w1, a0b, act=ACT_TANH, mixed=mixed)               # (T*Bp, W/2)
-        ctx, attn = ops.attn_pool_fwd(v, u, a2w.reshape(-1), a2b, T, B, Bp)
+        v = ops.layernorm_act(inp, ln_g, ln_b, out_bf16=mixed)                   # (T*Bp, W)
+        if a0w is None:            # no-attention ablation: mean pooling over time (09:236)
+            u = None
+            ctx, attn = ops.attn_pool_fwd(v, None, None, None, T, B, Bp)
+        else:
+            w1 = a0w
+            if v.dtype == bf16 and ops.dma_ok(v.shape[1], a0w.shape[0], v.shape[0]):
+                w1 = img.get("a0w16")
+                if w1 is None:
+                    w1 = a0w.to(bf16)
+            u = ops.gemm_nt(v, w1, a0b, act=ACT_TANH, mixed=mixed)               # (T*Bp, W/2)
+            ctx, attn = ops.attn_pool_fwd(v, u, a2w.reshape(-1), a2b, T, B, Bp)
     if save:       # keep the pre-activations of the two classifier GELUs for their backward
         z1p = ops.gemm_nt(ctx, c0w, c0b)
         z1 = ops.act(z1p, ACT_GELU)

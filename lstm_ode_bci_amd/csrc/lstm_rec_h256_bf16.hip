@@ -152,8 +152,8 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h256_bf16_kernel(
                     acc[g] = mfma_bf16(a, *reinterpret_cast<const bf16x8*>(wlw + (q * 4 + g) * 512), acc[g]);
                 continue;
             }
-            const int p = q - NQL, pn = (p + 3) % NSQ;  // three streamed groups ahead, cyclic over the steps
-            if constexpr (!(LOB_ABL_H256 & 1)) load_w(NQL + pn, wb[rb(pn)]);
+            const int p = q - NQL, pnx = (p + 3) % NSQ; // three streamed groups ahead, cyclic over the steps
+            if constexpr (!(LOB_ABL_H256 & 1)) load_w(NQL + pnx, wb[rb(pnx)]);
             __builtin_amdgcn_sched_barrier(0);          // pin the order: issue the prefetch, then consume group q
             const bf16x8 a = *reinterpret_cast<const bf16x8*>(hrow + 16 * q);
 #pragma unroll

@@ -345,9 +345,9 @@ __global__ __launch_bounds__(256) void layernorm_act_vec_kernel(
 #pragma unroll
             for (int i = 0; i < VPL; ++i) s += v[i];
             const float mean = norm ? row_sum<LPR>(s) * invw : 0.f;
-            float q = 0.f;
+            float q = 0.f;             // explicit fma: the fused kernels below (input_proj_ln / attn_score) must round alike
 #pragma unroll
-            for (int i = 0; i < VPL; ++i) { const float dl = v[i] - mean; q += dl * dl; }
+            for (int i = 0; i < VPL; ++i) { const float dl = v[i] - mean; q = __builtin_fmaf(dl, dl, q); }
             const float rstd = norm ? rsqrtf(row_sum<LPR>(q) * invw + eps) : 1.f;
             float ds[VPL];              // dropout scales: one hash per pair of neighbouring columns
 #pragma unroll
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void layernorm_act_vec_kernel(
             }
 #pragma unroll
             for (int i = 0; i < VPL; ++i) {
-                float o = (v[i] - mean) * rstd * gm[i] + bt[i];
+                float o = __builtin_fmaf((v[i] - mean) * rstd, gm[i], bt[i]);
                 v[i] = apply_act(o, act) * ds[i];
             }
             if (OUT_BF16) stv_bf16<VPL>(reinterpret_cast<__bf16*>(outv) + (size_t)orow * width + sl * VPL, v);
@@ -557,7 +557,8 @@ typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 
 // F: width factor -- W = 256 F columns of V, W2 = 128 F columns of U (F = 1: H = 128, F = 2: H = 256, both bidirectional):
 // a lane holds 4 F consecutive columns of V and 2 F of U
-template <int F>
+// SCORES: U holds the finished scores S[b][t] (lob_attn_scores_bf16) instead of the score layer's hidden activations
+template <int F, bool SCORES = false>
 __global__ __launch_bounds__(256) void attn_pool_fwd_vec_kernel(
     const __bf16* __restrict__ V, const float* __restrict__ U, const float* __restrict__ w2,
     const float* __restrict__ b2, float* __restrict__ ctx, float* __restrict__ attn, int T, int Bp) {
@@ -566,19 +567,23 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_vec_kernel(
     extern __shared__ __attribute__((aligned(16))) float sc[];   // [T] scores -> weights, then [4][W] partial contexts
     __shared__ float red[8];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float bias2 = b2 ? b2[0] : 0.f;
-    float wv[NU];
-    ldv<NU>(w2 + NU * lane, wv);
     const size_t rs = (size_t)Bp;
+    if constexpr (SCORES) {
+        for (int t = tid; t < T; t += 256) sc[t] = U[(size_t)b * T + t];
+    } else {
+        const float bias2 = b2 ? b2[0] : 0.f;
+        float wv[NU];
+        ldv<NU>(w2 + NU * lane, wv);
 #pragma unroll 4
-    for (int t = wave; t < T; t += 4) {
-        float u[NU];
-        ldv<NU>(U + ((size_t)t * rs + b) * W2 + NU * lane, u);
-        float s = u[0] * wv[0];
+        for (int t = wave; t < T; t += 4) {
+            float u[NU];
+            ldv<NU>(U + ((size_t)t * rs + b) * W2 + NU * lane, u);
+            float s = u[0] * wv[0];
 #pragma unroll
-        for (int i = 1; i < NU; ++i) s = fmaf(u[i], wv[i], s);
-        s = wave_sum(s);
-        if (lane == 0) sc[t] = s + bias2;
+            for (int i = 1; i < NU; ++i) s = fmaf(u[i], wv[i], s);
+            s = wave_sum(s);
+            if (lane == 0) sc[t] = s + bias2;
+        }
     }
     __syncthreads();
     float m = -INFINITY;
@@ -826,7 +831,7 @@ __global__ __launch_bounds__(256, 2) void input_proj_ln_kernel(
             const float mean = norm ? row_sum<16>(s) * invw : 0.f;
             float q = 0.f;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { const float dl = v[i] - mean; q += dl * dl; }
+            for (int i = 0; i < 8; ++i) { const float dl = v[i] - mean; q = __builtin_fmaf(dl, dl, q); }
             const float rstd = norm ? rsqrtf(row_sum<16>(q) * invw + eps) : 1.f;
             float ds[8];
 #pragma unroll
@@ -836,11 +841,123 @@ __global__ __launch_bounds__(256, 2) void input_proj_ln_kernel(
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const float o = (v[i] - mean) * rstd * gm[i] + bt[i];
+                const float o = __builtin_fmaf((v[i] - mean) * rstd, gm[i], bt[i]);
                 v[i] = apply_act(o, act) * ds[i];
             }
             stv_bf16<8>(out + (size_t)orow * width + sl * 8, v);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused tail of the mixed forward at H = 128 (round 3): post-LSTM LayerNorm (04_lstm_model.py:192) + the attention's
+// score layer u = tanh(W1 v + b1), s = w2 . u + b2 (Attention.forward, 04:123-125) in one pass over the last layer's bf16
+// output.  Unfused: LayerNorm (Y16 -> v), the K = 256 GEMM (v -> fp32 u), and the pooling kernel reading u and v again:
+// 3 KB per row; here 1.5 KB (inference: Y16 in, v out, one score per row) or 2 KB (training: + fp32 u for the backward).
+// A workgroup (4 waves) owns 128 consecutive time-major rows:
+//   1. wave w normalises rows 32 w .. + 31 with the LayerNorm kernel's lane assignment (32 lanes x 8 columns per row, two
+//      rows per pass; all 16 passes' loads issued up front), writes v to HBM and into the shared LDS tile;
+//   2. wave w owns the score layer's columns 32 w .. + 31: its 16 B fragments of W1 stay in registers for the whole
+//      launch; 4 row blocks x 16 k-steps of v_mfma_f32_32x32x16_bf16 in the unfused GEMM's k order;
+//   3. tanh(acc + b1) goes back into the same LDS block row-major (fp32), and wave w forms the scores of rows 32 w ..
+//      with the pooling kernel's lane assignment (2 columns per lane, the same wave reduction) -> S[b][t]; training also
+//      writes u.
+// Same instructions in the same order as the three kernels it replaces: v, u and the scores are bit-identical.
+// ------------------------------------------------------------------------------------------
+constexpr int AS_LDA = 264;            // bf16 row stride of the v tile (528 B)
+constexpr int AS_LDU = 132;            // fp32 row stride of the u tile (528 B): the two tiles share the LDS block
+
+template <bool SAVE>
+__global__ __launch_bounds__(256, 2) void attn_score_kernel(
+    const __bf16* __restrict__ Y, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const __bf16* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
+    __bf16* __restrict__ V, float* __restrict__ U, float* __restrict__ S, int T, int B, int Bp, float eps) {
+    constexpr int W = 256, W2 = 128;
+    __shared__ __attribute__((aligned(16))) float lds[128 * AS_LDU];
+    __bf16* at = reinterpret_cast<__bf16*>(lds);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    // B fragments of this wave's 32 score columns: W1[32 w + l31][16 ks + 8 hi + j]
+    ip_bf16x8 wf[16];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+        wf[ks] = *reinterpret_cast<const ip_bf16x8*>(W1 + (size_t)(32 * w + l31) * W + 16 * ks + 8 * hi);
+    const float b1v = b1 ? b1[32 * w + l31] : 0.f;
+    float gm[8], bt[8];
+    ldv<8>(gamma + l31 * 8, gm);
+    ldv<8>(beta + l31 * 8, bt);
+    float w2v[2];
+    ldv<2>(w2 + 2 * lane, w2v);
+    const float bias2 = b2 ? b2[0] : 0.f;
+    const long rows = (long)T * Bp;
+    const long ntile = (rows + 127) >> 7;
+    const float invw = 1.0f / (float)W;
+    for (long tl = blockIdx.x; tl < ntile; tl += gridDim.x) {
+        const long r0 = tl * 128 + 32 * w;
+        // ---- 1. LayerNorm of this wave's 32 rows (two per pass on 32 lanes each)
+        ip_bf16x8 raw[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const long r = r0 + 2 * p + hi;
+            ip_bf16x8 z;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) z[i] = (__bf16)0.f;
+            raw[p] = r < rows ? *reinterpret_cast<const ip_bf16x8*>(Y + (size_t)r * W + l31 * 8) : z;
+        }
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const long r = r0 + 2 * p + hi;
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = (float)raw[p][i];
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += v[i];
+            const float mean = row_sum<32>(s) * invw;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float dl = v[i] - mean; q = __builtin_fmaf(dl, dl, q); }
+            const float rstd = rsqrtf(row_sum<32>(q) * invw + eps);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = __builtin_fmaf((v[i] - mean) * rstd, gm[i], bt[i]);
+            __bf16* arow = at + (32 * w + 2 * p + hi) * AS_LDA + l31 * 8;
+            stv_bf16<8>(arow, v);                              // the LayerNorm kernel's own conversion
+            if (r < rows) *reinterpret_cast<ip_bf16x8*>(V + (size_t)r * W + l31 * 8) = *reinterpret_cast<const ip_bf16x8*>(arow);
+        }
+        __syncthreads();
+        // ---- 2. pre-activations of the score layer: this wave's 32 columns for all 128 rows
+        f32x16 acc[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[rb][i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                const ip_bf16x8 a = *reinterpret_cast<const ip_bf16x8*>(at + (32 * rb + l31) * AS_LDA + 16 * ks + 8 * hi);
+                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wf[ks], acc[rb], 0, 0, 0);
+            }
+        __syncthreads();                       // every wave is done with the v tile: the block now takes u (fp32)
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                lds[(32 * rb + (i & 3) + 8 * (i >> 2) + 4 * hi) * AS_LDU + 32 * w + l31] = tanhf(acc[rb][i] + b1v);
+        __syncthreads();
+        // ---- 3. scores of this wave's 32 rows (the pooling kernel's order: two columns per lane, wave reduction)
+        for (int rr = 0; rr < 32; ++rr) {
+            const long r = r0 + rr;
+            if (r >= rows) break;
+            const float u0 = lds[(32 * w + rr) * AS_LDU + 2 * lane], u1 = lds[(32 * w + rr) * AS_LDU + 2 * lane + 1];
+            if (SAVE) { float uu[2] = {u0, u1}; stv<2>(U + (size_t)r * W2 + 2 * lane, uu); }
+            float sc = u0 * w2v[0];
+            sc = fmaf(u1, w2v[1], sc);
+            sc = wave_sum(sc);
+            const int t = (int)(r / Bp), b = (int)(r - (long)t * Bp);
+            if (lane == 0 && b < B) S[(size_t)b * T + t] = sc + bias2;
+        }
+        __syncthreads();                       // the block is free for the next tile's v
     }
 }
 
@@ -859,6 +976,28 @@ extern "C" int lob_dropout_f32(const float* in, float* out, int64_t n, float p, 
 static bool ln_lpr16() {
     const bool v = lob_variant(LOB_VAR_LN_LPR) != 64;
     return v;
+}
+
+extern "C" int lob_attn_scores_bf16(const void* Y16, const float* gamma, const float* beta, const void* W1_16,
+                                    const float* b1, const float* w2, const float* b2, void* V, float* U, float* S,
+                                    int T, int B, int Bp, int H, int D, float eps, void* stream) {
+    if (!Y16 || !gamma || !beta || !W1_16 || !w2 || !V || !S || T <= 0 || B <= 0 || Bp < B) return LOB_E_ARG;
+    if (H != 128 || D != 2 || (Bp % 32)) return LOB_E_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(Y16) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta) |
+         reinterpret_cast<uintptr_t>(W1_16) | reinterpret_cast<uintptr_t>(w2) | reinterpret_cast<uintptr_t>(V) |
+         reinterpret_cast<uintptr_t>(U)) & 15) return LOB_E_ALIGN;
+    const long ntile = ((long)T * Bp + 127) / 128;
+    const int nb = (int)(ntile < 512 ? ntile : 512);
+    if (U)
+        hipLaunchKernelGGL((attn_score_kernel<true>), dim3(nb), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const __bf16*>(Y16), gamma, beta, reinterpret_cast<const __bf16*>(W1_16), b1, w2, b2,
+                           reinterpret_cast<__bf16*>(V), U, S, T, B, Bp, eps);
+    else
+        hipLaunchKernelGGL((attn_score_kernel<false>), dim3(nb), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const __bf16*>(Y16), gamma, beta, reinterpret_cast<const __bf16*>(W1_16), b1, w2, b2,
+                           reinterpret_cast<__bf16*>(V), U, S, T, B, Bp, eps);
+    LOB_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int lob_input_proj_ln_bf16(const float* x, int C, const float* W, int ldw, const float* bias,
@@ -969,8 +1108,16 @@ extern "C" int lob_attn_pool_fwd_f32(const void* V, int v_bf16, const float* U, 
                                      float* ctx, float* attn, int T, int B, int Bp, int W, int W2,
                                      void* stream) {
     if (!V || !ctx || !attn || T <= 0 || B <= 0 || Bp < B || W <= 0) return LOB_E_ARG;
-    if (U && (!w2 || W2 <= 0)) return LOB_E_ARG;
     if ((size_t)T * sizeof(float) > 60 * 1024) return LOB_E_SHAPE;
+    if (U && W2 == 0) {          // U = finished scores S[B][T] (lob_attn_scores_bf16)
+        if (!v_bf16 || W != 256 || (reinterpret_cast<uintptr_t>(V) & 7)) return LOB_E_SHAPE;
+        const size_t smem = ((size_t)((T + 3) & ~3) + 4 * W) * sizeof(float);
+        hipLaunchKernelGGL((attn_pool_fwd_vec_kernel<1, true>), dim3(B), dim3(256), smem, (hipStream_t)stream,
+                           reinterpret_cast<const __bf16*>(V), U, w2, b2, ctx, attn, T, Bp);
+        LOB_CHECK_LAUNCH();
+        return 0;
+    }
+    if (U && (!w2 || W2 <= 0)) return LOB_E_ARG;
     const bool al8 = ((reinterpret_cast<uintptr_t>(V) | reinterpret_cast<uintptr_t>(U) | reinterpret_cast<uintptr_t>(w2)) & 7) == 0;
     const bool al16v = ((reinterpret_cast<uintptr_t>(V) | reinterpret_cast<uintptr_t>(U) | reinterpret_cast<uintptr_t>(w2)) & 15) == 0;
     if (v_bf16 && U && ((W == 256 && W2 == 128 && al8) || (W == 512 && W2 == 256 && al16v))) {

@@ -419,6 +419,41 @@ def attn_pool_fwd(v, u, w2, b2, T, B, Bp):
     return ctx, attn
 
 
+#: mixed path, H == 128 bidirectional: post-LSTM LayerNorm + the attention's score layer in ONE kernel (bit-identical to the
+#: LayerNorm kernel + the K = 256 GEMM + the pooling kernel's score sums; tests switch it off to compare)
+FUSE_ATTN_SCORES = True
+
+
+def attn_scores_ok(y16, H, D, Bp, w1):
+    return (bool(FUSE_ATTN_SCORES) and H == 128 and D == 2 and Bp % 32 == 0 and y16.dtype == torch.bfloat16
+            and y16.is_contiguous() and w1 is not None and tuple(w1.shape) == (128, 256))
+
+
+def attn_scores(y16, gamma, beta, w1_16, b1, w2, b2, T, B, Bp, H, D, eps=1e-5, save=False):
+    """v = LN(y16) (bf16 [T*Bp, 256]), u = tanh(W1 v + b1) (fp32 [T*Bp, 128], only with save), scores S [B, T] fp32."""
+    _chk(y16, "y16", torch.bfloat16); _chk(gamma, "gamma"); _chk(beta, "beta"); _chk(w1_16, "w1", torch.bfloat16)
+    _chk(b1, "b1"); _chk(w2, "w2"); _chk(b2, "b2")
+    dev = y16.device
+    v = torch.empty((T * Bp, 2 * H), device=dev, dtype=torch.bfloat16)
+    u = torch.empty((T * Bp, H), device=dev, dtype=torch.float32) if save else None
+    S = torch.empty((B, T), device=dev, dtype=torch.float32)
+    rc = _lib.lib().lob_attn_scores_bf16(_ptr(y16), _ptr(gamma), _ptr(beta), _ptr(w1_16), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(v),
+                                         _ptr(u), _ptr(S), T, B, Bp, H, D, eps, _stream())
+    _lib.check(rc, "lob_attn_scores_bf16")
+    return v, u, S
+
+
+def attn_pool_fwd_scores(v, S, T, B, Bp):
+    """Softmax over time of finished scores S [B, T] and the context sums (the second half of attn_pool_fwd)."""
+    _chk(v, "v", torch.bfloat16); _chk(S, "S")
+    W = v.shape[1]
+    ctx = torch.empty((B, W), device=v.device, dtype=torch.float32)
+    attn = torch.empty((B, T), device=v.device, dtype=torch.float32)
+    rc = _lib.lib().lob_attn_pool_fwd_f32(_ptr(v), 1, _ptr(S), None, None, _ptr(ctx), _ptr(attn), T, B, Bp, W, 0, _stream())
+    _lib.check(rc, "lob_attn_pool_fwd_f32")
+    return ctx, attn
+
+
 def softmax_rows(x):
     _chk(x, "x")
     out = torch.empty_like(x)
