@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
         const float x = pre[i];
         float g = 1.f;
         if (act == LOB_ACT_GELU) g = gelu_grad(x);
-        else if (act == LOB_ACT_TANH) { const float t = tanhf(x); g = 1.f - t * t; }
+        else if (act == LOB_ACT_TANH) { const float t = fast_tanh(x); g = 1.f - t * t; }
         dx[i] = dy[i] * g;
     }
 }
@@ -943,7 +943,7 @@ __global__ __launch_bounds__(256, 2) void attn_score_kernel(
         for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
             for (int i = 0; i < 16; ++i)
-                lds[(32 * rb + (i & 3) + 8 * (i >> 2) + 4 * hi) * AS_LDU + 32 * w + l31] = tanhf(acc[rb][i] + b1v);
+                lds[(32 * rb + (i & 3) + 8 * (i >> 2) + 4 * hi) * AS_LDU + 32 * w + l31] = fast_tanh(acc[rb][i] + b1v);
         __syncthreads();
         // ---- 3. scores of this wave's 32 rows (the pooling kernel's order: two columns per lane, wave reduction)
         for (int rr = 0; rr < 32; ++rr) {
