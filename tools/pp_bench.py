@@ -93,3 +93,12 @@ if "fused" in want or not want:
         fl = 2.0 * rows * D * 4 * H * (nx + H)
         ab(f"layer dW nx={nx}: fused", lambda: ops.lstm_dw(dP, X, Y, T, Bp, H, D, out=(o1, o2)), fl, {"fused 1 launch": dict(GEMM_PP=5)})
         ab(f"layer dW nx={nx}: separate", separate, fl, {"3 launches pp": dict(GEMM_PP=5), "3 launches twin": dict(GEMM_PP=0)})
+
+if "h128" in want:      # the H = 128 step's dX shapes (K = 1024): k-split weight-stationary kernel against the ping-pong kernels
+    dP1 = rnd((rows, 1024), 1e-2, torch.bfloat16)
+    for N in (256, 128):
+        wt = rnd((N, 1024), 0.05, torch.bfloat16)
+        VH = {"k-split": dict(DX_KSPLIT=1), "pp 32x32x16": dict(DX_KSPLIT=0, GEMM_PP=7), "pp 16x16x32": dict(DX_KSPLIT=0, GEMM_PP=7 | 512),
+              "tiled": dict(DX_KSPLIT=0, GEMM_PP=0)}
+        ab(f"H=128 dX K=1024 N={N}", lambda: ops.gemm_nt(dP1, wt, mixed=True, out_bf16=True, drop_p=0.4, seed=3),
+           2.0 * rows * N * 1024, VH)
