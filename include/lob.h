@@ -309,6 +309,16 @@ int lob_input_proj_ln_bf16(const float* x, int C, const float* W, int ldw, const
  * gradient with the same seed instead of storing a mask.  in == out is allowed.           */
 int lob_dropout_f32(const float* in, float* out, int64_t n, float p, uint64_t seed, void* stream);
 
+/* Fused tail of the mixed backward, H == 128 bidirectional (round 3): dV = dU W1 (+ attn[b][t] dctx[b], the context path
+ * of the pooling) and the backward of the post-LSTM LayerNorm in one pass:
+ *   X16 [T*Bp][256] bf16: the LayerNorm's input (the last LSTM layer's output); dU16 [T*Bp][128] bf16: gradient w.r.t. the
+ *   score layer's pre-activations (lob_attn_pool_bwd_f32); W1T_16 bf16 [256][128] = attention.attention.0.weight^T;
+ *   dX16 [T*Bp][256] bf16 out; dgamma / dbeta accumulated (fp32 atomics); attn [B][T], dctx [B][256] fp32.
+ * dX16 is bit-identical to lob_gemm_nt_bf16 (bf16 dV) + lob_layernorm_act_bwd_f32(pool_attn, pool_dctx).             */
+int lob_attn_ln_bwd_bf16(const void* X16, const float* gamma, const float* beta, const void* dU16, const void* W1T_16,
+                         void* dX16, float* dgamma, float* dbeta, const float* attn, const float* dctx,
+                         int T, int B, int Bp, int H, int D, float eps, void* stream);
+
 /* Fused tail of the mixed forward, H == 128 bidirectional (round 3): post-LSTM LayerNorm (04_lstm_model.py:192) and the
  * attention's score layer (04:123-125) in one pass over the last LSTM layer's bf16 output Y16 [T*Bp][256] (time-major):
  *   v = LN(Y16) (bf16, written to V [T*Bp][256]);  u = tanh(W1 v + b1);  S[b][t] = w2 . u + b2   (rows b < B)

@@ -150,12 +150,18 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad, sink=None):
             ops.gemm_tn(dU, v, g[i_a0w], mixed=mixed)
             g[i_a0b] = du_cs if cs_fused else ops.colsum(dU, tgt.param(i_a0b, (dU.shape[1],)))
         w1t = wT.get("a0wT")
+        fused_tail = None
         if fused:
             want16 = ops.dma_ok(dU.shape[1], a0w.shape[1], dU.shape[0])
             if w1t is None or (w1t.dtype == torch.bfloat16) != want16:
                 w1t = _t(a0w).to(torch.bfloat16) if want16 else _t(a0w)
-            dV = ops.gemm_nt(dU, w1t, mixed=mixed,                       # dU W1; + a[t] dctx is added below
-                             out_bf16=carry16 and want16 and width_ok(sv["ylast"].shape[1]))
+            if (carry16 and want16 and width_ok(sv["ylast"].shape[1]) and ps[i_ln] is not None
+                    and ops.attn_ln_bwd_ok(sv["ylast"], dU, w1t, H, D, Bp, ps[i_ln])):
+                fused_tail = (dU, w1t)        # dV = dU W1 is formed inside the LayerNorm backward below
+                dV = None
+            else:
+                dV = ops.gemm_nt(dU, w1t, mixed=mixed,                   # dU W1; + a[t] dctx is added below
+                                 out_bf16=carry16 and want16 and width_ok(sv["ylast"].shape[1]))
             pool_ctx = (sv["attn"], dctx, T, B, Bp)
         else:
             if w1t is None or w1t.dtype != torch.float32:
@@ -171,10 +177,14 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad, sink=None):
     dg_t, db_t = affine(i_ln)
     ylast = sv["ylast"]
     dx16 = carry16 and width_ok(ylast.shape[1])
-    if ylast.dtype == torch.bfloat16 and not (dx16 and dV.dtype == torch.bfloat16):
-        ylast = ylast.float()        # a storage switch was flipped between forward and backward: widen, stay correct
-    dY, g[i_ln], g[i_ln + 1] = ops.layernorm_act_bwd(ylast, ps[i_ln], ps[i_ln + 1], dV, pool=pool_ctx, dg=dg_t, db=db_t,
-                                                     dx_bf16=dx16)
+    if a0w is not None and fused_tail is not None:
+        dY, g[i_ln], g[i_ln + 1] = ops.attn_ln_bwd(ylast, ps[i_ln], ps[i_ln + 1], fused_tail[0], fused_tail[1], sv["attn"], dctx,
+                                                   T, B, Bp, H, D, dg=dg_t, db=db_t)
+    else:
+        if ylast.dtype == torch.bfloat16 and not (dx16 and dV.dtype == torch.bfloat16):
+            ylast = ylast.float()        # a storage switch was flipped between forward and backward: widen, stay correct
+        dY, g[i_ln], g[i_ln + 1] = ops.layernorm_act_bwd(ylast, ps[i_ln], ps[i_ln + 1], dV, pool=pool_ctx, dg=dg_t, db=db_t,
+                                                         dx_bf16=dx16)
 
     # ---- LSTM stack, last layer first (04:211)
     for layer in reversed(range(L)):

@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void layernorm_act_vec_kernel(
             float q = 0.f;             // explicit fma: the fused kernels below (input_proj_ln / attn_score) must round alike
 #pragma unroll
             for (int i = 0; i < VPL; ++i) { const float dl = v[i] - mean; q = __builtin_fmaf(dl, dl, q); }
-            const float rstd = norm ? rsqrtf(row_sum<LPR>(q) * invw + eps) : 1.f;
+            const float rstd = norm ? rsqrtf(__builtin_fmaf(row_sum<LPR>(q), invw, eps)) : 1.f;
             float ds[VPL];              // dropout scales: one hash per pair of neighbouring columns
 #pragma unroll
             for (int i = 0; i < VPL; i += 2) {
@@ -431,10 +431,10 @@ __global__ __launch_bounds__(256) void layernorm_act_bwd_vec_kernel(
 #pragma unroll
             for (int i = 0; i < VPL; ++i) s += v[i];
             const float mean = norm ? row_sum<LPR>(s) * invw : 0.f;
-            float q = 0.f;
+            float q = 0.f;             // explicit fma throughout: attn_ln_bwd_kernel below must round alike
 #pragma unroll
-            for (int i = 0; i < VPL; ++i) { const float dl = v[i] - mean; q += dl * dl; }
-            const float rstd = norm ? rsqrtf(row_sum<LPR>(q) * invw + eps) : 1.f;
+            for (int i = 0; i < VPL; ++i) { const float dl = v[i] - mean; q = __builtin_fmaf(dl, dl, q); }
+            const float rstd = norm ? rsqrtf(__builtin_fmaf(row_sum<LPR>(q), invw, eps)) : 1.f;
             float m1 = 0.f, m2 = 0.f;
             float ds[VPL];
 #pragma unroll
@@ -447,16 +447,16 @@ __global__ __launch_bounds__(256) void layernorm_act_bwd_vec_kernel(
                 const float xh = (v[i] - mean) * rstd;
                 float g = go[i] * ds[i];
                 if (act == LOB_ACT_GELU) g *= gelu_grad(xh * gm[i] + bt[i]);
-                dga[i] += g * xh;
+                dga[i] = __builtin_fmaf(g, xh, dga[i]);
                 dba[i] += g;
                 const float dxh = g * gm[i];
                 v[i] = xh; go[i] = dxh;
-                m1 += dxh; m2 += dxh * xh;
+                m1 += dxh; m2 = __builtin_fmaf(dxh, xh, m2);
             }
             m1 = norm ? row_sum<LPR>(m1) * invw : 0.f;
             m2 = norm ? row_sum<LPR>(m2) * invw : 0.f;
 #pragma unroll
-            for (int i = 0; i < VPL; ++i) { v[i] = rstd * (go[i] - m1 - v[i] * m2); dxs[i] += v[i]; }
+            for (int i = 0; i < VPL; ++i) { v[i] = rstd * __builtin_fmaf(-v[i], m2, go[i] - m1); dxs[i] += v[i]; }
             stv_t<VPL, DXE>(dx + (size_t)row * width + sl * VPL, v);
         }
     }
@@ -832,7 +832,7 @@ __global__ __launch_bounds__(256, 2) void input_proj_ln_kernel(
             float q = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) { const float dl = v[i] - mean; q = __builtin_fmaf(dl, dl, q); }
-            const float rstd = norm ? rsqrtf(row_sum<16>(q) * invw + eps) : 1.f;
+            const float rstd = norm ? rsqrtf(__builtin_fmaf(row_sum<16>(q), invw, eps)) : 1.f;
             float ds[8];
 #pragma unroll
             for (int i = 0; i < 8; i += 2) {
@@ -917,7 +917,7 @@ __global__ __launch_bounds__(256, 2) void attn_score_kernel(
             float q = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) { const float dl = v[i] - mean; q = __builtin_fmaf(dl, dl, q); }
-            const float rstd = rsqrtf(row_sum<32>(q) * invw + eps);
+            const float rstd = rsqrtf(__builtin_fmaf(row_sum<32>(q), invw, eps));
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = __builtin_fmaf((v[i] - mean) * rstd, gm[i], bt[i]);
             __bf16* arow = at + (32 * w + 2 * p + hi) * AS_LDA + l31 * 8;
@@ -961,6 +961,155 @@ __global__ __launch_bounds__(256, 2) void attn_score_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Fused tail of the mixed BACKWARD at H = 128 (round 3): dV = dU W1 (the score layer's input gradient, 04:123) and the
+// post-LSTM LayerNorm's backward (04:192) with the attention's context term a[t] dctx folded in, in one pass.  Unfused,
+// the K = 128 GEMM wrote dV (bf16, 512 B per row) and the LayerNorm backward read it back.  A workgroup owns 128
+// time-major rows (8 waves): (0) its dU tile (128 x 128 bf16) into LDS; (1) each wave 32 of dV's 256 columns: 8 B
+// fragments of W1^T in registers for the whole launch, 4 row blocks x 8 k-steps of v_mfma_f32_32x32x16_bf16; (2) dV, rounded
+// to bf16 as the unfused GEMM stores it, row-major into the same LDS block; (3) wave w runs the LayerNorm backward of
+// rows 16 w .. + 15 with the unfused kernel's lane assignment and arithmetic (32 lanes x 8 columns, two rows per pass):
+// dx equals the unfused pair's except where a dV element rounds the other way (another k order: ~1e-5 of the elements);
+// dgamma / dbeta are summed in another order (they go through fp32 atomics either way).
+// ------------------------------------------------------------------------------------------
+constexpr int AB_LDA = 136;            // bf16 row stride of the dU tile (272 B = 17 x 16 B)
+constexpr int AB_LDV = 264;            // bf16 row stride of the dV tile (528 B)
+
+__global__ __launch_bounds__(512) void attn_ln_bwd_kernel(
+    const __bf16* __restrict__ X, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const __bf16* __restrict__ dU, const __bf16* __restrict__ W1T, __bf16* __restrict__ dX,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, const float* __restrict__ attn, const float* __restrict__ dctx,
+    int T, int B, int Bp, float eps) {
+    constexpr int W = 256, W2 = 128;
+    // EIGHT waves: wave w owns 32 of dV's columns (8 B fragments + 64 accumulator registers: two waves per SIMD fit) and
+    // the LayerNorm backward of 16 of the tile's rows
+    __shared__ __attribute__((aligned(16))) __bf16 lds[128 * AB_LDV];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    // B fragments of this wave's 32 dV columns: W1^T[32 w + l31][16 ks + 8 hi + j]
+    ip_bf16x8 wf[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+        wf[ks] = *reinterpret_cast<const ip_bf16x8*>(W1T + (size_t)(32 * w + l31) * W2 + 16 * ks + 8 * hi);
+    float gm[8], bt[8], dga[8], dba[8];
+    ldv<8>(gamma + l31 * 8, gm);
+    ldv<8>(beta + l31 * 8, bt);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { dga[i] = 0.f; dba[i] = 0.f; }
+    const long rows = (long)T * Bp;
+    const long ntile = (rows + 127) >> 7;
+    const float invw = 1.0f / (float)W;
+    for (long tl = blockIdx.x; tl < ntile; tl += gridDim.x) {
+        const long r0 = tl * 128 + 16 * w;
+        // ---- 0. this wave's 16 rows of dU (256 B each) into the tile: lane -> (row l / 16 + 4 i, 16-byte chunk l % 16)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rr = (lane >> 4) + 4 * i, ch = lane & 15;
+            const long r = r0 + rr;
+            ip_bf16x8 z;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.f;
+            if (r < rows) z = *reinterpret_cast<const ip_bf16x8*>(dU + (size_t)r * W2 + 8 * ch);
+            *reinterpret_cast<ip_bf16x8*>(lds + (16 * w + rr) * AB_LDA + 8 * ch) = z;
+        }
+        // the LayerNorm inputs of this wave's 16 rows: requested now, used after the matrix phase
+        ip_bf16x8 xr[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const long r = r0 + 2 * p + hi;
+            ip_bf16x8 z;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.f;
+            xr[p] = r < rows ? *reinterpret_cast<const ip_bf16x8*>(X + (size_t)r * W + l31 * 8) : z;
+        }
+        __syncthreads();
+        // ---- 1. dV = dU W1: this wave's 32 columns for all 128 rows
+        f32x16 acc[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[rb][i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                const ip_bf16x8 a = *reinterpret_cast<const ip_bf16x8*>(lds + (32 * rb + l31) * AB_LDA + 16 * ks + 8 * hi);
+                // operands SWAPPED like the unfused weight-stationary GEMM: D[n][r] -- this lane holds row r = l31 of the
+                // block, columns n = (i & 3) + 8 (i >> 2) + 4 hi
+                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], a, acc[rb], 0, 0, 0);
+            }
+        __syncthreads();                       // the dU tile is consumed: the block now takes dV (bf16, row-major)
+        typedef __bf16 ab_bf16x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                ab_bf16x4 pk = {(__bf16)acc[rb][4 * q4], (__bf16)acc[rb][4 * q4 + 1], (__bf16)acc[rb][4 * q4 + 2],
+                                (__bf16)acc[rb][4 * q4 + 3]};
+                *reinterpret_cast<ab_bf16x4*>(lds + (32 * rb + l31) * AB_LDV + 32 * w + 8 * q4 + 4 * hi) = pk;
+            }
+        __syncthreads();
+        // ---- 3. LayerNorm backward of rows 16 w .. + 15 (layernorm_act_bwd_vec_kernel<8, 32, bf16, bf16, bf16>)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const long r = r0 + 2 * p + hi;
+            if (r >= rows) continue;
+            float v[8], go[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = (float)xr[p][i];
+            ldv_bf16<8>(lds + (16 * w + 2 * p + hi) * AB_LDV + l31 * 8, go);
+            {      // context path of the attention pooling: dy += attn[b][t] * dctx[b][:]
+                const int t = (int)(r / Bp), b = (int)(r - (long)t * Bp);
+                if (b < B) {
+                    const float a = attn[(size_t)b * T + t];
+                    float dcv[8];
+                    ldv<8>(dctx + (size_t)b * W + l31 * 8, dcv);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) go[i] = fmaf(a, dcv[i], go[i]);
+                }
+            }
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += v[i];
+            const float mean = row_sum<32>(s) * invw;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float dl = v[i] - mean; q = __builtin_fmaf(dl, dl, q); }
+            const float rstd = rsqrtf(__builtin_fmaf(row_sum<32>(q), invw, eps));
+            float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float xh = (v[i] - mean) * rstd;
+                const float g = go[i];
+                dga[i] = __builtin_fmaf(g, xh, dga[i]);
+                dba[i] += g;
+                const float dxh = g * gm[i];
+                v[i] = xh; go[i] = dxh;
+                m1 += dxh; m2 = __builtin_fmaf(dxh, xh, m2);
+            }
+            m1 = row_sum<32>(m1) * invw;
+            m2 = row_sum<32>(m2) * invw;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = rstd * __builtin_fmaf(-v[i], m2, go[i] - m1);
+            stv_bf16<8>(dX + (size_t)r * W + l31 * 8, v);
+        }
+        __syncthreads();                       // the block is free for the next tile's dU
+    }
+    // block-level reduction of the affine gradients (in the tile's LDS block), then ONE atomic per column per block
+    float* red = reinterpret_cast<float*>(lds);          // [2][16][W] floats = 32 KB
+    const int wib = 2 * w + hi;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { red[(0 * 16 + wib) * W + l31 * 8 + i] = dga[i]; red[(1 * 16 + wib) * W + l31 * 8 + i] = dba[i]; }
+    __syncthreads();
+    if (tid < W) {
+        float sg = 0.f, sb = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { sg += red[(0 * 16 + k) * W + tid]; sb += red[(1 * 16 + k) * W + tid]; }
+        atomicAdd(dgamma + tid, sg);
+        atomicAdd(dbeta + tid, sb);
+    }
+}
+
 }  // namespace
 
 extern "C" int lob_dropout_f32(const float* in, float* out, int64_t n, float p, uint64_t seed, void* stream) {
@@ -976,6 +1125,25 @@ extern "C" int lob_dropout_f32(const float* in, float* out, int64_t n, float p, 
 static bool ln_lpr16() {
     const bool v = lob_variant(LOB_VAR_LN_LPR) != 64;
     return v;
+}
+
+extern "C" int lob_attn_ln_bwd_bf16(const void* X16, const float* gamma, const float* beta, const void* dU16,
+                                    const void* W1T_16, void* dX16, float* dgamma, float* dbeta, const float* attn,
+                                    const float* dctx, int T, int B, int Bp, int H, int D, float eps, void* stream) {
+    if (!X16 || !gamma || !beta || !dU16 || !W1T_16 || !dX16 || !dgamma || !dbeta || !attn || !dctx || T <= 0 || B <= 0 ||
+        Bp < B) return LOB_E_ARG;
+    if (H != 128 || D != 2 || (Bp % 32)) return LOB_E_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(X16) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta) |
+         reinterpret_cast<uintptr_t>(dU16) | reinterpret_cast<uintptr_t>(W1T_16) | reinterpret_cast<uintptr_t>(dX16) |
+         reinterpret_cast<uintptr_t>(dctx)) & 15) return LOB_E_ALIGN;
+    const long ntile = ((long)T * Bp + 127) / 128;
+    const int nb = (int)(ntile < 256 ? ntile : 256);      // one 8-wave workgroup per CU
+    hipLaunchKernelGGL(attn_ln_bwd_kernel, dim3(nb), dim3(512), 0, (hipStream_t)stream,
+                       reinterpret_cast<const __bf16*>(X16), gamma, beta, reinterpret_cast<const __bf16*>(dU16),
+                       reinterpret_cast<const __bf16*>(W1T_16), reinterpret_cast<__bf16*>(dX16), dgamma, dbeta, attn, dctx,
+                       T, B, Bp, eps);
+    LOB_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int lob_attn_scores_bf16(const void* Y16, const float* gamma, const float* beta, const void* W1_16,

@@ -454,6 +454,31 @@ def attn_pool_fwd_scores(v, S, T, B, Bp):
     return ctx, attn
 
 
+#: mixed path, H == 128 bidirectional: dV = dU W1 and the post-LSTM LayerNorm's backward in ONE kernel (dx bit-identical to
+#: the GEMM + LayerNorm-backward pair; tests switch it off to compare)
+FUSE_ATTN_LN_BWD = True
+
+
+def attn_ln_bwd_ok(ylast, dU, w1t, H, D, Bp, gamma):
+    bf = torch.bfloat16
+    return (bool(FUSE_ATTN_LN_BWD) and H == 128 and D == 2 and Bp % 32 == 0 and gamma is not None
+            and ylast.dtype == bf and dU.dtype == bf and w1t is not None and w1t.dtype == bf
+            and tuple(w1t.shape) == (256, 128) and ylast.is_contiguous() and dU.is_contiguous() and w1t.is_contiguous())
+
+
+def attn_ln_bwd(ylast, gamma, beta, dU, w1t, attn, dctx, T, B, Bp, H, D, eps=1e-5, dg=None, db=None):
+    """dY (bf16 [T*Bp, 256]) = LayerNorm backward of (dU @ W1 + attn[b][t] * dctx[b]); dgamma / dbeta accumulated."""
+    _chk(ylast, "ylast", torch.bfloat16); _chk(dU, "dU", torch.bfloat16); _chk(w1t, "w1t", torch.bfloat16)
+    _chk(gamma, "gamma"); _chk(beta, "beta"); _chk(attn, "attn"); _chk(dctx, "dctx")
+    dg = torch.zeros_like(gamma) if dg is None else dg
+    db = torch.zeros_like(beta) if db is None else db
+    dx = torch.empty_like(ylast)
+    rc = _lib.lib().lob_attn_ln_bwd_bf16(_ptr(ylast), _ptr(gamma), _ptr(beta), _ptr(dU), _ptr(w1t), _ptr(dx), _ptr(dg), _ptr(db),
+                                         _ptr(attn), _ptr(dctx), T, B, Bp, H, D, eps, _stream())
+    _lib.check(rc, "lob_attn_ln_bwd_bf16")
+    return dx, dg, db
+
+
 def softmax_rows(x):
     _chk(x, "x")
     out = torch.empty_like(x)

@@ -85,3 +85,71 @@ def test_model_outputs_do_not_change_with_the_fused_tail(dev):
     assert torch.equal(o1, o0)
     for a, b in zip(g1, g0):            # weight-gradient GEMMs use fp32 atomics: order-dependent last bits
         assert (a - b).abs().max().item() <= 2e-5 * max(1e-6, b.abs().max().item())
+
+
+@pytest.mark.parametrize("T,B", [(1, 1), (5, 3), (7, 40), (256, 8), (33, 70)])
+def test_fused_backward_tail_matches_gemm_plus_layernorm_backward(dev, T, B):
+    """lob_attn_ln_bwd_bf16 (dV = dU W1 + the pooling's context term, LayerNorm backward) against lob_gemm_nt_bf16 (bf16 dV)
+    + lob_layernorm_act_bwd_f32(pool).  The LayerNorm arithmetic is the same instruction for instruction; the K = 128
+    product is summed in another k order than the weight-stationary GEMM walks its swizzled LDS tile, so about one dV
+    element in 10^5 rounds to the neighbouring bf16 value and takes its own dx element with it (measured: 1 of 41 k,
+    20 of 2.1 M): everything else is bit-identical; dgamma / dbeta to fp32 summation order."""
+    from lstm_ode_bci_amd import ops
+    H, D = 128, 2
+    Bp = ops.ceil32(B)
+    g = torch.Generator(device=dev).manual_seed(T * 7 + B)
+    y16 = (torch.randn((T * Bp, 256), generator=g, device=dev) * 0.7).to(torch.bfloat16)
+    gam = torch.rand((256,), generator=g, device=dev) + 0.5
+    bet = torch.randn((256,), generator=g, device=dev) * 0.1
+    dU = (torch.randn((T * Bp, 128), generator=g, device=dev) * 0.05).to(torch.bfloat16)
+    w1t = (torch.randn((256, 128), generator=g, device=dev) * 0.08).to(torch.bfloat16)
+    attn = torch.softmax(torch.randn((B, T), generator=g, device=dev), dim=1)
+    dctx = torch.randn((B, 256), generator=g, device=dev) * 0.3
+    assert ops.attn_ln_bwd_ok(y16, dU, w1t, H, D, Bp, gam)
+    dx, dg, db = ops.attn_ln_bwd(y16, gam, bet, dU, w1t, attn, dctx, T, B, Bp, H, D)
+    dV = ops.gemm_nt(dU, w1t, mixed=True, out_bf16=True)
+    assert dV.dtype == torch.bfloat16
+    dxr, dgr, dbr = ops.layernorm_act_bwd(y16, gam, bet, dV, pool=(attn, dctx, T, B, Bp), dx_bf16=True)
+    same = (dx == dxr).float().mean().item()
+    assert same >= 1.0 - 1e-4, same
+    assert (dx.float() - dxr.float()).abs().max().item() <= 2 ** -7 * dxr.float().abs().max().item()
+    for a, b in ((dg, dgr), (db, dbr)):
+        assert (a - b).abs().max().item() <= 1e-5 * max(1.0, b.abs().max().item())
+    # float64 from the same bf16 operands: dy = bf16(dU W1) + attn * dctx, then the LayerNorm backward formula
+    x = y16.double()
+    dy = dV.double()
+    rows = torch.arange(T * Bp, device=dev)
+    t_i, b_i = rows // Bp, rows % Bp
+    ok = b_i < B
+    dy[ok] += attn.double()[b_i[ok], t_i[ok]][:, None] * dctx.double()[b_i[ok]]
+    mu = x.mean(1, keepdim=True)
+    rstd = 1.0 / torch.sqrt(x.var(1, unbiased=False, keepdim=True) + 1e-5)
+    xh = (x - mu) * rstd
+    dxh = dy * gam.double()
+    ref = rstd * (dxh - dxh.mean(1, keepdim=True) - xh * (dxh * xh).mean(1, keepdim=True))
+    err = (dx.double() - ref).abs().max().item()
+    assert err <= 1e-2 * max(1e-3, ref.abs().max().item())            # bf16 output rounding
+
+
+def test_model_gradients_do_not_change_with_the_fused_backward_tail(dev):
+    from lstm_ode_bci_amd import EnhancedLSTMModel, ops
+    sd = {k: torch.from_numpy(v) for k, v in syn.make_state_dict(61, 128, 3, 2, True).items()}
+    x, _ = syn.make_windows(24, 64, 61, seed=4)
+    xt = torch.from_numpy(x).to(dev)
+    grads = {}
+    for flag in (True, False):
+        m = EnhancedLSTMModel(61, 128, 3, 2, 0.4, True).to(dev)
+        m.load_state_dict(sd)
+        m.train()
+        old = ops.FUSE_ATTN_LN_BWD
+        ops.FUSE_ATTN_LN_BWD = flag
+        try:
+            torch.manual_seed(3)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                m(xt).float().square().sum().backward()
+        finally:
+            ops.FUSE_ATTN_LN_BWD = old
+        grads[flag] = {n: p.grad.clone() for n, p in m.named_parameters()}
+    for n in grads[True]:
+        a, b = grads[True][n], grads[False][n]
+        assert (a - b).abs().max().item() <= 2e-5 * max(1e-6, b.abs().max().item()), n
