@@ -96,14 +96,15 @@ __device__ __forceinline__ float wave_max(float v) {
 // step at B = 4096; 32-bit integer multiplies are quarter rate on CDNA, so every multiply counts.
 // The seed halves are wave-uniform (scalar registers); idx >> 32 is non-zero only beyond 4 G elements.
 __device__ __forceinline__ uint32_t lob_hash32(uint64_t seed, uint64_t idx) {
+    // two xorshift-multiply rounds (the "lowbias32" constants: avalanche bias 0.17 bits) over idx ^ seed; the high halves of
+    // the seed (wave-uniform: scalar arithmetic) and of the index (< 2^24: a full-rate 24-bit multiply) are folded in
+    // before the first round.  Round 3 dropped the third multiply round and the 32-bit multiply of idx >> 32: two
+    // quarter-rate multiplies per hash instead of four (the dropout-carrying recurrent forward spent ~10 % of its time here).
     uint32_t x = (uint32_t)idx ^ (uint32_t)seed;
-    x += (uint32_t)(idx >> 32) * 0x9E3779B9u;
+    x += __umul24((uint32_t)(idx >> 32), 0x9E3779u) + (uint32_t)(seed >> 32) * 0x85EBCA6Bu;
     x ^= x >> 16; x *= 0x7feb352du;
     x ^= x >> 15; x *= 0x846ca68bu;
     x ^= x >> 16;
-    x += (uint32_t)(seed >> 32);
-    x ^= x >> 15; x *= 0x2c1b3c6du;
-    x ^= x >> 12;
     return x;
 }
 // One 32-bit hash decides TWO neighbouring elements (idx >> 1; the even element reads bits 0..15, the odd one bits
