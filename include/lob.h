@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LOB_VERSION 203
+#define LOB_VERSION 204
 
 #define LOB_E_ARG   (-1)   /* null pointer / non-positive size                      */
 #define LOB_E_SHAPE (-2)   /* shape not supported by this kernel (see each entry)   */
