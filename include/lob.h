@@ -309,6 +309,17 @@ int lob_input_proj_ln_bf16(const float* x, int C, const float* W, int ldw, const
  * gradient with the same seed instead of storing a mask.  in == out is allowed.           */
 int lob_dropout_f32(const float* in, float* out, int64_t n, float p, uint64_t seed, void* stream);
 
+/* Fused head of the mixed backward, H == 128 (round 3): backward of input_proj's LayerNorm + GELU + dropout
+ * (04_lstm_model.py:175-177) and the Linear's weight gradient (04:174) in one pass; dpre is never written:
+ *   pre [B*T][128] fp32 (the LayerNorm's input, rows (b,t)); dA16 [T*Bp][128] bf16 (gradient of the block's output, time-major);
+ *   xb16 [B*T][Cp] bf16 (the padded windows saved by lob_input_proj_ln_bf16 / lob_pad_cast_bf16), Cp <= 64, Cp % 8 == 0;
+ *   dW [128][lddw] fp32 += dpre^T xb (bf16 operands, fp32 accumulate, atomics); dgamma / dbeta [128] accumulated;
+ *   dbias [128] (may be NULL) += column sums of the fp32 dpre.  act / drop_p / seed: those of the forward.
+ * Equals lob_layernorm_act_bwd_f32 (bf16 dx) + lob_gemm_tn_bf16 up to fp32 summation order.                         */
+int lob_input_proj_bwd_bf16(const float* pre, const float* gamma, const float* beta, const void* dA16, const void* xb16,
+                            int Cp, float* dW, int lddw, float* dgamma, float* dbeta, float* dbias,
+                            int B, int T, int Bp, int H, float eps, int act, float drop_p, uint64_t seed, void* stream);
+
 /* Fused tail of the mixed backward, H == 128 bidirectional (round 3): dV = dU W1 (+ attn[b][t] dctx[b], the context path
  * of the pooling) and the backward of the post-LSTM LayerNorm in one pass:
  *   X16 [T*Bp][256] bf16: the LayerNorm's input (the last LSTM layer's output); dU16 [T*Bp][128] bf16: gradient w.r.t. the

@@ -27,6 +27,8 @@ _SIGS = {
                               _f32p, C.c_void_p], C.c_int),
     "lob_layernorm_act_f32": ([_f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
                                C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_void_p], C.c_int),
+    "lob_input_proj_bwd_bf16": ([_f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, _f32p, C.c_int, _f32p, _f32p, _f32p, C.c_int, C.c_int,
+                                 C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, C.c_uint64, C.c_void_p], C.c_int),
     "lob_attn_ln_bwd_bf16": ([_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int,
                               C.c_int, C.c_int, C.c_float, C.c_void_p], C.c_int),
     "lob_attn_scores_bf16": ([_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int,

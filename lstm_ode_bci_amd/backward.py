@@ -258,6 +258,15 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad, sink=None):
     # bytes written and read (an input gradient, if asked for, keeps the fp32 rows)
     dpre16 = bool(ops.DPRE_BF16 and sv.get("xb") is not None and need_w and db_fused and not needs_input_grad[0]
                   and dY.dtype == torch.bfloat16 and sv["pre"].shape[1] in (128, 256))
+    if dpre16 and ops.input_proj_bwd_ok(sv["pre"], dY, sv["xb"], H):
+        # one launch: LayerNorm / GELU / dropout backward + the Linear's weight gradient; dpre never goes to HBM
+        xb = sv["xb"]
+        dwp = zeros((ps[0].shape[0], xb.shape[1]))
+        _, g[2], g[3] = ops.input_proj_bwd(sv["pre"], ps[2], ps[3], dY, xb, dwp, B, T, Bp, H, act=ACT_GELU, drop_p=p_in,
+                                           seed=_seed(seed, 0), dg=dg_t, db=db_t, dbias=db0)
+        g[0] = tgt.deliver(0, dwp[:, :C]) if sink is not None else dwp[:, :C].contiguous()
+        g[1] = db0
+        return None, (tgt.result(g) if tgt is not None else g)
     dpre, g[2], g[3] = ops.layernorm_act_bwd(sv["pre"], ps[2], ps[3], dY, act=ACT_GELU, remap=(T, B, Bp),
                                              drop_p=p_in, seed=_seed(seed, 0), dx_colsum=db0, dg=dg_t, db=db_t,
                                              dx_bf16=dpre16)

@@ -1110,6 +1110,172 @@ __global__ __launch_bounds__(512) void attn_ln_bwd_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Fused head of the mixed BACKWARD at width 128 (round 3): backward of input_proj's LayerNorm + GELU + dropout
+// (04_lstm_model.py:175-177) AND the Linear's weight gradient dW = dpre^T xb (04:174) in one pass: dpre (the gradient
+// w.r.t. the Linear's output) never goes to HBM.  Unfused, the LayerNorm backward wrote it (bf16, 256 B per row) and the TN
+// GEMM read it back next to the bf16 windows.  A wave owns 32 consecutive (b, t) rows: LayerNorm backward with the
+// unfused kernel's lane assignment and arithmetic (16 lanes x 8 columns, four rows per pass) -> bf16(dpre) TRANSPOSED into
+// the wave's LDS block, the rows' padded bf16 windows transposed next to it, then dW[128][64] += dpre^T xb as 8 blocks x
+// 2 k-steps of v_mfma_f32_32x32x16_bf16 into accumulators that live across the wave's tiles; at the end the four waves'
+// accumulators are summed through LDS and added to dW with one atomic per element and workgroup.  dgamma, dbeta and the
+// bias gradient (column sums of the fp32 dpre) as in the unfused kernel.
+// ------------------------------------------------------------------------------------------
+constexpr int HB_LDD = 160;            // bf16 row stride of the dpre tile ([row][128 columns + pad]: 320 B, see gemm_bf16.hip's LDK)
+constexpr int HB_LDX = 96;             // bf16 row stride of the window tile ([row][64 + pad]: 192 B -- four rows 64 B apart mod 256)
+
+typedef __bf16 hb_bf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) hb_bf16x4 hb_lds_bf16x4;
+// MFMA fragment of the 32-column block starting at column `cb`, k-step s (16 rows) of a [row][column] LDS image: gfx950's
+// transposing LDS read hands every lane 8 consecutive ROWS of one column (gemm_bf16.hip: tr_frag)
+template <int LD>
+__device__ __forceinline__ ip_bf16x8 hb_tr_frag(const __bf16* S, int cb, int ks, int lane) {
+    const int h = lane >> 5, mh = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
+    const __bf16* a = S + (16 * ks + 8 * h + q) * LD + cb + 16 * mh + 4 * p;
+    const hb_bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((hb_lds_bf16x4*)a);
+    const hb_bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((hb_lds_bf16x4*)(a + 4 * LD));
+    ip_bf16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return f;
+}
+
+__global__ __launch_bounds__(256, 2) void input_proj_bwd_kernel(
+    const float* __restrict__ pre, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const __bf16* __restrict__ dA, const __bf16* __restrict__ xb, int Cp, float* __restrict__ dW, int lddw,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dbias,
+    long rows, int T, int Bp, float eps, int act, float drop_p, uint64_t seed) {
+    constexpr int width = 128;
+    constexpr int WAVE_LDS = 32 * HB_LDD + 32 * HB_LDX;       // bf16 elements per wave: dpre tile + window tile = 16 KB
+    __shared__ __attribute__((aligned(16))) __bf16 tt[4 * WAVE_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
+    __bf16* dt = tt + wib * WAVE_LDS;
+    __bf16* xt = dt + 32 * HB_LDD;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int sub = lane >> 4, sl = lane & 15;
+    float gm[8], bt[8], dga[8], dba[8], dxs[8];
+    const bool norm = !(act & LOB_LN_IDENTITY);
+    act &= 0xff;
+    if (norm) { ldv<8>(gamma + sl * 8, gm); ldv<8>(beta + sl * 8, bt); }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { dga[i] = 0.f; dba[i] = 0.f; dxs[i] = 0.f; if (!norm) { gm[i] = 1.f; bt[i] = 0.f; } }
+    f32x16 acc[4][2];              // dW blocks [32 nb .. + 31][32 kb .. + 31]
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[nb][kb][i] = 0.f;
+    // window columns beyond Cp: zero once (their products must be zero, not stale LDS)
+    for (int i = lane; i < 32 * HB_LDX; i += 64) xt[i] = (__bf16)0.f;
+    const float invw = 1.0f / (float)width;
+    const long ntile = (rows + 31) >> 5;
+    const long gw = (long)blockIdx.x * 4 + wib, nw = (long)gridDim.x * 4;
+    const int cpc = Cp >> 3;                                   // 16-byte chunks per window row
+    for (long tl = gw; tl < ntile; tl += nw) {
+        const long r0 = tl * 32;
+        // ---- the tile's padded bf16 windows as they are: xt[r][k]
+        for (int i = lane; i < 32 * cpc; i += 64) {
+            const int rr = i / cpc, ch = i - rr * cpc;
+            ip_bf16x8 z;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.f;
+            if (r0 + rr < rows) z = *reinterpret_cast<const ip_bf16x8*>(xb + (size_t)(r0 + rr) * Cp + 8 * ch);
+            *reinterpret_cast<ip_bf16x8*>(xt + rr * HB_LDX + 8 * ch) = z;
+        }
+        // ---- LayerNorm backward, four rows per pass (layernorm_act_bwd_vec_kernel<8, 16, bf16, ., float>)
+#pragma unroll 2
+        for (int ps = 0; ps < 8; ++ps) {
+            const int rt = 4 * ps + sub;
+            const long r = r0 + rt;
+            float v[8], go[8];
+            if (r < rows) {
+                const long bw = r / T;
+                const long orow = (r - bw * T) * Bp + bw;
+                ldv<8>(pre + (size_t)r * width + sl * 8, v);
+                ldv_bf16<8>(dA + (size_t)orow * width + sl * 8, go);
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s += v[i];
+                const float mean = norm ? row_sum<16>(s) * invw : 0.f;
+                float q = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const float dl = v[i] - mean; q = __builtin_fmaf(dl, dl, q); }
+                const float rstd = norm ? rsqrtf(__builtin_fmaf(row_sum<16>(q), invw, eps)) : 1.f;
+                float m1 = 0.f, m2 = 0.f;
+                float ds[8];
+#pragma unroll
+                for (int i = 0; i < 8; i += 2) {
+                    if (drop_p > 0.f) lob_dropout_scale2(seed, (uint64_t)orow * width + sl * 8 + i, drop_p, ds[i], ds[i + 1]);
+                    else { ds[i] = 1.f; ds[i + 1] = 1.f; }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float xh = (v[i] - mean) * rstd;
+                    float g = go[i] * ds[i];
+                    if (act == LOB_ACT_GELU) g *= gelu_grad(xh * gm[i] + bt[i]);
+                    dga[i] = __builtin_fmaf(g, xh, dga[i]);
+                    dba[i] += g;
+                    const float dxh = g * gm[i];
+                    v[i] = xh; go[i] = dxh;
+                    m1 += dxh; m2 = __builtin_fmaf(dxh, xh, m2);
+                }
+                m1 = norm ? row_sum<16>(m1) * invw : 0.f;
+                m2 = norm ? row_sum<16>(m2) * invw : 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { v[i] = rstd * __builtin_fmaf(-v[i], m2, go[i] - m1); dxs[i] += v[i]; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = 0.f;
+            }
+            stv_bf16<8>(dt + rt * HB_LDD + 8 * sl, v);        // dpre[row][columns], bf16 as the unfused GEMM reads it
+        }
+        // ---- dW += dpre^T xb: A = dpre tile (block of 32 output rows n), B = window tile (block of 32 output columns k)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const ip_bf16x8 b0 = hb_tr_frag<HB_LDX>(xt, 0, ks, lane), b1 = hb_tr_frag<HB_LDX>(xt, 32, ks, lane);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                const ip_bf16x8 af = hb_tr_frag<HB_LDD>(dt, 32 * nb, ks, lane);
+                acc[nb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b0, acc[nb][0], 0, 0, 0);
+                acc[nb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b1, acc[nb][1], 0, 0, 0);
+            }
+        }
+    }
+    // ---- workgroup reductions in the tiles' LDS block: dW (four waves' accumulators), then dgamma / dbeta / dbias
+    __syncthreads();
+    float* wsum = reinterpret_cast<float*>(tt);                 // [128][64] fp32 = 32 KB
+    float* red = wsum + 128 * 64;                               // [3][16][128] fp32 = 24 KB  (block: 64 KB)
+    for (int i = tid; i < 128 * 64; i += 256) wsum[i] = 0.f;
+    const int wr = wib * 4 + sub;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        red[(0 * 16 + wr) * width + sl * 8 + i] = dga[i];
+        red[(1 * 16 + wr) * width + sl * 8 + i] = dba[i];
+        red[(2 * 16 + wr) * width + sl * 8 + i] = dxs[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                atomicAdd(&wsum[(32 * nb + (i & 3) + 8 * (i >> 2) + 4 * hi) * 64 + 32 * kb + l31], acc[nb][kb][i]);
+    __syncthreads();
+    for (int i = tid; i < 128 * Cp; i += 256) {
+        const int n = i / Cp, k = i - n * Cp;
+        atomicAdd(dW + (size_t)n * lddw + k, wsum[n * 64 + k]);
+    }
+    if (tid < width) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            s0 += red[(0 * 16 + k) * width + tid]; s1 += red[(1 * 16 + k) * width + tid]; s2 += red[(2 * 16 + k) * width + tid];
+        }
+        if (norm) { atomicAdd(dgamma + tid, s0); atomicAdd(dbeta + tid, s1); }
+        if (dbias) atomicAdd(dbias + tid, s2);
+    }
+}
+
 }  // namespace
 
 extern "C" int lob_dropout_f32(const float* in, float* out, int64_t n, float p, uint64_t seed, void* stream) {
@@ -1125,6 +1291,26 @@ extern "C" int lob_dropout_f32(const float* in, float* out, int64_t n, float p, 
 static bool ln_lpr16() {
     const bool v = lob_variant(LOB_VAR_LN_LPR) != 64;
     return v;
+}
+
+extern "C" int lob_input_proj_bwd_bf16(const float* pre, const float* gamma, const float* beta, const void* dA16,
+                                       const void* xb16, int Cp, float* dW, int lddw, float* dgamma, float* dbeta,
+                                       float* dbias, int B, int T, int Bp, int H, float eps, int act, float drop_p,
+                                       uint64_t seed, void* stream) {
+    if (!pre || !dA16 || !xb16 || !dW || B <= 0 || T <= 0 || Bp < B) return LOB_E_ARG;
+    if (!(act & LOB_LN_IDENTITY) && (!gamma || !beta || !dgamma || !dbeta)) return LOB_E_ARG;
+    if (H != 128 || Cp <= 0 || Cp > 64 || (Cp & 7) || lddw < Cp) return LOB_E_SHAPE;
+    if (drop_p < 0.f || drop_p >= 1.f) return LOB_E_ARG;
+    if ((reinterpret_cast<uintptr_t>(pre) | reinterpret_cast<uintptr_t>(dA16) | reinterpret_cast<uintptr_t>(xb16) |
+         reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) return LOB_E_ALIGN;
+    const long rows = (long)B * T;
+    const long ntile = (rows + 31) / 32;
+    const int nb = (int)((ntile + 3) / 4 < 512 ? (ntile + 3) / 4 : 512);
+    hipLaunchKernelGGL(input_proj_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, pre, gamma, beta,
+                       reinterpret_cast<const __bf16*>(dA16), reinterpret_cast<const __bf16*>(xb16), Cp, dW, lddw, dgamma, dbeta,
+                       dbias, rows, T, Bp, eps, act, drop_p, seed);
+    LOB_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int lob_attn_ln_bwd_bf16(const void* X16, const float* gamma, const float* beta, const void* dU16,

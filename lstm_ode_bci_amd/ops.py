@@ -479,6 +479,39 @@ def attn_ln_bwd(ylast, gamma, beta, dU, w1t, attn, dctx, T, B, Bp, H, D, eps=1e-
     return dx, dg, db
 
 
+#: mixed path, H == 128: backward of input_proj's LayerNorm + GELU + dropout AND the Linear's weight gradient in ONE kernel
+#: (dpre never goes to HBM); equal to the LayerNorm backward + TN GEMM pair up to fp32 summation order.  OFF by default:
+#: measured 0.07 ms per step SLOWER than the pair (same-box A/B: 14.30 against 14.23 ms) -- the LayerNorm backward with GELU'
+#: and the dropout hash is VALU-bound, and next to 128 accumulator registers only two waves per SIMD are left to hide it
+FUSE_INPUT_PROJ_BWD = False
+
+
+def input_proj_bwd_ok(pre, dA, xb, H):
+    bf = torch.bfloat16
+    return (bool(FUSE_INPUT_PROJ_BWD) and H == 128 and pre.dtype == torch.float32 and pre.shape[1] == 128 and dA.dtype == bf
+            and xb is not None and xb.dtype == bf and xb.shape[1] <= 64 and xb.shape[1] % 8 == 0
+            and pre.is_contiguous() and dA.is_contiguous() and xb.is_contiguous())
+
+
+def input_proj_bwd(pre, gamma, beta, dA, xb, dW, B, T, Bp, H, act=ACT_NONE, eps=1e-5, drop_p=0.0, seed=0, dg=None, db=None,
+                   dbias=None):
+    """dW [128, Cp] += dpre^T xb, dgamma / dbeta / dbias accumulated, where dpre = backward of LayerNorm + act + dropout of
+    input_proj applied to dA (bf16, time-major); pre: the LayerNorm's fp32 input rows (b,t)."""
+    _chk(pre, "pre"); _chk(dA, "dA", torch.bfloat16); _chk(xb, "xb", torch.bfloat16); _chk(dW, "dW")
+    _chk(gamma, "gamma"); _chk(beta, "beta")
+    if gamma is None:
+        act = act | LN_IDENTITY
+        dg = db = None
+    else:
+        dg = torch.zeros_like(gamma) if dg is None else dg
+        db = torch.zeros_like(beta) if db is None else db
+    rc = _lib.lib().lob_input_proj_bwd_bf16(_ptr(pre), _ptr(gamma), _ptr(beta), _ptr(dA), _ptr(xb), xb.shape[1], _ptr(dW),
+                                            dW.stride(0), _ptr(dg), _ptr(db), _ptr(dbias), B, T, Bp, H, eps, act,
+                                            float(drop_p), C.c_uint64(seed), _stream())
+    _lib.check(rc, "lob_input_proj_bwd_bf16")
+    return dW, dg, db
+
+
 def softmax_rows(x):
     _chk(x, "x")
     out = torch.empty_like(x)

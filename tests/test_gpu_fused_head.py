@@ -125,3 +125,80 @@ def test_fused_head_refuses_what_it_does_not_cover(dev):
     L = _lib.lib()
     assert L.lob_input_proj_ln_bf16(None, 61, None, 61, None, None, None, None, None, 64, None, 1, 1, 32, 128, 1e-5, 0, 0.0,
                                     0, None) == -1
+
+
+@pytest.mark.parametrize("B,T,C", [(1, 1, 61), (3, 7, 61), (5, 256, 61), (40, 33, 14), (130, 31, 61)])
+@pytest.mark.parametrize("p", [0.0, 0.3])
+@pytest.mark.parametrize("identity", [False, True])
+def test_fused_head_backward_matches_layernorm_backward_plus_tn_gemm(dev, B, T, C, p, identity):
+    """lob_input_proj_bwd_bf16 (LayerNorm + GELU + dropout backward and dW = dpre^T xb in one launch; dpre stays on chip)
+    against lob_layernorm_act_bwd_f32 (bf16 dpre) + lob_gemm_tn_bf16: the same bf16 operands reach the same matrix
+    instruction, only the fp32 order in which rows are summed differs (atomics in both) -> fp32-rounding agreement; and
+    against float64 from the same operands."""
+    from lstm_ode_bci_amd import ops
+    H = 128
+    g = torch.Generator(device=dev).manual_seed(B * 31 + T)
+    Bp = ops.ceil32(B)
+    Cp = (C + 7) // 8 * 8
+    pre = torch.randn((B * T, H), generator=g, device=dev) * 1.5
+    dA = (torch.randn((T * Bp, H), generator=g, device=dev) * 0.02).to(torch.bfloat16)
+    xb = torch.zeros((B * T, Cp), device=dev, dtype=torch.bfloat16)
+    xb[:, :C] = (torch.randn((B * T, C), generator=g, device=dev) * 2.0).to(torch.bfloat16)
+    gam = None if identity else torch.rand((H,), generator=g, device=dev) + 0.5
+    bet = None if identity else torch.randn((H,), generator=g, device=dev) * 0.1
+    old = ops.FUSE_INPUT_PROJ_BWD
+    ops.FUSE_INPUT_PROJ_BWD = True
+    try:
+        assert ops.input_proj_bwd_ok(pre, dA, xb, H)
+    finally:
+        ops.FUSE_INPUT_PROJ_BWD = old
+    dW = torch.zeros((H, Cp), device=dev)
+    dbias = torch.zeros((H,), device=dev)
+    _, dg, db = ops.input_proj_bwd(pre, gam, bet, dA, xb, dW, B, T, Bp, H, act=ops.ACT_GELU, drop_p=p, seed=99, dbias=dbias)
+    dbr = torch.zeros((H,), device=dev)
+    dpre, dgr, dber = ops.layernorm_act_bwd(pre, gam, bet, dA, act=ops.ACT_GELU, remap=(T, B, Bp), drop_p=p, seed=99,
+                                            dx_colsum=dbr, dx_bf16=True)
+    dWr = torch.zeros((H, Cp), device=dev)
+    ops.gemm_tn(dpre, xb, dWr, mixed=True)
+
+    def close(a, b, name, rel=2e-5):
+        assert (a - b).abs().max().item() <= rel * max(1e-6, b.abs().max().item()), (name, (a - b).abs().max().item())
+    close(dW, dWr, "dW")
+    close(dbias, dbr, "dbias")
+    if not identity:
+        close(dg, dgr, "dgamma"); close(db, dber, "dbeta")
+    assert torch.all(dW[:, C:] == 0)
+    ref = dpre.double().t() @ xb.double()
+    assert (dW.double() - ref).abs().max().item() <= 1e-4 * max(1e-6, ref.abs().max().item())
+
+
+def test_model_gradients_do_not_change_with_the_fused_head_backward(dev):
+    from lstm_ode_bci_amd import EnhancedLSTMModel, ops
+    sd = {k: torch.from_numpy(v) for k, v in syn.make_state_dict(61, 128, 3, 2, True).items()}
+    x, _ = syn.make_windows(40, 96, 61, seed=6)
+    xt = torch.from_numpy(x).to(dev)
+    grads = {}
+    for flag in (True, False):
+        m = EnhancedLSTMModel(61, 128, 3, 2, 0.4, True).to(dev)
+        m.load_state_dict(sd)
+        m.train()
+        old = ops.FUSE_INPUT_PROJ_BWD
+        ops.FUSE_INPUT_PROJ_BWD = flag
+        try:
+            torch.manual_seed(11)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                m(xt).float().square().sum().backward()
+        finally:
+            ops.FUSE_INPUT_PROJ_BWD = old
+        grads[flag] = {n: p.grad.clone() for n, p in m.named_parameters()}
+    for n in grads[True]:
+        a, b = grads[True][n], grads[False][n]
+        assert (a - b).abs().max().item() <= 2e-5 * max(1e-6, b.abs().max().item()), n
+    # an input gradient still works (falls back to the unfused pair, which materialises dpre)
+    m = EnhancedLSTMModel(61, 128, 3, 2, 0.4, True).to(dev)
+    m.load_state_dict(sd)
+    m.train()
+    xg = xt.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        m(xg).float().square().sum().backward()
+    assert xg.grad is not None and torch.isfinite(xg.grad).all() and xg.grad.abs().max().item() > 0
