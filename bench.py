@@ -415,9 +415,9 @@ class Leg:
 
         @contextlib.contextmanager
         def cm():
-            old = (ops.C_BF16, ops.DY_BF16_CARRY, ops.LN_X_BF16)
+            old = (ops.C_BF16, ops.DY_BF16_CARRY, ops.LN_X_BF16, ops.DPRE_BF16)
             if leg.strict_storage:
-                ops.C_BF16 = ops.DY_BF16_CARRY = ops.LN_X_BF16 = False
+                ops.C_BF16 = ops.DY_BF16_CARRY = ops.LN_X_BF16 = ops.DPRE_BF16 = False
             try:
                 if leg.exact_fp32:
                     with _lib.variant(F32_SPLIT=0):
@@ -425,7 +425,7 @@ class Leg:
                 else:
                     yield
             finally:
-                ops.C_BF16, ops.DY_BF16_CARRY, ops.LN_X_BF16 = old
+                ops.C_BF16, ops.DY_BF16_CARRY, ops.LN_X_BF16, ops.DPRE_BF16 = old
         return cm()
 
     def step(self):
