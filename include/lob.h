@@ -330,10 +330,10 @@ int lob_attn_ln_bwd_bf16(const void* X16, const float* gamma, const float* beta,
                          void* dX16, float* dgamma, float* dbeta, const float* attn, const float* dctx,
                          int T, int B, int Bp, int H, int D, float eps, void* stream);
 
-/* Fused tail of the mixed forward, H == 128 bidirectional (round 3): post-LSTM LayerNorm (04_lstm_model.py:192) and the
- * attention's score layer (04:123-125) in one pass over the last LSTM layer's bf16 output Y16 [T*Bp][256] (time-major):
- *   v = LN(Y16) (bf16, written to V [T*Bp][256]);  u = tanh(W1 v + b1);  S[b][t] = w2 . u + b2   (rows b < B)
- * W1_16: bf16 [128][256] (attention.attention.0.weight); U: fp32 [T*Bp][128] for the backward, or NULL (inference).
+/* Fused tail of the mixed forward, H == 128 or 256, bidirectional (round 3): post-LSTM LayerNorm (04_lstm_model.py:192) and the
+ * attention's score layer (04:123-125) in one pass over the last LSTM layer's bf16 output Y16 [T*Bp][2H] (time-major):
+ *   v = LN(Y16) (bf16, written to V [T*Bp][2H]);  u = tanh(W1 v + b1);  S[b][t] = w2 . u + b2   (rows b < B)
+ * W1_16: bf16 [H][2H] (attention.attention.0.weight); U: fp32 [T*Bp][H] for the backward, or NULL (inference).
  * v, u and the scores are bit-identical to lob_layernorm_act_f32 + lob_gemm_nt_bf16(tanh) + the score sums of
  * lob_attn_pool_fwd_f32.  The scores go to lob_attn_pool_fwd_f32 as U with W2 == 0.                                */
 int lob_attn_scores_bf16(const void* Y16, const float* gamma, const float* beta, const void* W1_16, const float* b1,
@@ -346,7 +346,7 @@ int lob_attn_scores_bf16(const void* Y16, const float* gamma, const float* beta,
  *   V [T*Bp][W], U [T*Bp][W2], attn [B][T], ctx [B][W].
  *   U == NULL: all scores equal, a = 1/T -- mean pooling over time, the no-attention ablation
  *   (torch.mean(lstm_out, dim=1), 09_sensitivity_analysis.py:236); w2, b2, W2 are then ignored.
- *   U != NULL with W2 == 0 (bf16 V, W == 256): U holds the finished scores S [B][T] of lob_attn_scores_bf16.   */
+ *   U != NULL with W2 == 0 (bf16 V, W == 256 or 512): U holds the finished scores S [B][T] of lob_attn_scores_bf16.   */
 int lob_attn_pool_fwd_f32(const void* V, int v_bf16, const float* U, const float* w2, const float* b2,
                           float* ctx, float* attn, int T, int B, int Bp, int W, int W2,
                           void* stream);

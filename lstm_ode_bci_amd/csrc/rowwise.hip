@@ -1276,6 +1276,112 @@ __global__ __launch_bounds__(256, 2) void input_proj_bwd_kernel(
     }
 }
 
+// The same fusion at H = 256 (post-LSTM width 512, score layer 512 -> 256): a workgroup of EIGHT waves owns 64 rows;
+// wave w normalises rows 8 w .. + 7 with the width-512 LayerNorm kernel's lane assignment (64 lanes x 8 columns, one row
+// per pass), owns the score layer's columns 32 w .. + 31 (32 B fragments of W1 = 128 registers, 2 row blocks x 32 k-steps)
+// and forms the scores of its 8 rows with the pooling kernel's order (4 columns per lane).
+constexpr int AS2_LDA = 520;           // bf16 row stride of the v tile (1040 B = 65 x 16 B)
+constexpr int AS2_LDU = 260;           // fp32 row stride of the u tile (1040 B)
+
+template <bool SAVE>
+__global__ __launch_bounds__(512) void attn_score_h256_kernel(
+    const __bf16* __restrict__ Y, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const __bf16* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
+    __bf16* __restrict__ V, float* __restrict__ U, float* __restrict__ S, int T, int B, int Bp, float eps) {
+    constexpr int W = 512, W2 = 256;
+    __shared__ __attribute__((aligned(16))) float lds[64 * AS2_LDU];
+    __bf16* at = reinterpret_cast<__bf16*>(lds);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    ip_bf16x8 wf[32];
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks)
+        wf[ks] = *reinterpret_cast<const ip_bf16x8*>(W1 + (size_t)(32 * w + l31) * W + 16 * ks + 8 * hi);
+    const float b1v = b1 ? b1[32 * w + l31] : 0.f;
+    float gm[8], bt[8];
+    ldv<8>(gamma + lane * 8, gm);
+    ldv<8>(beta + lane * 8, bt);
+    float w2v[4];
+    ldv<4>(w2 + 4 * lane, w2v);
+    const float bias2 = b2 ? b2[0] : 0.f;
+    const long rows = (long)T * Bp;
+    const long ntile = (rows + 63) >> 6;
+    const float invw = 1.0f / (float)W;
+    for (long tl = blockIdx.x; tl < ntile; tl += gridDim.x) {
+        const long r0 = tl * 64 + 8 * w;
+        // ---- 1. LayerNorm of this wave's 8 rows (layernorm_act_vec_kernel<8, true, 64, bf16>)
+        ip_bf16x8 raw[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const long r = r0 + p;
+            ip_bf16x8 z;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) z[i] = (__bf16)0.f;
+            raw[p] = r < rows ? *reinterpret_cast<const ip_bf16x8*>(Y + (size_t)r * W + lane * 8) : z;
+        }
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const long r = r0 + p;
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = (float)raw[p][i];
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += v[i];
+            const float mean = row_sum<64>(s) * invw;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float dl = v[i] - mean; q = __builtin_fmaf(dl, dl, q); }
+            const float rstd = rsqrtf(__builtin_fmaf(row_sum<64>(q), invw, eps));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = __builtin_fmaf((v[i] - mean) * rstd, gm[i], bt[i]);
+            __bf16* arow = at + (8 * w + p) * AS2_LDA + lane * 8;
+            stv_bf16<8>(arow, v);
+            if (r < rows) *reinterpret_cast<ip_bf16x8*>(V + (size_t)r * W + lane * 8) = *reinterpret_cast<const ip_bf16x8*>(arow);
+        }
+        __syncthreads();
+        // ---- 2. this wave's 32 score columns for the 64 rows
+        f32x16 acc[2];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[rb][i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 32; ++ks)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                const ip_bf16x8 a = *reinterpret_cast<const ip_bf16x8*>(at + (32 * rb + l31) * AS2_LDA + 16 * ks + 8 * hi);
+                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wf[ks], acc[rb], 0, 0, 0);
+            }
+        __syncthreads();
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                lds[(32 * rb + (i & 3) + 8 * (i >> 2) + 4 * hi) * AS2_LDU + 32 * w + l31] = fast_tanh(acc[rb][i] + b1v);
+        __syncthreads();
+        // ---- 3. scores of this wave's 8 rows (the pooling kernel's order: four columns per lane, wave reduction)
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const long r = r0 + rr;
+            if (r >= rows) break;
+            float uu[4];
+            {
+                const f32x4 t4 = *reinterpret_cast<const f32x4*>(lds + (8 * w + rr) * AS2_LDU + 4 * lane);
+                uu[0] = t4[0]; uu[1] = t4[1]; uu[2] = t4[2]; uu[3] = t4[3];
+            }
+            if (SAVE) stv<4>(U + (size_t)r * W2 + 4 * lane, uu);
+            float sc = uu[0] * w2v[0];
+#pragma unroll
+            for (int i = 1; i < 4; ++i) sc = fmaf(uu[i], w2v[i], sc);
+            sc = wave_sum(sc);
+            const int t = (int)(r / Bp), b = (int)(r - (long)t * Bp);
+            if (lane == 0 && b < B) S[(size_t)b * T + t] = sc + bias2;
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 extern "C" int lob_dropout_f32(const float* in, float* out, int64_t n, float p, uint64_t seed, void* stream) {
@@ -1336,10 +1442,24 @@ extern "C" int lob_attn_scores_bf16(const void* Y16, const float* gamma, const f
                                     const float* b1, const float* w2, const float* b2, void* V, float* U, float* S,
                                     int T, int B, int Bp, int H, int D, float eps, void* stream) {
     if (!Y16 || !gamma || !beta || !W1_16 || !w2 || !V || !S || T <= 0 || B <= 0 || Bp < B) return LOB_E_ARG;
-    if (H != 128 || D != 2 || (Bp % 32)) return LOB_E_SHAPE;
+    if ((H != 128 && H != 256) || D != 2 || (Bp % 32)) return LOB_E_SHAPE;
     if ((reinterpret_cast<uintptr_t>(Y16) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta) |
          reinterpret_cast<uintptr_t>(W1_16) | reinterpret_cast<uintptr_t>(w2) | reinterpret_cast<uintptr_t>(V) |
          reinterpret_cast<uintptr_t>(U)) & 15) return LOB_E_ALIGN;
+    if (H == 256) {
+        const long nt = ((long)T * Bp + 63) / 64;
+        const int nb2 = (int)(nt < 256 ? nt : 256);           // one 8-wave workgroup per CU
+        if (U)
+            hipLaunchKernelGGL((attn_score_h256_kernel<true>), dim3(nb2), dim3(512), 0, (hipStream_t)stream,
+                               reinterpret_cast<const __bf16*>(Y16), gamma, beta, reinterpret_cast<const __bf16*>(W1_16), b1, w2,
+                               b2, reinterpret_cast<__bf16*>(V), U, S, T, B, Bp, eps);
+        else
+            hipLaunchKernelGGL((attn_score_h256_kernel<false>), dim3(nb2), dim3(512), 0, (hipStream_t)stream,
+                               reinterpret_cast<const __bf16*>(Y16), gamma, beta, reinterpret_cast<const __bf16*>(W1_16), b1, w2,
+                               b2, reinterpret_cast<__bf16*>(V), U, S, T, B, Bp, eps);
+        LOB_CHECK_LAUNCH();
+        return 0;
+    }
     const long ntile = ((long)T * Bp + 127) / 128;
     const int nb = (int)(ntile < 512 ? ntile : 512);
     if (U)
@@ -1464,10 +1584,12 @@ extern "C" int lob_attn_pool_fwd_f32(const void* V, int v_bf16, const float* U, 
     if (!V || !ctx || !attn || T <= 0 || B <= 0 || Bp < B || W <= 0) return LOB_E_ARG;
     if ((size_t)T * sizeof(float) > 60 * 1024) return LOB_E_SHAPE;
     if (U && W2 == 0) {          // U = finished scores S[B][T] (lob_attn_scores_bf16)
-        if (!v_bf16 || W != 256 || (reinterpret_cast<uintptr_t>(V) & 7)) return LOB_E_SHAPE;
+        if (!v_bf16 || (W != 256 && W != 512) || (reinterpret_cast<uintptr_t>(V) & 15)) return LOB_E_SHAPE;
         const size_t smem = ((size_t)((T + 3) & ~3) + 4 * W) * sizeof(float);
-        hipLaunchKernelGGL((attn_pool_fwd_vec_kernel<1, true>), dim3(B), dim3(256), smem, (hipStream_t)stream,
-                           reinterpret_cast<const __bf16*>(V), U, w2, b2, ctx, attn, T, Bp);
+        if (W == 256) hipLaunchKernelGGL((attn_pool_fwd_vec_kernel<1, true>), dim3(B), dim3(256), smem, (hipStream_t)stream,
+                                         reinterpret_cast<const __bf16*>(V), U, w2, b2, ctx, attn, T, Bp);
+        else          hipLaunchKernelGGL((attn_pool_fwd_vec_kernel<2, true>), dim3(B), dim3(256), smem, (hipStream_t)stream,
+                                         reinterpret_cast<const __bf16*>(V), U, w2, b2, ctx, attn, T, Bp);
         LOB_CHECK_LAUNCH();
         return 0;
     }

@@ -425,8 +425,8 @@ FUSE_ATTN_SCORES = True
 
 
 def attn_scores_ok(y16, H, D, Bp, w1):
-    return (bool(FUSE_ATTN_SCORES) and H == 128 and D == 2 and Bp % 32 == 0 and y16.dtype == torch.bfloat16
-            and y16.is_contiguous() and w1 is not None and tuple(w1.shape) == (128, 256))
+    return (bool(FUSE_ATTN_SCORES) and H in (128, 256) and D == 2 and Bp % 32 == 0 and y16.dtype == torch.bfloat16
+            and y16.is_contiguous() and w1 is not None and tuple(w1.shape) == (H, 2 * H))
 
 
 def attn_scores(y16, gamma, beta, w1_16, b1, w2, b2, T, B, Bp, H, D, eps=1e-5, save=False):

@@ -20,24 +20,26 @@ def dev():
 
 @pytest.mark.parametrize("T,B", [(1, 1), (5, 3), (7, 40), (256, 8), (33, 70), (64, 128)])
 @pytest.mark.parametrize("save", [False, True])
-def test_fused_tail_is_bit_identical_to_the_three_kernels(dev, T, B, save):
+@pytest.mark.parametrize("H", [128, 256])
+def test_fused_tail_is_bit_identical_to_the_three_kernels(dev, T, B, save, H):
     from lstm_ode_bci_amd import ops
-    H, D = 128, 2
+    D = 2
+    W = 2 * H
     Bp = ops.ceil32(B)
-    g = torch.Generator(device=dev).manual_seed(T * 100 + B)
-    y16 = (torch.randn((T * Bp, 256), generator=g, device=dev) * 0.7).to(torch.bfloat16)
-    gam = torch.rand((256,), generator=g, device=dev) + 0.5
-    bet = torch.randn((256,), generator=g, device=dev) * 0.1
-    w1 = torch.randn((128, 256), generator=g, device=dev) * 0.08
-    b1 = torch.randn((128,), generator=g, device=dev) * 0.1
-    w2 = torch.randn((128,), generator=g, device=dev) * 0.3
+    g = torch.Generator(device=dev).manual_seed(T * 100 + B + H)
+    y16 = (torch.randn((T * Bp, W), generator=g, device=dev) * 0.7).to(torch.bfloat16)
+    gam = torch.rand((W,), generator=g, device=dev) + 0.5
+    bet = torch.randn((W,), generator=g, device=dev) * 0.1
+    w1 = torch.randn((H, W), generator=g, device=dev) * 0.08
+    b1 = torch.randn((H,), generator=g, device=dev) * 0.1
+    w2 = torch.randn((H,), generator=g, device=dev) * 0.3
     b2 = torch.randn((1,), generator=g, device=dev)
     w1_16 = w1.to(torch.bfloat16)
     assert ops.attn_scores_ok(y16, H, D, Bp, w1)
     v, u, S = ops.attn_scores(y16, gam, bet, w1_16, b1, w2, b2, T, B, Bp, H, D, save=save)
     ctx, attn = ops.attn_pool_fwd_scores(v, S, T, B, Bp)
     vr = ops.layernorm_act(y16, gam, bet, out_bf16=True)
-    ur = ops.gemm_nt(vr, w1_16 if ops.dma_ok(256, 128, T * Bp) else w1, b1, act=ops.ACT_TANH, mixed=True)
+    ur = ops.gemm_nt(vr, w1_16 if ops.dma_ok(W, H, T * Bp) else w1, b1, act=ops.ACT_TANH, mixed=True)
     ctxr, attnr = ops.attn_pool_fwd(vr, ur, w2, b2, T, B, Bp)
     assert torch.equal(v.view(torch.int16), vr.view(torch.int16))
     if save:
@@ -50,17 +52,18 @@ def test_fused_tail_is_bit_identical_to_the_three_kernels(dev, T, B, save):
     u64 = torch.tanh(v64 @ w1_16.double().t() + b1.double())
     s64 = (u64 @ w2.double() + b2.double()).reshape(T, Bp)[:, :B].t()
     a64 = torch.softmax(s64, dim=1)
-    assert (attn.double() - a64).abs().max().item() < 2e-6
+    assert (attn.double() - a64).abs().max().item() < 4e-6
 
 
-def test_model_outputs_do_not_change_with_the_fused_tail(dev):
+@pytest.mark.parametrize("H", [128, 256])
+def test_model_outputs_do_not_change_with_the_fused_tail(dev, H):
     from lstm_ode_bci_amd import EnhancedLSTMModel, ops
-    sd = {k: torch.from_numpy(v) for k, v in syn.make_state_dict(61, 128, 3, 2, True).items()}
+    sd = {k: torch.from_numpy(v) for k, v in syn.make_state_dict(61, H, 3, 2, True).items()}
     x, _ = syn.make_windows(24, 64, 61, seed=4)
     xt = torch.from_numpy(x).to(dev)
 
     def run(fused, train):
-        m = EnhancedLSTMModel(61, 128, 3, 2, 0.4, True).to(dev)
+        m = EnhancedLSTMModel(61, H, 3, 2, 0.4, True).to(dev)
         m.load_state_dict(sd)
         m.train(train)
         old = ops.FUSE_ATTN_SCORES
