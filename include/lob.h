@@ -320,11 +320,11 @@ int lob_input_proj_bwd_bf16(const float* pre, const float* gamma, const float* b
                             int Cp, float* dW, int lddw, float* dgamma, float* dbeta, float* dbias,
                             int B, int T, int Bp, int H, float eps, int act, float drop_p, uint64_t seed, void* stream);
 
-/* Fused tail of the mixed backward, H == 128 bidirectional (round 3): dV = dU W1 (+ attn[b][t] dctx[b], the context path
+/* Fused tail of the mixed backward, H == 128 or 256, bidirectional (round 3): dV = dU W1 (+ attn[b][t] dctx[b], the context path
  * of the pooling) and the backward of the post-LSTM LayerNorm in one pass:
- *   X16 [T*Bp][256] bf16: the LayerNorm's input (the last LSTM layer's output); dU16 [T*Bp][128] bf16: gradient w.r.t. the
- *   score layer's pre-activations (lob_attn_pool_bwd_f32); W1T_16 bf16 [256][128] = attention.attention.0.weight^T;
- *   dX16 [T*Bp][256] bf16 out; dgamma / dbeta accumulated (fp32 atomics); attn [B][T], dctx [B][256] fp32.
+ *   X16 [T*Bp][2H] bf16: the LayerNorm's input (the last LSTM layer's output); dU16 [T*Bp][H] bf16: gradient w.r.t. the
+ *   score layer's pre-activations (lob_attn_pool_bwd_f32); W1T_16 bf16 [2H][H] = attention.attention.0.weight^T;
+ *   dX16 [T*Bp][2H] bf16 out; dgamma / dbeta accumulated (fp32 atomics); attn [B][T], dctx [B][2H] fp32.
  * dX16 is bit-identical to lob_gemm_nt_bf16 (bf16 dV) + lob_layernorm_act_bwd_f32(pool_attn, pool_dctx).             */
 int lob_attn_ln_bwd_bf16(const void* X16, const float* gamma, const float* beta, const void* dU16, const void* W1T_16,
                          void* dX16, float* dgamma, float* dbeta, const float* attn, const float* dctx,

@@ -1382,6 +1382,147 @@ __global__ __launch_bounds__(512) void attn_score_h256_kernel(
     }
 }
 
+// The backward tail at H = 256 (width 512, dU 256 wide): eight waves per 64-row tile; wave w owns 64 of dV's 512 columns
+// (2 column blocks x 16 k-steps = 32 B fragments of W1^T) and the LayerNorm backward of rows 8 w .. + 7 with the width-512
+// kernel's lane assignment (64 lanes x 8 columns, one row per pass).
+constexpr int AB2_LDA = 264;           // bf16 row stride of the dU tile (528 B)
+constexpr int AB2_LDV = 520;           // bf16 row stride of the dV tile (1040 B)
+
+__global__ __launch_bounds__(512) void attn_ln_bwd_h256_kernel(
+    const __bf16* __restrict__ X, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const __bf16* __restrict__ dU, const __bf16* __restrict__ W1T, __bf16* __restrict__ dX,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, const float* __restrict__ attn, const float* __restrict__ dctx,
+    int T, int B, int Bp, float eps) {
+    constexpr int W = 512, W2 = 256;
+    __shared__ __attribute__((aligned(16))) __bf16 lds[64 * AB2_LDV];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    ip_bf16x8 wf[2][16];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks)
+            wf[cb][ks] = *reinterpret_cast<const ip_bf16x8*>(W1T + (size_t)(64 * w + 32 * cb + l31) * W2 + 16 * ks + 8 * hi);
+    float gm[8], bt[8], dga[8], dba[8];
+    ldv<8>(gamma + lane * 8, gm);
+    ldv<8>(beta + lane * 8, bt);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { dga[i] = 0.f; dba[i] = 0.f; }
+    const long rows = (long)T * Bp;
+    const long ntile = (rows + 63) >> 6;
+    const float invw = 1.0f / (float)W;
+    for (long tl = blockIdx.x; tl < ntile; tl += gridDim.x) {
+        const long r0 = tl * 64 + 8 * w;
+        // ---- 0. this wave's 8 rows of dU (512 B each): lane -> (row l / 32 + 2 i, 16-byte chunk l % 32)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rr = (lane >> 5) + 2 * i, ch = lane & 31;
+            const long r = r0 + rr;
+            ip_bf16x8 z;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.f;
+            if (r < rows) z = *reinterpret_cast<const ip_bf16x8*>(dU + (size_t)r * W2 + 8 * ch);
+            *reinterpret_cast<ip_bf16x8*>(lds + (8 * w + rr) * AB2_LDA + 8 * ch) = z;
+        }
+        __syncthreads();
+        // ---- 1. dV = dU W1: this wave's 64 columns for the 64 rows (operands swapped like the unfused GEMM)
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[rb][cb][i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                const ip_bf16x8 a = *reinterpret_cast<const ip_bf16x8*>(lds + (32 * rb + l31) * AB2_LDA + 16 * ks + 8 * hi);
+                acc[rb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][ks], a, acc[rb][0], 0, 0, 0);
+                acc[rb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1][ks], a, acc[rb][1], 0, 0, 0);
+            }
+        __syncthreads();
+        typedef __bf16 ab_bf16x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    ab_bf16x4 pk = {(__bf16)acc[rb][cb][4 * q4], (__bf16)acc[rb][cb][4 * q4 + 1], (__bf16)acc[rb][cb][4 * q4 + 2],
+                                    (__bf16)acc[rb][cb][4 * q4 + 3]};
+                    *reinterpret_cast<ab_bf16x4*>(lds + (32 * rb + l31) * AB2_LDV + 64 * w + 32 * cb + 8 * q4 + 4 * hi) = pk;
+                }
+        // the LayerNorm inputs of this wave's 8 rows: requested now (the accumulators are dead), used after the barrier
+        ip_bf16x8 xr[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const long r = r0 + p;
+            ip_bf16x8 z;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.f;
+            xr[p] = r < rows ? *reinterpret_cast<const ip_bf16x8*>(X + (size_t)r * W + lane * 8) : z;
+        }
+        __syncthreads();
+        // ---- 3. LayerNorm backward of rows 8 w .. + 7 (layernorm_act_bwd_vec_kernel<8, 64, bf16, bf16, bf16>)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const long r = r0 + p;
+            if (r >= rows) continue;
+            float v[8], go[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = (float)xr[p][i];
+            ldv_bf16<8>(lds + (8 * w + p) * AB2_LDV + lane * 8, go);
+            {
+                const int t = (int)(r / Bp), b = (int)(r - (long)t * Bp);
+                if (b < B) {
+                    const float a = attn[(size_t)b * T + t];
+                    float dcv[8];
+                    ldv<8>(dctx + (size_t)b * W + lane * 8, dcv);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) go[i] = fmaf(a, dcv[i], go[i]);
+                }
+            }
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += v[i];
+            const float mean = row_sum<64>(s) * invw;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float dl = v[i] - mean; q = __builtin_fmaf(dl, dl, q); }
+            const float rstd = rsqrtf(__builtin_fmaf(row_sum<64>(q), invw, eps));
+            float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float xh = (v[i] - mean) * rstd;
+                const float g = go[i];
+                dga[i] = __builtin_fmaf(g, xh, dga[i]);
+                dba[i] += g;
+                const float dxh = g * gm[i];
+                v[i] = xh; go[i] = dxh;
+                m1 += dxh; m2 = __builtin_fmaf(dxh, xh, m2);
+            }
+            m1 = row_sum<64>(m1) * invw;
+            m2 = row_sum<64>(m2) * invw;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = rstd * __builtin_fmaf(-v[i], m2, go[i] - m1);
+            stv_bf16<8>(dX + (size_t)r * W + lane * 8, v);
+        }
+        __syncthreads();
+    }
+    float* red = reinterpret_cast<float*>(lds);          // [2][8][W] floats = 32 KB
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { red[(0 * 8 + w) * W + lane * 8 + i] = dga[i]; red[(1 * 8 + w) * W + lane * 8 + i] = dba[i]; }
+    __syncthreads();
+    {
+        float sg = 0.f, sb = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { sg += red[(0 * 8 + k) * W + tid]; sb += red[(1 * 8 + k) * W + tid]; }
+        atomicAdd(dgamma + tid, sg);
+        atomicAdd(dbeta + tid, sb);
+    }
+}
+
 }  // namespace
 
 extern "C" int lob_dropout_f32(const float* in, float* out, int64_t n, float p, uint64_t seed, void* stream) {
@@ -1424,10 +1565,20 @@ extern "C" int lob_attn_ln_bwd_bf16(const void* X16, const float* gamma, const f
                                     const float* dctx, int T, int B, int Bp, int H, int D, float eps, void* stream) {
     if (!X16 || !gamma || !beta || !dU16 || !W1T_16 || !dX16 || !dgamma || !dbeta || !attn || !dctx || T <= 0 || B <= 0 ||
         Bp < B) return LOB_E_ARG;
-    if (H != 128 || D != 2 || (Bp % 32)) return LOB_E_SHAPE;
+    if ((H != 128 && H != 256) || D != 2 || (Bp % 32)) return LOB_E_SHAPE;
     if ((reinterpret_cast<uintptr_t>(X16) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta) |
          reinterpret_cast<uintptr_t>(dU16) | reinterpret_cast<uintptr_t>(W1T_16) | reinterpret_cast<uintptr_t>(dX16) |
          reinterpret_cast<uintptr_t>(dctx)) & 15) return LOB_E_ALIGN;
+    if (H == 256) {
+        const long nt = ((long)T * Bp + 63) / 64;
+        const int nb2 = (int)(nt < 256 ? nt : 256);
+        hipLaunchKernelGGL(attn_ln_bwd_h256_kernel, dim3(nb2), dim3(512), 0, (hipStream_t)stream,
+                           reinterpret_cast<const __bf16*>(X16), gamma, beta, reinterpret_cast<const __bf16*>(dU16),
+                           reinterpret_cast<const __bf16*>(W1T_16), reinterpret_cast<__bf16*>(dX16), dgamma, dbeta, attn, dctx,
+                           T, B, Bp, eps);
+        LOB_CHECK_LAUNCH();
+        return 0;
+    }
     const long ntile = ((long)T * Bp + 127) / 128;
     const int nb = (int)(ntile < 256 ? ntile : 256);      // one 8-wave workgroup per CU
     hipLaunchKernelGGL(attn_ln_bwd_kernel, dim3(nb), dim3(512), 0, (hipStream_t)stream,

@@ -461,9 +461,9 @@ FUSE_ATTN_LN_BWD = True
 
 def attn_ln_bwd_ok(ylast, dU, w1t, H, D, Bp, gamma):
     bf = torch.bfloat16
-    return (bool(FUSE_ATTN_LN_BWD) and H == 128 and D == 2 and Bp % 32 == 0 and gamma is not None
+    return (bool(FUSE_ATTN_LN_BWD) and H in (128, 256) and D == 2 and Bp % 32 == 0 and gamma is not None
             and ylast.dtype == bf and dU.dtype == bf and w1t is not None and w1t.dtype == bf
-            and tuple(w1t.shape) == (256, 128) and ylast.is_contiguous() and dU.is_contiguous() and w1t.is_contiguous())
+            and tuple(w1t.shape) == (2 * H, H) and ylast.is_contiguous() and dU.is_contiguous() and w1t.is_contiguous())
 
 
 def attn_ln_bwd(ylast, gamma, beta, dU, w1t, attn, dctx, T, B, Bp, H, D, eps=1e-5, dg=None, db=None):

@@ -91,23 +91,25 @@ def test_model_outputs_do_not_change_with_the_fused_tail(dev, H):
 
 
 @pytest.mark.parametrize("T,B", [(1, 1), (5, 3), (7, 40), (256, 8), (33, 70)])
-def test_fused_backward_tail_matches_gemm_plus_layernorm_backward(dev, T, B):
+@pytest.mark.parametrize("H", [128, 256])
+def test_fused_backward_tail_matches_gemm_plus_layernorm_backward(dev, T, B, H):
     """lob_attn_ln_bwd_bf16 (dV = dU W1 + the pooling's context term, LayerNorm backward) against lob_gemm_nt_bf16 (bf16 dV)
-    + lob_layernorm_act_bwd_f32(pool).  The LayerNorm arithmetic is the same instruction for instruction; the K = 128
+    + lob_layernorm_act_bwd_f32(pool).  The LayerNorm arithmetic is the same instruction for instruction; the K = H
     product is summed in another k order than the weight-stationary GEMM walks its swizzled LDS tile, so about one dV
     element in 10^5 rounds to the neighbouring bf16 value and takes its own dx element with it (measured: 1 of 41 k,
     20 of 2.1 M): everything else is bit-identical; dgamma / dbeta to fp32 summation order."""
     from lstm_ode_bci_amd import ops
-    H, D = 128, 2
+    D = 2
+    W = 2 * H
     Bp = ops.ceil32(B)
-    g = torch.Generator(device=dev).manual_seed(T * 7 + B)
-    y16 = (torch.randn((T * Bp, 256), generator=g, device=dev) * 0.7).to(torch.bfloat16)
-    gam = torch.rand((256,), generator=g, device=dev) + 0.5
-    bet = torch.randn((256,), generator=g, device=dev) * 0.1
-    dU = (torch.randn((T * Bp, 128), generator=g, device=dev) * 0.05).to(torch.bfloat16)
-    w1t = (torch.randn((256, 128), generator=g, device=dev) * 0.08).to(torch.bfloat16)
+    g = torch.Generator(device=dev).manual_seed(T * 7 + B + H)
+    y16 = (torch.randn((T * Bp, W), generator=g, device=dev) * 0.7).to(torch.bfloat16)
+    gam = torch.rand((W,), generator=g, device=dev) + 0.5
+    bet = torch.randn((W,), generator=g, device=dev) * 0.1
+    dU = (torch.randn((T * Bp, H), generator=g, device=dev) * 0.05).to(torch.bfloat16)
+    w1t = (torch.randn((W, H), generator=g, device=dev) * 0.08).to(torch.bfloat16)
     attn = torch.softmax(torch.randn((B, T), generator=g, device=dev), dim=1)
-    dctx = torch.randn((B, 256), generator=g, device=dev) * 0.3
+    dctx = torch.randn((B, W), generator=g, device=dev) * 0.3
     assert ops.attn_ln_bwd_ok(y16, dU, w1t, H, D, Bp, gam)
     dx, dg, db = ops.attn_ln_bwd(y16, gam, bet, dU, w1t, attn, dctx, T, B, Bp, H, D)
     dV = ops.gemm_nt(dU, w1t, mixed=True, out_bf16=True)
@@ -134,14 +136,15 @@ def test_fused_backward_tail_matches_gemm_plus_layernorm_backward(dev, T, B):
     assert err <= 1e-2 * max(1e-3, ref.abs().max().item())            # bf16 output rounding
 
 
-def test_model_gradients_do_not_change_with_the_fused_backward_tail(dev):
+@pytest.mark.parametrize("H", [128, 256])
+def test_model_gradients_do_not_change_with_the_fused_backward_tail(dev, H):
     from lstm_ode_bci_amd import EnhancedLSTMModel, ops
-    sd = {k: torch.from_numpy(v) for k, v in syn.make_state_dict(61, 128, 3, 2, True).items()}
+    sd = {k: torch.from_numpy(v) for k, v in syn.make_state_dict(61, H, 3, 2, True).items()}
     x, _ = syn.make_windows(24, 64, 61, seed=4)
     xt = torch.from_numpy(x).to(dev)
     grads = {}
     for flag in (True, False):
-        m = EnhancedLSTMModel(61, 128, 3, 2, 0.4, True).to(dev)
+        m = EnhancedLSTMModel(61, H, 3, 2, 0.4, True).to(dev)
         m.load_state_dict(sd)
         m.train()
         old = ops.FUSE_ATTN_LN_BWD
