@@ -50,6 +50,11 @@ template <typename E> struct Raw16;
 template <> struct Raw16<float> { f32x4 v[8]; };
 template <> struct Raw16<__bf16> { bf16x4 v[8]; };
 
+// Cache-policy experiment (tools/h256_ablate.sh with ABL_SRC=lstm_rec_bf16_s16 ABL_DEF=LOB_NT128): bit 0 = non-temporal P
+// loads, bit 1 = non-temporal saved-gate / cell-state stores, bit 2 = non-temporal Y16 / Yd stores of the forward kernel
+#ifndef LOB_NT128
+#define LOB_NT128 0
+#endif
 template <typename E>
 __device__ __forceinline__ void load_raw16(const E* p, unsigned off, Raw16<E>& r) {
 #pragma unroll
@@ -57,6 +62,7 @@ __device__ __forceinline__ void load_raw16(const E* p, unsigned off, Raw16<E>& r
 #pragma unroll
         for (int cbu = 0; cbu < 2; ++cbu) {
             if constexpr (sizeof(E) == 4) r.v[2 * g + cbu] = *reinterpret_cast<const f32x4*>((p + g * 1024 + cbu * 64) + off);
+            else if constexpr (LOB_NT128 & 1) r.v[2 * g + cbu] = __builtin_nontemporal_load(reinterpret_cast<const bf16x4*>((p + g * 1024 + cbu * 128) + off));
             else                          r.v[2 * g + cbu] = *reinterpret_cast<const bf16x4*>((p + g * 1024 + cbu * 128) + off);
         }
 }
@@ -70,7 +76,8 @@ __device__ __forceinline__ void store_frag16(E* p, unsigned off, const f32x4 (&s
                 *reinterpret_cast<f32x4*>((p + g * 1024 + cbu * 64) + off) = src[g][cbu];
             } else {
                 bf16x4 v = {(__bf16)src[g][cbu][0], (__bf16)src[g][cbu][1], (__bf16)src[g][cbu][2], (__bf16)src[g][cbu][3]};
-                *reinterpret_cast<bf16x4*>((p + g * 1024 + cbu * 128) + off) = v;
+                if constexpr (LOB_NT128 & 2) __builtin_nontemporal_store(v, reinterpret_cast<bf16x4*>((p + g * 1024 + cbu * 128) + off));
+                else *reinterpret_cast<bf16x4*>((p + g * 1024 + cbu * 128) + off) = v;
             }
         }
 }
@@ -196,7 +203,8 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_fwd_h128_bf16_s16_kernel(
                     *reinterpret_cast<f32x4*>((cp + cbu * FRAG_CBU<CE>) + lane_c) = v;
                 } else {
                     bf16x4 v = {(__bf16)c[cbu][0], (__bf16)c[cbu][1], (__bf16)c[cbu][2], (__bf16)c[cbu][3]};
-                    *reinterpret_cast<bf16x4*>((cp + cbu * FRAG_CBU<CE>) + lane_c) = v;
+                    if constexpr (LOB_NT128 & 2) __builtin_nontemporal_store(v, reinterpret_cast<bf16x4*>((cp + cbu * FRAG_CBU<CE>) + lane_c));
+                    else *reinterpret_cast<bf16x4*>((cp + cbu * FRAG_CBU<CE>) + lane_c) = v;
                 }
             }
         }
@@ -213,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_fwd_h128_bf16_s16_kernel(
             const int row = tid >> 4, c8 = (tid & 15) * 8;
             const bf16x8 hv = *reinterpret_cast<const bf16x8*>(hsrc + row * HB_LD + c8);
             const size_t o = ((size_t)t * Bp + row0 + row) * DH + d * H + c8;
-            if (Y16) *reinterpret_cast<bf16x8*>(Y16p + o) = hv;
+            if (Y16) { if constexpr (LOB_NT128 & 4) __builtin_nontemporal_store(hv, reinterpret_cast<bf16x8*>(Y16p + o)); else *reinterpret_cast<bf16x8*>(Y16p + o) = hv; }
             if (DROP) {
                 bf16x8 dv;
 #pragma unroll
@@ -223,7 +231,8 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_fwd_h128_bf16_s16_kernel(
                     dv[j] = (__bf16)((float)hv[j] * s0);
                     dv[j + 1] = (__bf16)((float)hv[j + 1] * s1);
                 }
-                *reinterpret_cast<bf16x8*>(Yd + o) = dv;
+                if constexpr (LOB_NT128 & 4) __builtin_nontemporal_store(dv, reinterpret_cast<bf16x8*>(Yd + o));
+                else *reinterpret_cast<bf16x8*>(Yd + o) = dv;
             }
         }
     };
