@@ -3,7 +3,6 @@
 LayerNorm): same matrix instruction, same k order, same lane assignment in the LayerNorm, same dropout hash -- the
 activations, the saved pre-activations and the saved bf16 windows must be BIT-IDENTICAL, on ragged shapes too (B * T not a
 multiple of the 32-row tile, padded batch rows, C = 14 / 61 / 64-8), and so must the model's outputs and gradients."""
-import numpy as np
 import pytest
 import torch
 

@@ -3,7 +3,6 @@ attention's score layer 04:123-125 in one launch, scores handed to the pooling k
 replaces: same lane assignment in the LayerNorm, same matrix instruction and k order in the score layer, same reduction
 order of the scores -> v, u, the attention weights and the context must be BIT-IDENTICAL, also on row counts that do
 not fill the 128-row tile and with padded batch rows; and the model's outputs / gradients must not move."""
-import numpy as np
 import pytest
 import torch
 
