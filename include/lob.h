@@ -42,6 +42,8 @@ extern "C" {
 #define LOB_X_BF16 0x1000     /* OR into `act` of lob_layernorm_act_f32 / lob_layernorm_act_bwd_f32: the input rows x are
                                * bf16 (widths 256 / 512; the backward then also needs LOB_DY_BF16 | LOB_OUT_BF16): in the mixed
                                * path the last LSTM layer hands its output over as bf16 only                             */
+#define LOB_IP_COLWAVE 0x4000 /* OR into `act` of lob_input_proj_ln_bf16 (H == 128): the column-decomposed kernel (the one H == 256
+                               * always runs) instead of the wave-per-tile one -- same results, test twin                         */
 #define LOB_LN_IDENTITY 0x200 /* OR into `act` of lob_layernorm_act(_bwd)_f32: skip the normalisation and the
                                * affine (nn.Identity in place of nn.LayerNorm: the no-LayerNorm ablation,
                                * 09_sensitivity_analysis.py:190,209); gamma/beta/dgamma/dbeta may be NULL */
@@ -293,7 +295,7 @@ int lob_layernorm_act_f32(const float* in, const float* gamma, const float* beta
                           int remap_T, int remap_B, int remap_Bp,
                           float drop_p, uint64_t seed, void* stream);
 
-/* Fused input projection of the mixed path, H == 128 (input_proj = Linear(C -> H) -> LayerNorm -> GELU -> Dropout,
+/* Fused input projection of the mixed path, H == 128 or 256 (input_proj = Linear(C -> H) -> LayerNorm -> GELU -> Dropout,
  * 04_lstm_model.py:173-178), C <= 64: reads the fp32 windows x[B*T][C] (rows (b,t), 16-byte aligned base) once and writes
  * the bf16 activations out[T*Bp][H] time-major (row t*Bp + b; pad rows b >= B untouched) -- the same numbers, bit for
  * bit, as lob_pad_cast_bf16 + lob_gemm_nt_bf16(bias) + lob_layernorm_act_f32(remap, dropout) in a row.  W: fp32 [H][ldw]

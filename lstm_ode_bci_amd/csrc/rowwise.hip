@@ -1523,6 +1523,151 @@ __global__ __launch_bounds__(512) void attn_ln_bwd_h256_kernel(
     }
 }
 
+// The input projection decomposed by COLUMNS (round 3; width 256, and width 128 as a test twin): a workgroup of
+// WIDTH / 32 waves owns 64 consecutive (b, t) rows; every wave multiplies the whole tile with ITS 32 output columns (4 B
+// fragments, 2 row blocks x 4 k-steps of v_mfma_f32_32x32x16_bf16: 32 accumulator registers instead of 64-128), the fp32
+// pre-activations meet in one shared LDS tile, and the LayerNorm rows are dealt to the waves.  ~100 registers per wave: 16
+// waves per CU instead of 8.  Same instruction, k order, lane assignment and arithmetic as input_proj_ln_kernel and the
+// unfused sequence: bit-identical results.  At width 128 the wave-per-tile kernel above is faster (0.34 against 0.38 ms: four
+// barriers per 64 rows here); at width 256 its accumulators and B fragments (2 x 128 registers) do not fit, this one does.
+template <bool SAVE, int WIDTH>
+__global__ __launch_bounds__(WIDTH * 2) void input_proj_ln2_kernel(
+    const float* __restrict__ x, int C, int Cp, const float* __restrict__ W, int ldw, const float* __restrict__ bias,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ pre, __bf16* __restrict__ xb,
+    __bf16* __restrict__ out, long rows, int T, int Bp, float eps, int act, float drop_p, uint64_t seed) {
+    constexpr int NW = WIDTH / 32, NT = NW * 64;           // waves / threads per workgroup
+    constexpr int LDT = WIDTH + 4;                         // fp32 row stride of the output tile
+    constexpr int LPR = WIDTH == 128 ? 16 : 64, VPL = WIDTH / LPR, GPW = 64 / LPR;    // the unfused LayerNorm kernel's lanes
+    constexpr int RPWAVE = 64 / NW;                        // LayerNorm rows per wave and tile
+    __shared__ __attribute__((aligned(16))) float tile[64 * LDT];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int sub = lane / LPR, sl = lane % LPR;
+    // B fragments of this wave's 32 columns: W[32 w + l31][16 ks + 8 hi + j], zero beyond C
+    ip_bf16x8 wf[4];
+    {
+        const float* wrow = W + (size_t)(32 * w + l31) * ldw;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 16 * ks + 8 * hi + j;
+                wf[ks][j] = (__bf16)(k < C ? wrow[k] : 0.f);
+            }
+    }
+    const float bv = bias ? bias[32 * w + l31] : 0.f;
+    float gm[VPL], bt[VPL];
+    const bool norm = !(act & LOB_LN_IDENTITY);
+    act &= 0xff;
+    if (norm) { ldv<VPL>(gamma + sl * VPL, gm); ldv<VPL>(beta + sl * VPL, bt); }
+    else {
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) { gm[i] = 1.f; bt[i] = 0.f; }
+    }
+    const float invw = 1.0f / (float)WIDTH;
+    const long ntile = (rows + 63) >> 6;
+    const long total = rows * (long)C;
+    const int nch = 16 * C;                                // 16-byte chunks of a full tile (64 rows x C floats)
+    constexpr int CPT = (16 * 64 + NT - 1) / NT;           // chunks per thread (C <= 64)
+    f32x4 pf[CPT];
+    auto fetch = [&](long tl) {
+        const long f0 = tl * 64 * C;
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int ch = tid + NT * i;
+            const long f = f0 + 4L * ch;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ch < nch) {
+                if (f + 4 <= total) v = *reinterpret_cast<const f32x4*>(x + f);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (f + e < total) v[e] = x[f + e];
+                }
+            }
+            pf[i] = v;
+        }
+    };
+    long tl = blockIdx.x;
+    if (tl < ntile) fetch(tl);
+    for (; tl < ntile; tl += gridDim.x) {
+        const long r0 = tl * 64;
+        // ---- 0. the tile's floats, flat, into the block
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int ch = tid + NT * i;
+            if (ch < nch) *reinterpret_cast<f32x4*>(tile + 4 * ch) = pf[i];
+        }
+        if (tl + gridDim.x < ntile) fetch(tl + gridDim.x);
+        __syncthreads();
+        // ---- 1. this wave's 32 columns of the 64 rows
+        f32x16 acc[2];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            ip_bf16x8 af[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 16 * ks + 8 * hi + j;
+                    af[ks][j] = (__bf16)(k < C ? tile[(32 * rb + l31) * C + k] : 0.f);
+                }
+            if (SAVE && w == rb && r0 + 32 * rb + l31 < rows) {          // waves 0 and 1 write the padded bf16 windows
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    if (16 * ks + 8 * hi < Cp)
+                        *reinterpret_cast<ip_bf16x8*>(xb + (size_t)(r0 + 32 * rb + l31) * Cp + 16 * ks + 8 * hi) = af[ks];
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], wf[ks], acc[rb], 0, 0, 0);
+        }
+        __syncthreads();                       // every wave has read the windows: the block now takes the pre-activations
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                tile[(32 * rb + (r & 3) + 8 * (r >> 2) + 4 * hi) * LDT + 32 * w + l31] = acc[rb][r] + bv;
+        __syncthreads();
+        // ---- 2. LayerNorm + activation + dropout of this wave's rows, GPW rows per pass (the unfused kernel's lanes)
+#pragma unroll 2
+        for (int ps = 0; ps < RPWAVE / GPW; ++ps) {
+            const int rt = RPWAVE * w + GPW * ps + sub;
+            const long r = r0 + rt;
+            if (r >= rows) continue;
+            float v[VPL];
+            ldv<VPL>(tile + rt * LDT + VPL * sl, v);
+            if (SAVE) stv<VPL>(pre + (size_t)r * WIDTH + VPL * sl, v);
+            const long bw = r / T;
+            const int orow = (int)(r - bw * T) * Bp + (int)bw;
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) s += v[i];
+            const float mean = norm ? row_sum<LPR>(s) * invw : 0.f;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) { const float dl = v[i] - mean; q = __builtin_fmaf(dl, dl, q); }
+            const float rstd = norm ? rsqrtf(__builtin_fmaf(row_sum<LPR>(q), invw, eps)) : 1.f;
+            float ds[VPL];
+#pragma unroll
+            for (int i = 0; i < VPL; i += 2) {
+                if (drop_p > 0.f) lob_dropout_scale2(seed, (uint64_t)orow * WIDTH + sl * VPL + i, drop_p, ds[i], ds[i + 1]);
+                else { ds[i] = 1.f; ds[i + 1] = 1.f; }
+            }
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                const float o = __builtin_fmaf((v[i] - mean) * rstd, gm[i], bt[i]);
+                v[i] = apply_act(o, act) * ds[i];
+            }
+            stv_bf16<VPL>(out + (size_t)orow * WIDTH + sl * VPL, v);
+        }
+        __syncthreads();                       // the block is free for the next tile's windows
+    }
+}
+
 }  // namespace
 
 extern "C" int lob_dropout_f32(const float* in, float* out, int64_t n, float p, uint64_t seed, void* stream) {
@@ -1632,22 +1777,38 @@ extern "C" int lob_input_proj_ln_bf16(const float* x, int C, const float* W, int
     if (!x || !W || !out || B <= 0 || T <= 0 || Bp < B || C <= 0 || ldw < C) return LOB_E_ARG;
     if (!(act & LOB_LN_IDENTITY) && (!gamma || !beta)) return LOB_E_ARG;
     if ((pre == nullptr) != (xb == nullptr)) return LOB_E_ARG;
-    if (H != 128 || C > 64 || (xb && (Cp < C || Cp > 64 || (Cp & 7)))) return LOB_E_SHAPE;
+    if ((H != 128 && H != 256) || C > 64 || (xb && (Cp < C || Cp > 64 || (Cp & 7)))) return LOB_E_SHAPE;
     if (drop_p < 0.f || drop_p >= 1.f) return LOB_E_ARG;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(pre) | reinterpret_cast<uintptr_t>(xb) |
          reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15)
         return LOB_E_ALIGN;
     const long rows = (long)B * T;
+    __bf16* xbb = reinterpret_cast<__bf16*>(xb);
+    __bf16* outb = reinterpret_cast<__bf16*>(out);
+    // H = 128 runs the wave-per-tile kernel (0.34 against 0.38 ms at B = 4096); LOB_IP_COLWAVE in act selects the
+    // column-decomposed one there as well (test twin).  H = 256: column-decomposed only (0.56 against 0.87 ms unfused)
+    const bool colwave = (act & LOB_IP_COLWAVE) != 0;
+    act &= ~LOB_IP_COLWAVE;
+    if (H == 256 || colwave) {
+        const long nt = (rows + 63) / 64;
+        const int wgs = H == 128 ? 1024 : 512;              // 4 (2) workgroups of 4 (8) waves per CU
+        const int nb2 = (int)(nt < wgs ? nt : wgs);
+#define LOB_IP2(SV, WD) hipLaunchKernelGGL((input_proj_ln2_kernel<SV, WD>), dim3(nb2), dim3(WD * 2), 0, (hipStream_t)stream, x, C, \
+                                           Cp, W, ldw, bias, gamma, beta, pre, xbb, outb, rows, T, Bp, eps, act, drop_p, seed)
+        if (H == 128) { if (pre) LOB_IP2(true, 128); else LOB_IP2(false, 128); }
+        else          { if (pre) LOB_IP2(true, 256); else LOB_IP2(false, 256); }
+#undef LOB_IP2
+        LOB_CHECK_LAUNCH();
+        return 0;
+    }
     const long ntile = (rows + 31) / 32;
     const int nb = (int)((ntile + 3) / 4 < 512 ? (ntile + 3) / 4 : 512);      // 2 workgroups per CU, persistent waves
     if (pre)
         hipLaunchKernelGGL((input_proj_ln_kernel<true>), dim3(nb), dim3(256), 0, (hipStream_t)stream, x, C, Cp, W, ldw, bias,
-                           gamma, beta, pre, reinterpret_cast<__bf16*>(xb), reinterpret_cast<__bf16*>(out), rows, T, Bp, eps,
-                           act, drop_p, seed);
+                           gamma, beta, pre, xbb, outb, rows, T, Bp, eps, act, drop_p, seed);
     else
         hipLaunchKernelGGL((input_proj_ln_kernel<false>), dim3(nb), dim3(256), 0, (hipStream_t)stream, x, C, Cp, W, ldw, bias,
-                           gamma, beta, pre, reinterpret_cast<__bf16*>(xb), reinterpret_cast<__bf16*>(out), rows, T, Bp, eps,
-                           act, drop_p, seed);
+                           gamma, beta, pre, xbb, outb, rows, T, Bp, eps, act, drop_p, seed);
     LOB_CHECK_LAUNCH();
     return 0;
 }

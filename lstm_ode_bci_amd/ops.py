@@ -373,10 +373,13 @@ FUSE_INPUT_PROJ = True
 
 
 def input_proj_ok(x2d, H, C):
-    return bool(FUSE_INPUT_PROJ) and H == 128 and 0 < C <= 64 and x2d.is_contiguous() and x2d.data_ptr() % 16 == 0
+    return bool(FUSE_INPUT_PROJ) and H in (128, 256) and 0 < C <= 64 and x2d.is_contiguous() and x2d.data_ptr() % 16 == 0
 
 
-def input_proj_ln(x2d, w, b, gamma, beta, B, T, Bp, H, act=ACT_NONE, eps=1e-5, drop_p=0.0, seed=0, save=False):
+IP_COLWAVE = 0x4000      # include/lob.h LOB_IP_COLWAVE
+
+
+def input_proj_ln(x2d, w, b, gamma, beta, B, T, Bp, H, act=ACT_NONE, eps=1e-5, drop_p=0.0, seed=0, save=False, colwave=False):
     """input_proj (04_lstm_model.py:173-178) of the mixed path in one launch: x2d fp32 [B*T, C] rows (b,t) -> bf16
     activations [T*Bp, H] time-major.  save: also returns the fp32 pre-activations [B*T, H] and the bf16 padded windows
     [B*T, Cp] that the backward reads.  Returns (a, pre | None, xb | None)."""
@@ -385,6 +388,8 @@ def input_proj_ln(x2d, w, b, gamma, beta, B, T, Bp, H, act=ACT_NONE, eps=1e-5, d
     assert rows == B * T and w.shape == (H, Cc)
     if gamma is None:
         act = act | LN_IDENTITY
+    if colwave and H == 128:        # H = 128: the column-decomposed kernel (H = 256 always runs it) as the test twin
+        act = act | IP_COLWAVE
     dev = x2d.device
     a = (torch.zeros if Bp != B else torch.empty)((T * Bp, H), device=dev, dtype=torch.bfloat16)
     Cp = (Cc + 7) // 8 * 8

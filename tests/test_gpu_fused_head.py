@@ -32,10 +32,10 @@ def _unfused(ops, x2d, w, b, g, be, B, T, Bp, act, p, seed):
                                    (130, 31, 61)])
 @pytest.mark.parametrize("p", [0.0, 0.3])
 @pytest.mark.parametrize("identity", [False, True])
-def test_fused_input_projection_is_bit_identical_to_the_sequence(dev, B, T, C, p, identity):
+@pytest.mark.parametrize("H", [128, 256])
+def test_fused_input_projection_is_bit_identical_to_the_sequence(dev, B, T, C, p, identity, H):
     from lstm_ode_bci_amd import ops
-    H = 128
-    g = torch.Generator(device=dev).manual_seed(B * 1000 + T)
+    g = torch.Generator(device=dev).manual_seed(B * 1000 + T + H)
     x2d = torch.randn((B * T, C), generator=g, device=dev) * 3.0
     w = torch.randn((H, C), generator=g, device=dev) * 0.2
     b = torch.randn((H,), generator=g, device=dev) * 0.1
@@ -50,19 +50,24 @@ def test_fused_input_projection_is_bit_identical_to_the_sequence(dev, B, T, C, p
     assert torch.equal(a.view(torch.int16), ar.view(torch.int16))
     a2, pre2, xb2 = ops.input_proj_ln(x2d, w, b, gam, bet, B, T, Bp, H, act=ops.ACT_GELU, drop_p=p, seed=1234, save=False)
     assert pre2 is None and xb2 is None and torch.equal(a2.view(torch.int16), a.view(torch.int16))
+    if H == 128:        # the column-decomposed kernel (what H = 256 runs) at width 128: same bits as well
+        a3, pre3, xb3 = ops.input_proj_ln(x2d, w, b, gam, bet, B, T, Bp, H, act=ops.ACT_GELU, drop_p=p, seed=1234, save=True,
+                                          colwave=True)
+        assert torch.equal(a3.view(torch.int16), a.view(torch.int16)) and torch.equal(pre3, pre) and torch.equal(xb3, xb)
     # against float64 from the same bf16-rounded operands (not twin against twin)
     pre64 = x2d.to(torch.bfloat16).double() @ w.to(torch.bfloat16).double().t() + b.double()
     assert (pre.double() - pre64).abs().max().item() < 1e-4 * max(1.0, pre64.abs().max().item())
 
 
-def test_model_outputs_and_gradients_do_not_change_with_the_fused_head(dev):
+@pytest.mark.parametrize("H", [128, 256])
+def test_model_outputs_and_gradients_do_not_change_with_the_fused_head(dev, H):
     from lstm_ode_bci_amd import EnhancedLSTMModel, ops
-    sd = {k: torch.from_numpy(v) for k, v in syn.make_state_dict(61, 128, 3, 2, True).items()}
+    sd = {k: torch.from_numpy(v) for k, v in syn.make_state_dict(61, H, 3, 2, True).items()}
     x, y = syn.make_windows(24, 64, 61, seed=4)
     xt = torch.from_numpy(x).to(dev)
 
     def run(fused, train):
-        m = EnhancedLSTMModel(61, 128, 3, 2, 0.4, True).to(dev)
+        m = EnhancedLSTMModel(61, H, 3, 2, 0.4, True).to(dev)
         m.load_state_dict(sd)
         m.train(train)
         old = ops.FUSE_INPUT_PROJ
@@ -120,7 +125,7 @@ def test_fused_head_refuses_what_it_does_not_cover(dev):
     from lstm_ode_bci_amd import _lib, ops
     x2d = torch.zeros((64, 80), device=dev)
     assert not ops.input_proj_ok(x2d, 128, 80) and not ops.input_proj_ok(x2d[:, :61], 128, 61)     # C > 64; strided rows
-    assert not ops.input_proj_ok(torch.zeros((64, 61), device=dev), 256, 61)
+    assert not ops.input_proj_ok(torch.zeros((64, 61), device=dev), 64, 61)
     L = _lib.lib()
     assert L.lob_input_proj_ln_bf16(None, 61, None, 61, None, None, None, None, None, 64, None, 1, 1, 32, 128, 1e-5, 0, 0.0,
                                     0, None) == -1
