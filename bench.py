@@ -652,15 +652,39 @@ def compact(res):
     return out
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher around it: run the same command line under
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` (one rank per GPU, rendezvous on 127.0.0.1 at a
+    free port) as a CHILD process, pass its stdout (rank 0's one JSON line) and stderr through, return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")               # torch.distributed.run would set 1 and say so on stderr
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
 def main():
     a = parse()
     H = a.hidden
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (fresh child processes; this process has made no
+        # GPU call and never replaces its own image), relay their output and exit with their code
+        raise SystemExit(launch_ranks(a.gpus))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with python -m torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"bench.py: --gpus {a.gpus} does not match WORLD_SIZE={world} of the launcher")
     # LOB_DIST_BACKEND=gloo + LOB_SHARE_GPU=1: rehearsal of the N > 1 code path on a one-GPU box (all ranks on
     # cuda:0, collectives through host memory); the real multi-GPU run uses nccl (= RCCL over xGMI), one GPU each
     backend = os.environ.get("LOB_DIST_BACKEND", "nccl")

@@ -48,3 +48,49 @@ def test_cpu_baseline_leg_runs_and_describes_its_sample():
     assert set(r["table"]) == {"best_n_B32", "best_n_B256", "n1_B32", "n1_B256"}
     assert all(v["iters"] >= 2 for v in r["table"].values()) and r["table"]["n1_B32"]["threads"] == 1
     assert r["n1_value"] > 0
+
+
+def test_plain_multi_gpu_launch_builds_the_distributed_command(monkeypatch):
+    """`python bench.py --gpus N` (no launcher): bench.launch_ranks starts `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N ... bench.py <same flags>` as a child and returns its exit code -- checked here without a GPU by
+    intercepting the child."""
+    import subprocess
+    import bench
+    seen = {}
+
+    class FakeProc:
+        def __init__(self, cmd, env=None, stdout=None, text=None, bufsize=None):
+            seen["cmd"], seen["env"] = cmd, env
+            self.stdout = iter(['{"n_gpus": 4}\n'])
+
+        def wait(self):
+            return 7
+
+    monkeypatch.setattr(subprocess, "Popen", FakeProc)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    rc = bench.launch_ranks(4)
+    assert rc == 7
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_main_dispatches_to_the_launcher_before_any_gpu_call(monkeypatch):
+    import bench
+    import torch
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(bench, "launch_ranks", lambda n: 5)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda *_: (_ for _ in ()).throw(AssertionError("GPU touched")))
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 5
+    # under a launcher whose world size disagrees with --gpus the rank refuses instead of mis-reporting n_gpus
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "does not match" in str(e.value.code)

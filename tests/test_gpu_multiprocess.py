@@ -152,3 +152,38 @@ def test_bench_py_two_ranks_under_torch_distributed_run(tmp_path, mode):
     # whole-job value: both ranks' windows over the slowest rank's time
     assert abs(res["value"] - 2 * 4096 * 2 / (res["ms_per_step"] * 2 * 1e-3)) <= 1e-6 * res["value"]
     assert "cpu_baseline" not in res and "roofline" in res
+
+
+@pytest.mark.parametrize("mode", ["train", "fwd"])
+def test_bench_py_two_ranks_started_plainly(tmp_path, mode):
+    """`python3 bench.py --gpus 2 ...` WITHOUT a launcher around it (the way the driver starts the N = 1
+    bench) must start its own ranks as child processes, relay rank 0's ONE JSON line and return the children's exit code."""
+    import json
+    import math
+    env = dict(os.environ, LOB_DIST_BACKEND="gloo", LOB_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE", "GROUP_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--mode", mode]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 2 and res["warmup"] == 1 and res["scaling"] == "weak"
+    cfg = res["config"]
+    assert cfg["global_batch"] == 2 * cfg["batch_per_gpu"] == 2 * 4096
+    assert cfg["collective"] == ("all_reduce(grads 4.55MB)" if mode == "train" else "all_gather(logits)")
+    assert math.isfinite(res["value"]) and res["value"] > 0
+    assert abs(res["value"] - 2 * 4096 * 2 / (res["ms_per_step"] * 2 * 1e-3)) <= 1e-6 * res["value"]
+
+
+def test_bench_py_plain_launch_relays_a_failing_child(tmp_path):
+    """The launcher's exit code is the children's: a bad flag must not read as success."""
+    env = dict(os.environ, LOB_DIST_BACKEND="no_such_backend", LOB_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
+                        "--warmup", "0", "--no-cpu-baseline"], env=env, cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
