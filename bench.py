@@ -545,16 +545,25 @@ class Leg:
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # HBM bytes per launch from rocprofv3 --pmc
             if os.path.exists(tpath):
                 try:
+                    from lstm_ode_bci_amd import _lib
                     table = json.load(open(tpath))
+                    stamps = table.get("_build_id", {})
+                    have = _lib.lib().lob_build_id().decode()
                     sfx = f"|{precision}|B{B}" + ("" if H == 128 else f"|H{H}")
                     roof["traffic"] = table.get(roof["kernel"] + sfx)
+                    # the table is a separate profiler pass (rocprofv3 --pmc cannot run inside this process): every
+                    # entry carries the build id it was measured on; one from another build is reported, but marked
+                    if roof["traffic"] is not None:
+                        roof["traffic_source"] = "profiles/pmc_traffic.json"
+                        roof["traffic_stale"] = stamps.get(roof["kernel"] + sfx) != have
                     # whole step: HBM bytes of ALL kernels of one step from the same PMC passes (tools/pmc_traffic.py),
-                    # over this run's measured step time
+                    # over this run's measured step time; only when measured on THIS build.  An upper bound: the 2x
+                    # FETCH_SIZE correction (validated on wide coalesced reads) is applied to every kernel of the step
                     sb = table.get("step" + sfx) if (mode == "train" and not self.strict_storage) else None
-                    if sb:
+                    if sb and stamps.get("step" + sfx) == have:
                         gbps = sb / (dt / steps) / 1e9
                         roof["step"] = {"bytes": sb, "achieved": gbps, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
-                                        "bytes_per_window": sb / B}
+                                        "bytes_per_window": sb / B, "note": "upper bound (2x read correction on every kernel)"}
                 except Exception:
                     pass
             res["roofline"] = roof
@@ -609,7 +618,7 @@ def compact(res):
         if not r:
             return None
         out = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "bytes_per_launch",
-                                     "flop_per_launch", "sec_per_launch", "timing", "step") if r.get(k) is not None or k == "traffic"}
+                                     "flop_per_launch", "sec_per_launch", "timing", "step", "traffic_stale") if r.get(k) is not None or k == "traffic"}
         if "all" in r:      # [ms per launch, launches per step, fraction of HBM peak, fraction of its MFMA peak]
             out["all"] = {k: [v["ms"], v["launches_per_step"], v["frac_of_hbm_peak"], v["frac_of_mfma_peak"]]
                           for k, v in r["all"].items()}

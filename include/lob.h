@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LOB_VERSION 204
+#define LOB_VERSION 205
 
 #define LOB_E_ARG   (-1)   /* null pointer / non-positive size                      */
 #define LOB_E_SHAPE (-2)   /* shape not supported by this kernel (see each entry)   */
@@ -48,7 +48,12 @@ extern "C" {
                                * affine (nn.Identity in place of nn.LayerNorm: the no-LayerNorm ablation,
                                * 09_sensitivity_analysis.py:190,209); gamma/beta/dgamma/dbeta may be NULL */
 
+/* The ABI is VERSIONED, not append-only: entry points have gained parameters between versions (e.g. `range` of
+ * lob_gate_gemm_x_f32 / lob_lstm_rec_fwd_f32 and `dattn` of lob_attn_pool_bwd_f32 in 202) and 205 removed two symbols.  A caller
+ * must check, once after loading the library, that it was compiled against the same header -- lob_abi_ok() below, or the
+ * build-id check of the Python loader -- and refuse to call anything otherwise.                                          */
 int lob_version(void);
+#define lob_abi_ok() (lob_version() == LOB_VERSION)
 
 /* Identity of the build: a hash of every csrc source, this header and the compile flags, injected by
  * lstm_ode_bci_amd/build.py (-DLOB_BUILD_ID).  The Python loader compares it with the hash of the sources it
@@ -85,13 +90,12 @@ const char* lob_build_id(void);
 #define LOB_VAR_REC_FEW      17  /* 1: mixed inference forward with fewer than 4 windows skips the padding registers' cell update */
 #define LOB_VAR_GEMM_PP      18  /* bit mask, H=256 mixed step: 1 = dX, 2 = gate GEMM, 4 = weight gradients on the 8-wave
                                   *    ping-pong 256x256x64 kernels (csrc/gemm_pp.hip); 0 bits: the tiled / weight-stationary
-                                  *    twins.  512 = dX on v_mfma_f32_16x16x32_bf16 (default: 1 | 4 | 512).  Diagnostic builds
-                                  *    (garbage results, tools/pp_bench.py): 8 = ring schedule, 16..64 = ablations,
-                                  *    128 / 256 = priority protocol, 1024 / 2048 = operand DMA alone                          */
-#define LOB_VAR_H256_PAIR    19  /* H=256 mixed recurrent forward with a workspace (lob_lstm_rec_fwd_bf16_ws): 1 = the two-workgroup
-                                  *    kernel (W_hh resident, h halves exchanged; csrc/lstm_rec_h256_pair.hip), 0 (default) = the
-                                  *    single-workgroup kernel: the pair kernel measured only 3-6 % faster        */
-#define LOB_VAR_COUNT        20
+                                  *    twins.  512 = dX on v_mfma_f32_16x16x32_bf16 (default: 1 | 4 | 512).  Slower but CORRECT
+                                  *    schedules kept as twins: 8 = ring schedule, 128 / 256 = priority protocol.  The
+                                  *    instantiations that compute garbage (16..64 = ablations, 1024 / 2048 = operand DMA alone,
+                                  *    tools/pp_bench.py) exist only in builds with -DLOB_PP_DIAG; the product library ignores
+                                  *    those bits                                                                                */
+#define LOB_VAR_COUNT        19
 int lob_debug_set_variant(int which, int value);
 int lob_debug_get_variant(int which);
 
@@ -215,18 +219,6 @@ int lob_lstm_dw_bf16(const void* dP, int ldp, const void* X, int ldx, int nx, co
 int lob_lstm_rec_fwd_bf16(void* P, int pg_bf16, const float* Whh, const void* Whh16, float* Y, void* Csave, int c_bf16,
                           void* Y16, void* Yd, float drop_p, uint64_t seed,
                           int T, int Bp, int H, int D, int save, int nvalid, void* stream);
-/* The same with a caller-provided scratch buffer: at H == 256 and Bp % 64 == 0 a workspace of at least
- * lob_rec_pair_ws_bytes(H, Bp, D) bytes (16-byte aligned, contents irrelevant, not shared between launches that may
- * run concurrently) AND LOB_VAR_H256_PAIR = 1 select the two-workgroup kernel: each CU keeps HALF of W_hh resident and the two sides exchange
- * their halves of h every step through the workspace (no per-step weight stream).  Same results up to fp32 rounding of
- * the MFMA shape.  ws == NULL, a short workspace or any other shape: exactly lob_lstm_rec_fwd_bf16.
- * lob_rec_pair_ws_bytes returns 0 where the kernel does not apply.  The first 32-bit word of the workspace is 0 after
- * a good launch; non-zero = an exchange wait ran into its bound (seconds: the partner workgroup never arrived) and
- * the launch's results are invalid -- the caller must check it.                                                       */
-size_t lob_rec_pair_ws_bytes(int H, int Bp, int D);
-int lob_lstm_rec_fwd_bf16_ws(void* P, int pg_bf16, const float* Whh, const void* Whh16, float* Y, void* Csave, int c_bf16,
-                             void* Y16, void* Yd, float drop_p, uint64_t seed,
-                             int T, int Bp, int H, int D, int save, int nvalid, void* ws, size_t ws_bytes, void* stream);
 /*   nvalid: how many of the Bp rows carry windows (rows >= nvalid are padding); 0 = unknown / all.  Only a hint: with
  *   save == 0, bf16 P, H == 128 and nvalid < 4 the padding rows' cell update is skipped and their outputs are zeros.  */
 /*   c_bf16 = 1 (H == 128, 16-row kernels, bf16 saved gates): the cell states saved for BPTT are stored as bf16, in the

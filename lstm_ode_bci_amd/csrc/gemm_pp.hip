@@ -1130,6 +1130,7 @@ __global__ __launch_bounds__(512, 2) void lstm_dw_pp_kernel(DWPPArgs g) {
     }
 }
 
+#ifdef LOB_PP_DIAG
 // Diagnostic: the operand DMA of gemm_nt_pp_kernel ALONE -- same tile walk, same source addresses, same 1-KB
 // global_load_lds_dwordx4 instructions into LDS, but no barriers, no reads, no MFMAs, DEPTH instructions in flight per wave.
 // What the L2 -> LDS path delivers for this traffic mix (A once from HBM and once from L2 / MALL, B from L2) is the floor
@@ -1174,6 +1175,7 @@ __global__ __launch_bounds__(512, 2) void dma_probe_kernel(PPArgs g) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
+#endif
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -1203,20 +1205,28 @@ int lob_gemm_nt_pp(const void* A, int lda, const void* Wt, int ldw, void* C, int
     if (lob_variant(LOB_VAR_GEMM_PP) & 8) hipLaunchKernelGGL(gemm_nt_ring_kernel, dim3((unsigned)pp_grid(M, N)), dim3(512), 0, s, g);
     else {
         const dim3 gr((unsigned)pp_grid(M, N)), bl(512);
-        if (lob_variant(LOB_VAR_GEMM_PP) & 1024) {                 // diagnostic: the operand DMA alone (tools/pp_bench.py dma)
+#ifdef LOB_PP_DIAG      // garbage-result instantiations: diagnostic builds only (tools/h256_ablate.sh, ABL_SRC=gemm_pp ABL_DEF=LOB_PP_DIAG)
+        if (lob_variant(LOB_VAR_GEMM_PP) & 1024) {                 // the operand DMA alone (tools/pp_bench.py dma)
             if (lob_variant(LOB_VAR_GEMM_PP) & 2048) hipLaunchKernelGGL(dma_probe_kernel<24>, gr, bl, 0, s, g);
             else                                     hipLaunchKernelGGL(dma_probe_kernel<8>, gr, bl, 0, s, g);
             LOB_CHECK_LAUNCH();
             return 0;
         }
-        switch ((lob_variant(LOB_VAR_GEMM_PP) >> 4) & 7) {         // diagnostic ablations (tools/pp_bench.py abl)
-            case 1: hipLaunchKernelGGL((gemm_nt_pp_kernel<0, 1>), gr, bl, 0, s, g); break;
-            case 2: hipLaunchKernelGGL((gemm_nt_pp_kernel<0, 2>), gr, bl, 0, s, g); break;
-            case 3: hipLaunchKernelGGL((gemm_nt_pp_kernel<0, 3>), gr, bl, 0, s, g); break;
-            case 4: hipLaunchKernelGGL((gemm_nt_pp_kernel<0, 4>), gr, bl, 0, s, g); break;
-            case 5: hipLaunchKernelGGL((gemm_nt_pp_kernel<0, 5>), gr, bl, 0, s, g); break;
-            case 6: hipLaunchKernelGGL((gemm_nt_pp_kernel<0, 6>), gr, bl, 0, s, g); break;
+#define LOB_PP_ABL_CASES                                                                        \
+            case 1: hipLaunchKernelGGL((gemm_nt_pp_kernel<0, 1>), gr, bl, 0, s, g); break;      \
+            case 2: hipLaunchKernelGGL((gemm_nt_pp_kernel<0, 2>), gr, bl, 0, s, g); break;      \
+            case 3: hipLaunchKernelGGL((gemm_nt_pp_kernel<0, 3>), gr, bl, 0, s, g); break;      \
+            case 4: hipLaunchKernelGGL((gemm_nt_pp_kernel<0, 4>), gr, bl, 0, s, g); break;      \
+            case 5: hipLaunchKernelGGL((gemm_nt_pp_kernel<0, 5>), gr, bl, 0, s, g); break;      \
+            case 6: hipLaunchKernelGGL((gemm_nt_pp_kernel<0, 6>), gr, bl, 0, s, g); break;      \
             case 7: hipLaunchKernelGGL((gemm_nt_pp_kernel<0, 7>), gr, bl, 0, s, g); break;
+        const int abl = (lob_variant(LOB_VAR_GEMM_PP) >> 4) & 7;   // ablations (tools/pp_bench.py abl)
+#else
+#define LOB_PP_ABL_CASES
+        const int abl = 0;      // the product library holds no kernel that computes garbage: bits 16..64 / 1024 / 2048 are ignored
+#endif
+        switch (abl) {
+            LOB_PP_ABL_CASES
             default:
                 if (lob_variant(LOB_VAR_GEMM_PP) & 512) { hipLaunchKernelGGL(gemm_nt_pp16_kernel, gr, bl, 0, s, g); break; }
                 switch ((lob_variant(LOB_VAR_GEMM_PP) >> 7) & 3) {
@@ -1225,6 +1235,7 @@ int lob_gemm_nt_pp(const void* A, int lda, const void* Wt, int ldw, void* C, int
                     default: hipLaunchKernelGGL((gemm_nt_pp_kernel<0>), gr, bl, 0, s, g);
                 }
         }
+#undef LOB_PP_ABL_CASES
     }
     LOB_CHECK_LAUNCH();
     return 0;

@@ -349,8 +349,6 @@ int lob_rec_bwd_bf16_s16(const void* G, int pg_bf16, const void* Csave, int c_bf
 // H = 256: W_hh streamed from L2 (lstm_rec_h256_bf16.hip); bf16 P / saved gates only
 int lob_rec_fwd_h256_bf16(void* P, const void* Whh16, float* Y, void* Csave, int c_bf16, void* Y16, void* Yd, float drop_p,
                           uint64_t seed, int T, int Bp, int D, int save, hipStream_t s);
-int lob_rec_fwd_h256_pair(void* P, const void* Whh16, float* Y, void* Csave, int c_bf16, void* Y16, void* Yd, float drop_p,
-                          uint64_t seed, int T, int Bp, int D, int save, void* ws, size_t ws_bytes, hipStream_t s);
 int lob_rec_bwd_h256_bf16(const void* G, const void* Csave, int c_bf16, const void* WhhT16, const void* dY, int dy_bf16,
                           void* dP, float* dbias, float* dbias2, int T, int Bp, int D, hipStream_t s);
 static bool use_s16() {
@@ -361,14 +359,6 @@ static bool use_s16() {
 extern "C" int lob_lstm_rec_fwd_bf16(void* P, int pg_bf16, const float* Whh, const void* Whh16, float* Y, void* Csavev,
                                      int c_bf16, void* Y16, void* Yd, float drop_p, uint64_t seed,
                                      int T, int Bp, int Hh, int D, int save, int nvalid, void* stream) {
-    return lob_lstm_rec_fwd_bf16_ws(P, pg_bf16, Whh, Whh16, Y, Csavev, c_bf16, Y16, Yd, drop_p, seed, T, Bp, Hh, D, save, nvalid,
-                                    nullptr, 0, stream);
-}
-
-extern "C" int lob_lstm_rec_fwd_bf16_ws(void* P, int pg_bf16, const float* Whh, const void* Whh16, float* Y, void* Csavev,
-                                        int c_bf16, void* Y16, void* Yd, float drop_p, uint64_t seed,
-                                        int T, int Bp, int Hh, int D, int save, int nvalid, void* ws, size_t ws_bytes,
-                                        void* stream) {
     if (!P || !Whh || T <= 0 || Bp <= 0 || (D != 1 && D != 2)) return LOB_E_ARG;
     if (!Y && !Y16) return LOB_E_ARG;
     if (nvalid < 0 || nvalid > Bp) return LOB_E_ARG;
@@ -382,11 +372,6 @@ extern "C" int lob_lstm_rec_fwd_bf16_ws(void* P, int pg_bf16, const float* Whh, 
         if (!Whh16) return LOB_E_ARG;
         if ((reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(Whh16) | reinterpret_cast<uintptr_t>(Csave) |
              reinterpret_cast<uintptr_t>(Y16) | reinterpret_cast<uintptr_t>(Yd)) & 15) return LOB_E_ALIGN;
-        // a workspace of lob_rec_pair_ws_bytes() selects the two-workgroup kernel (W_hh resident, h halves exchanged);
-        // LOB_VAR_H256_PAIR = 0: always the single-workgroup kernel (the twin)
-        if (ws && lob_variant(LOB_VAR_H256_PAIR) != 0 && (Bp % 64) == 0 && ws_bytes >= lob_rec_pair_ws_bytes(256, Bp, D))
-            return lob_rec_fwd_h256_pair(P, Whh16, Y, Csavev, c_bf16, Y16, Yd, drop_p, seed, T, Bp, D, save, ws, ws_bytes,
-                                         (hipStream_t)stream);
         return lob_rec_fwd_h256_bf16(P, Whh16, Y, Csavev, c_bf16, Y16, Yd, drop_p, seed, T, Bp, D, save, (hipStream_t)stream);
     }
     if (Hh != 128 || (Bp % 32)) return LOB_E_SHAPE;

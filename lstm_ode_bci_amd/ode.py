@@ -61,13 +61,11 @@ class CognitiveStateODE:
     def solve(self, initial_state, t_span, n_points=100, method="odeint"):
         """(t (n,), solution (n,3) float64), clipped to [0,1] and row-normalised (06:174-180; 05:137-169).
         ``method='odeint'`` (the default and the only value the reference's scripts ever pass; 06:174 has no such
-        argument at all) integrates with the fixed-step fp64 RK4 kernel, within 1e-6 of LSODA.  ``method='solve_ivp'``
-        (05:157-163: scipy's adaptive RK45 at its default rtol 1e-3 / atol 1e-6) runs the SAME kernel: the system is
-        linear and the kernel's result is the more accurate of the two, so it differs from scipy's RK45 output by that
-        solver's own error (<= 2e-3 measured, tests/test_gpu_parity.py) -- inside the tolerance the reference asked
-        its solver for.  Any other value raises, as scipy's branch would not be reached either."""
-        if method not in ("odeint", "solve_ivp"):
-            raise ValueError(f"CognitiveStateODE.solve: method={method!r} is not one of 'odeint', 'solve_ivp' (05:137-163)")
+        argument at all) integrates with the fixed-step fp64 RK4 kernel, within 1e-6 of LSODA.  ANY other value takes the
+        reference's ``else:`` branch (05:154-163: ``solve_ivp``, scipy's adaptive RK45 at its default rtol 1e-3 / atol
+        1e-6) and runs the SAME kernel here: the system is linear and the kernel's result is the more accurate of the
+        two, so it differs from scipy's RK45 output by that solver's own error (<= 2e-3 measured,
+        tests/test_gpu_parity.py) -- inside the tolerance the reference asked its solver for."""
         t = np.linspace(t_span[0], t_span[1], n_points)
         y0 = torch.as_tensor(np.asarray(initial_state, dtype=np.float64).reshape(1, 3), device=self._dev())
         traj, _, _ = ops.ode_rk4(self._rates(), n_points, t_span[0], t_span[1], self.rk4_substeps,

@@ -256,37 +256,6 @@ def can_fuse_dropout(H, mixed):
     return bool(mixed) and bf16_rec(H, PG_BF16)
 
 
-# The two-workgroup H = 256 forward (csrc/lstm_rec_h256_pair.hip) reports an exchange wait that ran into its bound in
-# a word of its workspace.  That word is copied to pinned host memory behind the launch (4 bytes, no synchronisation) and
-# looked at once its event has passed: at the next recurrent launch, or by pair_check(sync=True).
-_PAIR_PENDING = []
-
-
-def pair_check(sync=False):
-    """Raises LobError if a finished two-workgroup recurrent launch reported a timed-out exchange (its outputs are
-    invalid).  sync=True waits for every pending launch first."""
-    keep = []
-    for ev, host in _PAIR_PENDING:
-        if sync:
-            ev.synchronize()
-        if sync or ev.query():
-            if int(host[0]) != 0:
-                _PAIR_PENDING.clear()
-                raise _lib.LobError("lob_lstm_rec_fwd_bf16_ws: an exchange wait of the two-workgroup H=256 kernel timed out "
-                                    f"(step {int(host[0]) - 1}): the partner workgroup never arrived; results are invalid")
-        else:
-            keep.append((ev, host))
-    _PAIR_PENDING[:] = keep
-
-
-def _pair_track(ws):
-    host = torch.empty((1,), dtype=torch.int32, pin_memory=True)
-    host.copy_(ws[:4].view(torch.int32), non_blocking=True)
-    ev = torch.cuda.Event()
-    ev.record()
-    _PAIR_PENDING.append((ev, host))
-
-
 def lstm_rec_fwd(P, whh, T, Bp, H, D, save, mixed=False, drop_p=0.0, seed=0, want_f32=True, want_bf16=False, nvalid=0,
                  range=None):
     """Runs the persistent recurrent kernel; returns (Y fp32 or None, Csave or None, Y16 or None, Yd or None).
@@ -314,18 +283,9 @@ def lstm_rec_fwd(P, whh, T, Bp, H, D, save, mixed=False, drop_p=0.0, seed=0, wan
             Y16 = torch.empty((T * Bp, D * H), device=dev, dtype=torch.bfloat16)
         if drop_p > 0:
             Yd = torch.empty((T * Bp, D * H), device=dev, dtype=torch.bfloat16)
-        # H == 256, Bp % 64 == 0, LOB_VAR_H256_PAIR = 1 (opt-in: measured 3-6 % faster only): scratch for the two-workgroup
-        # kernel (error word + the h exchange buffer, 128 KB per 64 rows and direction); stream-ordered reuse by the
-        # caching allocator is safe, the kernel is the only user
-        nws = int(_lib.lib().lob_rec_pair_ws_bytes(H, Bp, D)) if (H == 256 and _lib.get_variant("H256_PAIR") != 0) else 0
-        ws = torch.empty((nws,), device=dev, dtype=torch.uint8) if nws else None
-        if _PAIR_PENDING:
-            pair_check()
-        rc = _lib.lib().lob_lstm_rec_fwd_bf16_ws(_ptr(P), int(p16), _ptr(whh), _ptr(whh16), _ptr(Y), _ptr(Cs), int(c16),
-                                                 _ptr(Y16), _ptr(Yd), float(drop_p), C.c_uint64(seed), T, Bp, H, D,
-                                                 1 if save else 0, int(nvalid), _ptr(ws), nws, _stream())
-        if ws is not None and rc == 0:
-            _pair_track(ws)
+        rc = _lib.lib().lob_lstm_rec_fwd_bf16(_ptr(P), int(p16), _ptr(whh), _ptr(whh16), _ptr(Y), _ptr(Cs), int(c16),
+                                              _ptr(Y16), _ptr(Yd), float(drop_p), C.c_uint64(seed), T, Bp, H, D,
+                                              1 if save else 0, int(nvalid), _stream())
     else:
         assert drop_p == 0 and not p16 and not want_bf16
         Y = torch.empty((T * Bp, D * H), device=dev, dtype=torch.float32)

@@ -69,7 +69,7 @@ def sharded_apply(X, fn, group=None):
 
 
 def predict_batch_sharded(integ, X_batch, forecast_steps=20, batch_size=512, gather_trajectories=True, group=None,
-                          overlap=True, local_shard=False):
+                          overlap=True, local_shard=False, use_amp=None, gather_to=None):
     """``LSTMODEIntegration.predict_batch`` over all ranks of the default process group.
     Returns device tensors (trajectories (N,steps,3) f64 | None, probs (N,2) f32, predictions (N,) i64),
     identical on every rank and bit-identical to the single-GPU result.
@@ -83,10 +83,19 @@ def predict_batch_sharded(integ, X_batch, forecast_steps=20, batch_size=512, gat
     chunk c's trajectories -- the only message that is bandwidth-relevant (29.5 MB per rank and 4096 windows at 300
     points; probabilities / decisions are 64 + 32 KB) -- is issued on a side stream behind an event and runs while
     the LSTM kernels of chunk c+1 occupy the compute stream; the compute stream joins the side stream once, at the
-    end.  Probabilities and decisions are collated with one small all-gather each after the last chunk."""
+    end.  Probabilities and decisions are collated with one small all-gather each after the last chunk.
+
+    ``use_amp``: precision of the LSTM pass, as in ``predict_batch`` (None = the object's setting).  ``gather_to=r``: the
+    trajectories -- the only large output (472 MB for 65,536 windows x 300 points) -- are collated on rank r ONLY
+    (``dist.gather``; the reference's consumer runs on one host, 06:409-440) and every other rank returns None for them;
+    probabilities and decisions (96 KB) still reach every rank."""
+    amp = {} if use_amp is None else {"use_amp": use_amp}
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return integ.predict_batch_device(X_batch, forecast_steps, batch_size, want_traj=gather_trajectories)
+        return integ.predict_batch_device(X_batch, forecast_steps, batch_size, want_traj=gather_trajectories, **amp)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if gather_to is not None and not (0 <= int(gather_to) < world):
+        raise ValueError(f"predict_batch_sharded: gather_to={gather_to} is not a rank of this group (world size {world})")
+    keep_traj = gather_to is None or int(gather_to) == rank          # does this rank hold the collated trajectories?
     if local_shard:
         bounds = gather_shard_sizes(len(X_batch), group)
         n = bounds[-1][1]
@@ -96,6 +105,10 @@ def predict_batch_sharded(integ, X_batch, forecast_steps=20, batch_size=512, gat
         bounds = [shard_bounds(n, world, r) for r in range(world)]
         x_off = 0
     lo, hi = bounds[rank]
+    if n == 0:                                                   # nothing anywhere (every rank sees the same n): no collective
+        dev = _traj_proto(integ, X_batch, forecast_steps).device
+        traj0 = torch.empty((0, forecast_steps, 3), dtype=torch.float64, device=dev) if (gather_trajectories and keep_traj) else None
+        return (traj0, torch.empty((0, 2), dtype=torch.float32, device=dev), torch.empty((0,), dtype=torch.int64, device=dev))
     per = max(h - l for l, h in bounds)                          # largest shard: every rank walks the same chunk grid
     chunk = integ._chunk(batch_size, False) if hasattr(integ, "_chunk") else max(int(batch_size), 1)
     traj_full = None
@@ -107,7 +120,7 @@ def predict_batch_sharded(integ, X_batch, forecast_steps=20, batch_size=512, gat
         a, b = min(lo + c, hi), min(lo + c + len_c, hi)
         if b > a:
             traj, probs, pred = integ.predict_batch_device(X_batch[a - x_off:b - x_off], forecast_steps,
-                                                           max(len_c, int(batch_size)), want_traj=gather_trajectories)
+                                                           max(len_c, int(batch_size)), want_traj=gather_trajectories, **amp)
             probs_loc.append(probs)
             pred_loc.append(pred)
         else:
@@ -118,17 +131,25 @@ def predict_batch_sharded(integ, X_batch, forecast_steps=20, batch_size=512, gat
             proto = traj if traj is not None else None
             if proto is None:            # a rank whose shard is exhausted still needs shape/dtype/device of the message
                 proto = _traj_proto(integ, X_batch, forecast_steps)
-            traj_full = proto.new_empty((n,) + tuple(proto.shape[1:]))
+            # the collated result lives on every rank (all-gather) or on rank `gather_to` alone
+            traj_full = proto.new_empty(((n if keep_traj else 0),) + tuple(proto.shape[1:]))
             use_stream = bool(overlap) and traj_full.is_cuda
             if use_stream:
                 comm = torch.cuda.Stream(device=traj_full.device)
         send = traj_full.new_zeros((len_c,) + tuple(traj_full.shape[1:]))
         if traj is not None:
             send[:b - a] = traj
-        recv = traj_full.new_empty((world * len_c,) + tuple(traj_full.shape[1:]))
+        recv = traj_full.new_empty(((world * len_c if keep_traj else 0),) + tuple(traj_full.shape[1:]))
 
         def exchange(send=send, recv=recv, c=c, len_c=len_c):
-            dist.all_gather_into_tensor(recv, send, group=group)
+            if gather_to is None:
+                dist.all_gather_into_tensor(recv, send, group=group)
+            else:
+                dst = dist.get_global_rank(group, int(gather_to)) if group is not None else int(gather_to)
+                parts = [recv[r * len_c:(r + 1) * len_c] for r in range(world)] if keep_traj else None
+                dist.gather(send, gather_list=parts, dst=dst, group=group)
+            if not keep_traj:
+                return
             for r, (l, h) in enumerate(bounds):
                 valid = min(len_c, max(0, (h - l) - c))
                 if valid:
@@ -146,6 +167,8 @@ def predict_batch_sharded(integ, X_batch, forecast_steps=20, batch_size=512, gat
             exchange()
     if comm is not None:
         torch.cuda.current_stream(traj_full.device).wait_stream(comm)
+    if traj_full is not None and not keep_traj:
+        traj_full = None
     if probs_loc:
         probs_l, pred_l = torch.cat(probs_loc, 0), torch.cat(pred_loc, 0)
     else:                                 # fewer windows than ranks: this rank still takes part in the collation

@@ -86,14 +86,3 @@ def test_argument_layer_under_address_sanitizer():
     if r.returncode == 77:
         pytest.skip("ASan runtime not installed")
     assert r.returncode == 0 and "asan_abi_check: ok" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
-
-
-def test_pair_workspace_size_rules():
-    """lob_rec_pair_ws_bytes (include/lob.h): 256-byte header + 128 KB of tagged exchange words per 64 rows and direction;
-    0 wherever the two-workgroup kernel does not apply."""
-    from lstm_ode_bci_amd import _lib
-    L = _lib.lib()
-    assert L.lob_rec_pair_ws_bytes(256, 4096, 2) == 256 + 64 * 2 * (2 * 2 * 2 * 2048 * 8)
-    assert L.lob_rec_pair_ws_bytes(256, 64, 1) == 256 + 2 * 2 * 2 * 2048 * 8
-    assert L.lob_rec_pair_ws_bytes(256, 96, 2) == 0 and L.lob_rec_pair_ws_bytes(128, 4096, 2) == 0
-    assert L.lob_rec_pair_ws_bytes(256, 0, 2) == 0 and L.lob_rec_pair_ws_bytes(256, 64, 3) == 0

@@ -233,6 +233,7 @@ def test_ode_class_solve(dev):
         tr, sr = R45.solve_ivp_rk45(y0_, span, n, syn.FITTED_RATES)
         assert np.array_equal(t5, tr) and np.abs(s5 - sr).max() < 2e-3
         assert np.array_equal(s5, ode.solve(y0_, span, n)[1])
+        assert np.array_equal(s5, ode.solve(y0_, span, n, method="RK45")[1])      # any non-'odeint' string: the else branch (05:157)
     # n_points = 1 and ragged batch sizes
     t1, s1 = ode.solve([1, 1, 2], (0, 5), 1)
     assert np.allclose(s1, [[0.25, 0.25, 0.5]])

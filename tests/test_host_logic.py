@@ -227,10 +227,12 @@ def test_batch_size_is_a_lower_bound_by_default_and_an_upper_bound_on_request():
         integ._chunk(0, False)
 
 
-def test_solve_rejects_unknown_methods():
-    """05:137-163 knows 'odeint' and 'solve_ivp' (both served by the RK4 kernel); anything else raises before any GPU call."""
-    with pytest.raises(ValueError, match="solve_ivp"):
-        CognitiveStateODE().solve([0.6, 0.2, 0.2], (0, 20), 20, method="lsoda")
+def test_solve_method_argument_follows_the_reference_branching():
+    """05:154-163: `if method == 'odeint': ... else: solve_ivp(...)` -- every other string takes the second branch (no
+    ValueError in the reference), and both branches are served by the same RK4 kernel here."""
+    import inspect
+    src = inspect.getsource(CognitiveStateODE.solve)
+    assert "raise ValueError" not in src and 'method="odeint"' in src
 
 
 class _FakeDev:

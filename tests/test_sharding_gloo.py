@@ -96,7 +96,10 @@ class _FakeInteg:
     def _chunk(self, batch_size, respect):
         return max(int(batch_size), self.min_device_chunk)
 
-    def predict_batch_device(self, X, forecast_steps=20, batch_size=512, want_traj=True):
+    seen_amp = ()
+
+    def predict_batch_device(self, X, forecast_steps=20, batch_size=512, want_traj=True, use_amp=None):
+        self.seen_amp = self.seen_amp + (use_amp,)
         s = X.reshape(len(X), -1).double().sum(1)
         traj = s[:, None, None] * torch.arange(1, forecast_steps * 3 + 1, dtype=torch.float64).reshape(1, forecast_steps, 3)
         probs = torch.stack([torch.sigmoid(s), 1 - torch.sigmoid(s)], 1).float()
@@ -125,6 +128,32 @@ def _pbs_worker(rank, world, port, n, q):
                                              local_shard=True)
         ok &= all(a is None or torch.equal(a, b) for a, b in zip(out, ref))
     ok &= sharding.gather_shard_sizes(len(mine)) == [(0, cut), (cut, n)]
+    # gather_to = r: the trajectories are collated on rank r only (dist.gather); probabilities / decisions everywhere
+    for dst in (0, 1):
+        for local in (False, True):
+            out = sharding.predict_batch_sharded(integ, mine if local else X, forecast_steps=5, batch_size=2,
+                                                 local_shard=local, gather_to=dst)
+            ok &= (out[0] is None) == (rank != dst)
+            ok &= all(a is None or torch.equal(a, b) for a, b in zip(out, ref))
+    try:
+        sharding.predict_batch_sharded(integ, X, forecast_steps=5, gather_to=2)
+        ok = False
+    except ValueError:
+        pass
+    # use_amp reaches the per-shard call; unset, the object's own setting decides
+    integ.seen_amp = ()
+    sharding.predict_batch_sharded(integ, X, forecast_steps=5, batch_size=2, use_amp=True)
+    lo_, hi_ = sharding.shard_bounds(n, world, rank)
+    ok &= (len(integ.seen_amp) > 0) == (hi_ > lo_) and all(a is True for a in integ.seen_amp)
+    integ.seen_amp = ()
+    sharding.predict_batch_sharded(integ, X, forecast_steps=5, batch_size=2)
+    ok &= all(a is None for a in integ.seen_amp)
+    # nothing on any rank (local_shard with empty shards everywhere): empty outputs, no 0-row tensor through the chunk loop
+    integ.seen_amp = ()
+    e = sharding.predict_batch_sharded(integ, X[:0], forecast_steps=5, batch_size=2, local_shard=True)
+    ok &= integ.seen_amp == () and tuple(e[0].shape) == (0, 5, 3) and tuple(e[1].shape) == (0, 2) and tuple(e[2].shape) == (0,)
+    e = sharding.predict_batch_sharded(integ, X[:0], forecast_steps=5, batch_size=2)
+    ok &= integ.seen_amp == () and len(e[1]) == 0
     t0 = sharding.dp_broadcast_(torch.tensor([float(rank + 5)]), 0)
     ok &= float(t0) == 5.0
     # control-flow helpers of the data-parallel train loop

@@ -6,7 +6,7 @@ set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p $R/ab
 OBJS=$(ls $R/lstm_ode_bci_amd/build/*.o | grep -v lstm_rec_h256_bf16.o)
-SRC=${ABL_SRC:-lstm_rec_h256_bf16}      # ABL_SRC=lstm_rec_h256_pair ABL_DEF=LOB_ABL_PAIR for the two-workgroup kernel
+SRC=${ABL_SRC:-lstm_rec_h256_bf16}
 DEF=${ABL_DEF:-LOB_ABL_H256}
 OBJS=$(ls $R/lstm_ode_bci_amd/build/*.o | grep -v $SRC.o)
 for k in "$@"; do

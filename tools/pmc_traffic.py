@@ -2,7 +2,7 @@
 """Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (collected SEPARATELY, as
 MI355X_MICROARCH.md prescribes) into per-launch HBM traffic of the bench's hot kernels.
 
-    python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <tag> [B] [H] [nsteps]
+    python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <tag> [B] [H] [nsteps] [precision]
 
 nsteps (steps + warm-up of a `bench.py --no-roofline --no-extra --no-cpu-baseline` pass: nothing but the steps ran under
 the profiler): adds the HBM bytes of ONE WHOLE STEP (all kernels) as `step|<precision>|B<B>[|H<H>]` -- what bench.py
@@ -12,7 +12,10 @@ gfx950 corrections (MI355X_MICROARCH.md §HBM): FETCH_SIZE counts 64 B per 128-B
 half of the bytes of wide coalesced reads (checked here on kernels with a known byte count: the bf16
 recurrent kernels read 2.1 GB of P and report 1.05 M KB), so reads = 2 x FETCH_SIZE; WRITE_SIZE is exact.
 Both counters are in KB.  Writes profiles/<tag>_pmc_summary.csv and updates profiles/pmc_traffic.json,
-which bench.py reads to fill roofline.traffic.
+which bench.py reads to fill roofline.traffic.  Every entry is stamped with the build id of the sources it was measured on
+(`_build_id`: build.source_id() of this tree -- run the tool before touching csrc/ again); bench.py marks an entry whose
+stamp differs from the library it runs as stale and then reports no whole-step figure.  The whole-step sum applies the 2x
+read correction to EVERY kernel, although it was validated on wide coalesced reads only: an upper bound.
 """
 import collections
 import csv
@@ -54,7 +57,11 @@ def main():
     B = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
     H = int(sys.argv[5]) if len(sys.argv) > 5 else 128
     nsteps = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+    precision = sys.argv[7] if len(sys.argv) > 7 else "mixed"
     sfx = "" if H == 128 else f"|H{H}"
+    sys.path.insert(0, ROOT)
+    from lstm_ode_bci_amd import build as _build
+    bid = _build.source_id()
     f, w = load(fetch, "FETCH_SIZE"), load(write, "WRITE_SIZE")
     rows = []
     for k in sorted(set(f) | set(w), key=lambda k: -(sum(f.get(k, [0])) + sum(w.get(k, [0])))):
@@ -69,15 +76,20 @@ def main():
         wr.writerows(rows)
     jpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     table = json.load(open(jpath)) if os.path.exists(jpath) else {}
+    stamps = table.setdefault("_build_id", {})
     for label, alts in (KERNELS if H == 128 else KERNELS_H256).items():
         for prec, sub in alts:
+            if prec != precision:
+                continue
             for r in rows:
                 if sub in r["kernel"]:
                     table[f"{label}|{prec}|B{B}{sfx}"] = r["hbm_bytes_per_launch_corrected"]
+                    stamps[f"{label}|{prec}|B{B}{sfx}"] = bid
                     break
     if nsteps > 0:      # every kernel of the pass, launches x bytes, over the steps that ran
         total = sum((2 * sum(f.get(k, [0.0])) + sum(w.get(k, [0.0]))) * 1024 for k in set(f) | set(w))
-        table[f"step|mixed|B{B}{sfx}"] = int(total / nsteps)
+        table[f"step|{precision}|B{B}{sfx}"] = int(total / nsteps)
+        stamps[f"step|{precision}|B{B}{sfx}"] = bid
     json.dump(table, open(jpath, "w"), indent=1, sort_keys=True)
     print(out)
     print(json.dumps(table, indent=1))

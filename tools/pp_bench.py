@@ -59,7 +59,7 @@ if not want or "dw" in want:
     out = torch.zeros((4 * H, H), device=dev)
     ab("dW_hh one direction", lambda: ops.gemm_tn(dP[Bp:, :4 * H], y[:(T - 1) * Bp, :H], out), 2.0 * rows * H * 4 * H, V)
 
-if "abl" in want:
+if "abl" in want:     # needs a -DLOB_PP_DIAG build of gemm_pp.hip (ABL_SRC=gemm_pp ABL_DEF=LOB_PP_DIAG tools/h256_ablate.sh 1; LOB_LIB_PATH=ab/liblob_abl1.so)
     wt = rnd((512, D * 4 * H), 0.05, torch.bfloat16)
     VA = {"full": dict(GEMM_PP=7)}
     for a, nm in ((1, "no DMA"), (2, "no ds_read"), (4, "no MFMA"), (3, "no DMA+read"), (5, "no DMA+MFMA"), (6, "no read+MFMA"),
@@ -72,7 +72,7 @@ if "prio" in want:
     VP = {"mfma prio1": dict(GEMM_PP=7), "no setprio": dict(GEMM_PP=7 | (1 << 7)), "load prio1": dict(GEMM_PP=7 | (2 << 7))}
     ab("dX N=512 priority", lambda: ops.gemm_nt(dP, wt, mixed=True, out_bf16=True), 2.0 * rows * 512 * D * 4 * H, VP, rounds=6)
 
-if "dma" in want:
+if "dma" in want:     # -DLOB_PP_DIAG build as well
     for N in (512, 256):
         wt = rnd((N, D * 4 * H), 0.05, torch.bfloat16)
         VD = {"full kernel": dict(GEMM_PP=7), "DMA only, 8 in flight/wave": dict(GEMM_PP=7 | 1024),

@@ -48,12 +48,3 @@ dY = rnd((rows, D * H), 1e-3, torch.bfloat16)
 ms_b = timeit(lambda: ops.lstm_rec_bwd(G, Cs, whh, dY, T, Bp, H, D, dp_bf16=True))
 print(f"H={H} lib={os.environ.get('LOB_LIB_PATH', 'default')}: fwd save {ms_f:.3f} ms | save+dropout {ms_d:.3f} | "
       f"inference {ms_i:.3f} | BPTT {ms_b:.3f}", flush=True)
-if H == 256:
-    from lstm_ode_bci_amd import _lib
-    for v in (1, 0):
-        with _lib.variant(H256_PAIR=v):
-            f = timeit(lambda: ops.lstm_rec_fwd(G, whh, T, Bp, H, D, True, **kw), before=lambda: G.copy_(P))
-            fd = timeit(lambda: ops.lstm_rec_fwd(G, whh, T, Bp, H, D, True, drop_p=0.4, seed=5, **kw), before=lambda: G.copy_(P))
-            fi = timeit(lambda: ops.lstm_rec_fwd(P, whh, T, Bp, H, D, False, **kw))
-            ops.pair_check(sync=True)
-        print(f"H256_PAIR={v}: fwd save {f:.3f} ms | save+dropout {fd:.3f} | inference {fi:.3f}", flush=True)
