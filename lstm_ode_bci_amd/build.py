@@ -61,7 +61,7 @@ def isa_checks():
         sys.path.insert(0, tools)
     import isa_check
     return (isa_check.main() + isa_check.check_dma_gemms() + isa_check.check_gate_ws() + isa_check.check_dx_ksplit() +
-            isa_check.check_gemm_pp())
+            isa_check.check_gemm_pp() + isa_check.check_h256_rec())
 
 
 def build(force=False, verbose=True, check_isa=True):

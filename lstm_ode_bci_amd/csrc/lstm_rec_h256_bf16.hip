@@ -37,6 +37,24 @@
 #ifndef LOB_ABL_H256
 #define LOB_ABL_H256 0
 #endif
+// Issue order (round 4).  A wave's vector-memory operations retire IN ORDER (one vmcnt counter for loads, stores and
+// LDS-DMA): a W_hh fragment load (an L2 hit, ~0.2 us) issued behind an HBM load or a store cannot be waited for before
+// that older operation has completed (~1-2 us under load), so every HBM operation issued inside or just in front of the
+// per-step W stream stalls the stream for its own latency.  Both kernels therefore issue their HBM loads at the START of
+// a W-free stretch that is about an HBM latency long:
+//   forward: P of the next step is loaded right AFTER the step's MFMA loop and lands during the cell update (it used to
+//            be loaded in front of the MFMA loop: 2.64 -> 2.29 ms per launch, same-box A/B, bit-identical);
+//   BPTT:    the dgates phase runs in two halves (tile rows r < 8 / r >= 8 of a lane) and the next step's saved gates,
+//            cell states and dY of a half are loaded into the registers that half has just released -- the first half's
+//            in the middle of the dgates phase, the second half's after the MFMA loop (2.84 -> 2.71 ms).
+// Measured and dropped (profiles/r04_h256_issue_order.txt): the forward's bf16 row outputs deferred into the next cell
+// update (slower: their dropout hashes then compete with the cell update instead of covering W latency); touching the
+// next step's HBM lines ahead of the real loads (slower: +25 % line fills through the CU's one memory pipe); refilling
+// the BPTT ring fragment by fragment, 448 instead of 256 MFMA cycles ahead (no change: BPTT is not latency-bound on W).
+// LOB_H256_NQR: register-resident W groups of the forward next to the NQL groups in LDS (fragment ring, see the kernel)
+#ifndef LOB_H256_NQR
+#define LOB_H256_NQR 5
+#endif
 
 namespace {
 
@@ -48,6 +66,12 @@ constexpr int DGB_LD = 1032;       // dgates tile row stride in bf16 (2064 B = 1
 
 __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// compile-time loop: the body sees its index as a constant (register arrays stay registers)
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) { f(std::integral_constant<int, B>{}); static_for<B + 1, E>(f); }
 }
 
 struct Raw { bf16x8 v[8]; };       // one wave's [4 gates][2 q pairs] x 8 elements per lane, unconverted
@@ -109,11 +133,24 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h256_bf16_kernel(
     constexpr int NSQ = 16 - NQL;                      // streamed groups per step
     constexpr int NRB = (NSQ % 4 == 0) ? 4 : 5;        // ring buffers (see above)
     static_assert(NSQ % 4 == 0 || NSQ % 4 == 1, "ring assignment: pos % 4, last position in a fifth buffer");
-    bf16x8 wb[NRB][4];
+    // NQL == 3 (the product configuration): the ring is refilled fragment by fragment -- 8 buffers = 32 registers, 7
+    // fragments = 448 MFMA cycles ahead, instead of 5 x 4 buffers = 80 registers three groups ahead -- and the registers
+    // this frees hold NQR MORE groups of the wave's fragments for the whole launch: 32 of its 64 fragments are streamed
+    // per step instead of 52 (saving forward 2.28 -> 2.13 ms, inference 1.91 -> 1.72).  NQL == 0 keeps the group ring: the
+    // all-streamed twin (LOB_VAR_H256_LDSW = 0)
+    constexpr bool FRAG_RING = NQL == 3;
+    constexpr int NQR = FRAG_RING ? LOB_H256_NQR : 0;
+    constexpr int NSF = (16 - NQL - NQR) * 4;          // streamed fragments per step (fragment ring)
+    static_assert(!FRAG_RING || NSF % 8 == 0, "fragment ring: a fragment must keep its buffer across steps");
+    bf16x8 wb[FRAG_RING ? 2 : NRB][4];
+    bf16x8 wr[NQR > 0 ? NQR : 1][4];
     auto load_w = [&](int q, bf16x8 (&dst)[4]) {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             dst[g] = *reinterpret_cast<const bf16x8*>((wwave + (q * 4 + g) * 512) + w_off);
+    };
+    auto load_wf = [&](int i) {                        // streamed fragment i -> buffer i % 8
+        wb[(i & 7) >> 2][i & 3] = *reinterpret_cast<const bf16x8*>((wwave + ((NQL + NQR) * 4 + i) * 512) + w_off);
     };
     // streamed position p (0 .. NSQ-1) = group NQL + p, ring buffer rb(p)
     auto rb = [](int p) { return (NSQ % 4 == 1 && p == NSQ - 1) ? 4 : (p & 3); };
@@ -123,11 +160,43 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h256_bf16_kernel(
         for (int f = 0; f < NQL * 4; ++f)
             *reinterpret_cast<bf16x8*>(wlw + f * 512) = *reinterpret_cast<const bf16x8*>((wwave + f * 512) + w_off);
     }
-    load_w(NQL + 0, wb[rb(0)]);
-    load_w(NQL + 1, wb[rb(1)]);
-    load_w(NQL + 2, wb[rb(2)]);
+    if constexpr (FRAG_RING) {
+#pragma unroll
+        for (int r = 0; r < NQR; ++r)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                wr[r][g] = *reinterpret_cast<const bf16x8*>((wwave + ((NQL + r) * 4 + g) * 512) + lane * 8);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) load_wf(i);
+    } else {
+        load_w(NQL + 0, wb[rb(0)]);
+        load_w(NQL + 1, wb[rb(1)]);
+        load_w(NQL + 2, wb[rb(2)]);
+    }
     __syncthreads();
 
+    // the bf16 row segments of a finished step (32 rows x 512 B) from its h tile: Y16 = bf16(h), Yd = bf16(dropout(h))
+    auto emit_rows = [&](int buf, int t) {
+        const __bf16* hsrc = hs + buf * 32 * HB_LD;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 512 * i, row = idx >> 5, c8 = (idx & 31) * 8;
+            const bf16x8 hv = *reinterpret_cast<const bf16x8*>(hsrc + row * HB_LD + c8);
+            const size_t o = ((size_t)t * Bp + bt * 32 + row) * DH + d * HH + c8;
+            if (Y16) *reinterpret_cast<bf16x8*>(Y16p + o) = hv;
+            if (DROP) {
+                bf16x8 dv;
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {          // o is a multiple of 8: (o+j, o+j+1) share one hash
+                    float s0, s1;
+                    lob_dropout_scale2(seed, (uint64_t)o + j, drop_p, s0, s1);
+                    dv[j] = (__bf16)((float)hv[j] * s0);
+                    dv[j + 1] = (__bf16)((float)hv[j + 1] * s1);
+                }
+                *reinterpret_cast<bf16x8*>(Yd + o) = dv;
+            }
+        }
+    };
     int cur = 0;
     for (int step = 0; step < T; ++step) {
         const int t = t_first + dt * step;
@@ -138,7 +207,6 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h256_bf16_kernel(
             for (int pq = 0; pq < 2; ++pq)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[g][8 * pq + e] = (float)pn.v[2 * g + pq][e];
-        if (step + 1 < T) load_raw<LOB_NT_P>(pblk + (size_t)(t + dt) * pstep, off8, pn);
         const __bf16* hrow = hs + cur * 32 * HB_LD + l31 * HB_LD + 8 * hi;
         // the weights are loop-invariant, and hipcc would hoist all 64 fragment loads out of the time loop (256
         // registers -> scratch); an opaque no-op on the lane offset ties every step's loads to that step
@@ -152,6 +220,23 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h256_bf16_kernel(
                     acc[g] = mfma_bf16(a, *reinterpret_cast<const bf16x8*>(wlw + (q * 4 + g) * 512), acc[g]);
                 continue;
             }
+            if constexpr (FRAG_RING) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(hrow + 16 * q);
+                if (q < NQL + NQR) {                    // register-resident group
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[g] = mfma_bf16(a, wr[q - NQL][g], acc[g]);
+                    continue;
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int i = (q - NQL - NQR) * 4 + g;
+                    if constexpr (!(LOB_ABL_H256 & 1)) load_wf((i + 7) % NSF);      // into the buffer MFMA i - 1 has just read
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[g] = mfma_bf16(a, wb[(i & 7) >> 2][i & 3], acc[g]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                continue;
+            }
             const int p = q - NQL, pnx = (p + 3) % NSQ; // three streamed groups ahead, cyclic over the steps
             if constexpr (!(LOB_ABL_H256 & 1)) load_w(NQL + pnx, wb[rb(pnx)]);
             __builtin_amdgcn_sched_barrier(0);          // pin the order: issue the prefetch, then consume group q
@@ -160,6 +245,9 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h256_bf16_kernel(
             for (int g = 0; g < 4; ++g) acc[g] = mfma_bf16(a, wb[rb(p)][g], acc[g]);
             __builtin_amdgcn_sched_barrier(0);
         }
+        // ---- the W-free window of the step starts here (the last W loads issued are the prefetch of the next step's
+        // first fragments): P of the next step is requested now and lands during the cell update
+        if (step + 1 < T) load_raw<LOB_NT_P>(pblk + (size_t)(t + dt) * pstep, off8, pn);
         __bf16* hnext = hs + (cur ^ 1) * 32 * HB_LD + 32 * w + l31 + 4 * hi * HB_LD;
         float* yrow = Y + ((size_t)t * Bp + bt * 32) * DH + d * HH + 32 * w;
 #pragma unroll
@@ -212,27 +300,7 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h256_bf16_kernel(
             }
         }
         __syncthreads();
-        if (Y16 || DROP) {       // h_t is complete in hs[cur ^ 1]: emit the bf16 row segments (32 rows x 512 B)
-            const __bf16* hsrc = hs + (cur ^ 1) * 32 * HB_LD;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int idx = tid + 512 * i, row = idx >> 5, c8 = (idx & 31) * 8;
-                const bf16x8 hv = *reinterpret_cast<const bf16x8*>(hsrc + row * HB_LD + c8);
-                const size_t o = ((size_t)t * Bp + bt * 32 + row) * DH + d * HH + c8;
-                if (Y16) *reinterpret_cast<bf16x8*>(Y16p + o) = hv;
-                if (DROP) {
-                    bf16x8 dv;
-#pragma unroll
-                    for (int j = 0; j < 8; j += 2) {          // o is a multiple of 8: (o+j, o+j+1) share one hash
-                        float s0, s1;
-                        lob_dropout_scale2(seed, (uint64_t)o + j, drop_p, s0, s1);
-                        dv[j] = (__bf16)((float)hv[j] * s0);
-                        dv[j + 1] = (__bf16)((float)hv[j + 1] * s1);
-                    }
-                    *reinterpret_cast<bf16x8*>(Yd + o) = dv;
-                }
-            }
-        }
+        if (Y16 || DROP) emit_rows(cur ^ 1, t);        // h_t is complete in hs[cur ^ 1]
         cur ^= 1;
     }
 }
@@ -278,6 +346,9 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_bwd_h256_bf16_kernel(
     struct CRaw16 { bf16x8 v[2]; };
     typedef typename std::conditional<sizeof(CE) == 2, CRaw16, f32x16>::type CS;
     CS ct, cp;
+    // bf16 cell states (the default storage): the two-halves schedule of the header; fp32 cell states (strict storage) keep
+    // whole-step loads in front of the MFMA loop (16 more live registers: the other schedules spill there)
+    constexpr bool HALVES = sizeof(CE) == 2;
     auto cval = [](const CS& cs, int r) -> float {
         if constexpr (sizeof(CE) == 2) return (float)cs.v[r >> 3][r & 7];
         else return cs[r];
@@ -327,6 +398,34 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_bwd_h256_bf16_kernel(
             else                      dy[r] = (float)(dp + ((r & 3) + 8 * (r >> 2)) * DH)[dy_off];
         }
     };
+    // (HALVES) the same loads by halves of the lane's 16 tile elements (pq = r >> 3); t is in range (the caller clamps),
+    // the cell states of an out-of-range step are never used (cp_ok below)
+    auto load_half = [&](int t, int pq) {
+        const __bf16* gq = gwave + (size_t)t * gstep;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if constexpr (LOB_NT_G) graw.v[2 * g + pq] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>((gq + g * 1024 + pq * 512) + off8));
+            else                    graw.v[2 * g + pq] = *reinterpret_cast<const bf16x8*>((gq + g * 1024 + pq * 512) + off8);
+        }
+        const int tc = t + dt;
+        const CE* cq = cwave + (size_t)((tc >= 0 && tc < T) ? tc : t) * cstep;
+        if constexpr (sizeof(CE) == 4) {
+#pragma unroll
+            for (int q = 2 * pq; q < 2 * pq + 2; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>((cq + q * 256) + off4);
+                cp[4 * q] = v[0]; cp[4 * q + 1] = v[1]; cp[4 * q + 2] = v[2]; cp[4 * q + 3] = v[3];
+            }
+        } else {
+            if constexpr (LOB_NT_CDY) cp.v[pq] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>((cq + pq * 512) + off8));
+            else                      cp.v[pq] = *reinterpret_cast<const bf16x8*>((cq + pq * 512) + off8);
+        }
+        const DE* dp = dywave + (size_t)t * Bp * DH;
+#pragma unroll
+        for (int r = 8 * pq; r < 8 * pq + 8; ++r) {
+            if constexpr (LOB_NT_CDY) dy[r] = (float)__builtin_nontemporal_load((dp + ((r & 3) + 8 * (r >> 2)) * DH) + dy_off);
+            else                      dy[r] = (float)(dp + ((r & 3) + 8 * (r >> 2)) * DH)[dy_off];
+        }
+    };
     bf16x8 wb[NRB][4];            // group q = k-steps 4q .. 4q+3 (64 k-steps of 16 gate rows in 16 groups); streamed position
                                   // p = q - NGL lives in buffer p % NRB
     auto load_w = [&](int q, bf16x8 (&dst)[4]) {
@@ -340,16 +439,19 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_bwd_h256_bf16_kernel(
             *reinterpret_cast<bf16x8*>(wlw + f * 512) = *reinterpret_cast<const bf16x8*>((wtwave + f * 512) + wt_off);
     }
     load_c(t_first, ct);
-    load_step(t_first);
+    if constexpr (HALVES) { load_half(t_first, 0); load_half(t_first, 1); }
+    else load_step(t_first);
 #pragma unroll
     for (int a = 0; a < NAH; ++a) load_w(NGL + a, wb[a % NRB]);
 
     for (int step = 0; step < T; ++step) {
         const int t = t_first + dt * step;
         __bf16* dgw = dgs + 32 * w + l31 + 4 * hi * DGB_LD;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int g8 = r >> 3, e8 = r & 7;     // element r of the 32x32 block = q pair r>>3, position r&7
+        const int tcp = t + dt;
+        const bool cp_ok = tcp >= 0 && tcp < T;            // (HALVES) c of the step before the first one is zero
+        auto dgate_elem = [&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            constexpr int g8 = r >> 3, e8 = r & 7;     // element r of the 32x32 block = q pair r>>3, position r&7
             const float ig = (float)graw.v[0 + g8][e8], fg = (float)graw.v[2 + g8][e8];
             const float gg = (float)graw.v[4 + g8][e8], og = (float)graw.v[6 + g8][e8];
             const float dh = dy[r] + dhrec[r];
@@ -357,14 +459,47 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_bwd_h256_bf16_kernel(
             const float dc = dcarry[r] + dh * og * (1.f - tc * tc);
             dcarry[r] = dc * fg;
             __bf16* p = dgw + ((r & 3) + 8 * (r >> 2)) * DGB_LD;
-            const float v0 = dc * gg * ig * (1.f - ig), v1 = dc * cval(cp, r) * fg * (1.f - fg);
+            const float cpv = (HALVES && !cp_ok) ? 0.f : cval(cp, r);
+            const float v0 = dc * gg * ig * (1.f - ig), v1 = dc * cpv * fg * (1.f - fg);
             const float v2 = dc * ig * (1.f - gg * gg), v3 = dh * tc * og * (1.f - og);
             p[0 * HH] = (__bf16)v0; p[1 * HH] = (__bf16)v1; p[2 * HH] = (__bf16)v2; p[3 * HH] = (__bf16)v3;
             dbsum[0] += v0; dbsum[1] += v1; dbsum[2] += v2; dbsum[3] += v3;
+        };
+        if constexpr (HALVES) {
+            const int tn = step + 1 < T ? t + dt : t;      // clamped: the last step re-reads its own lines, unused
+            static_for<0, 8>(dgate_elem);
+            if constexpr (sizeof(CE) == 2) ct.v[0] = cp.v[0];
+            else {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) ct[r] = cp[r];
+            }
+            load_half(tn, 0);
+            static_for<8, 16>(dgate_elem);
+            if constexpr (sizeof(CE) == 2) ct.v[1] = cp.v[1];
+            else {
+#pragma unroll
+                for (int r = 8; r < 16; ++r) ct[r] = cp[r];
+            }
+        } else {          // the plain loop (this form, not the lambda, is what hipcc allocates without spills at fp32 cell states)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int g8 = r >> 3, e8 = r & 7;
+                const float ig = (float)graw.v[0 + g8][e8], fg = (float)graw.v[2 + g8][e8];
+                const float gg = (float)graw.v[4 + g8][e8], og = (float)graw.v[6 + g8][e8];
+                const float dh = dy[r] + dhrec[r];
+                const float tc = (LOB_ABL_H256 & 2) ? cval(ct, r) * 0.5f : fast_tanh(cval(ct, r));
+                const float dc = dcarry[r] + dh * og * (1.f - tc * tc);
+                dcarry[r] = dc * fg;
+                __bf16* p = dgw + ((r & 3) + 8 * (r >> 2)) * DGB_LD;
+                const float v0 = dc * gg * ig * (1.f - ig), v1 = dc * cval(cp, r) * fg * (1.f - fg);
+                const float v2 = dc * ig * (1.f - gg * gg), v3 = dh * tc * og * (1.f - og);
+                p[0 * HH] = (__bf16)v0; p[1 * HH] = (__bf16)v1; p[2 * HH] = (__bf16)v2; p[3 * HH] = (__bf16)v3;
+                dbsum[0] += v0; dbsum[1] += v1; dbsum[2] += v2; dbsum[3] += v3;
+            }
+            ct = cp;
         }
-        ct = cp;
         __syncthreads();
-        if (step + 1 < T) load_step(t + dt);
+        if constexpr (!HALVES) { if (step + 1 < T) load_step(t + dt); }
 #pragma unroll
         for (int r = 0; r < 16; ++r) dhrec[r] = 0.f;
         const __bf16* arow = dgs + l31 * DGB_LD + 8 * hi;
@@ -386,6 +521,9 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_bwd_h256_bf16_kernel(
                 dhrec = mfma_bf16(*reinterpret_cast<const bf16x8*>(arow + 16 * (4 * q + j)), wb[p % NRB][j], dhrec);
             __builtin_amdgcn_sched_barrier(0);
         }
+        // the W-free stretch (dP stores, barrier, the first half of the next dgates phase) starts here.  No branch around
+        // these loads: a block boundary at this point costs ~25 registers (the last step re-reads its own lines, unused)
+        if constexpr (HALVES) load_half(step + 1 < T ? t + dt : t, 1);
         // ---- the bf16 tile IS the dP image: 32 rows x 2 KB; 128 lanes x 16 B per row, 4 rows per pass
         __bf16* dpb = dP + ((size_t)t * Bp + bt * 32) * D4H + d * 4 * HH;
 #pragma unroll

@@ -245,6 +245,65 @@ def check_gemm_pp(path=None):
     return problems
 
 
+def check_h256_rec(path=None):
+    """The H = 256 recurrent kernels (lstm_rec_h256_bf16.hip) sit at 244-256 registers; their schedule depends on what
+    must stay true of the compiled code (round 4):
+    * no scratch (spill) traffic in any instantiation -- a spill reload is a vector-memory operation in the same in-order
+      queue as the W stream;
+    * product forward (NQL = 3): between the step's first and last MFMA only W-fragment loads are issued (16-B loads; the
+      P loads of the next step -- also 16 B -- come after the last MFMA), and the ring's waits in that stretch are counted
+      (`vmcnt(N)`, N >= 6), never `vmcnt(0)`;
+    * product BPTT (bf16 cell states): no branch between the last MFMA of a step and its dP stores (a block boundary
+      there cost ~25 registers and spilled)."""
+    src = os.path.join(ROOT, "lstm_ode_bci_amd", "csrc", "lstm_rec_h256_bf16.hip")
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    out = path or os.path.join(tempfile.mkdtemp(prefix="lob_isa_"), "h256.s")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"),
+                    "-I", os.path.dirname(src), "-S", "--cuda-device-only", src, "-o", out],
+                   check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    text = open(out).read()
+    lines = text.split("\n")
+    problems = []
+    names = sorted(set(re.findall(r"^(_ZN\S*lstm_rec_(?:fwd|bwd)_h256_bf16_kernel\S*):", text, re.M)))
+    if len(names) < 20:
+        problems.append(f"lstm_rec_h256_bf16: only {len(names)} kernels found (file changed?)")
+    for n in names:
+        body = _function(lines, re.escape(n[3:]))
+        if any("scratch_" in l for l in body):
+            problems.append(f"{n}: scratch (spill) traffic")
+    # product forward: saving, bf16 outputs, dropout, bf16 cell states, NQL = 3
+    for pat in ("lstm_rec_fwd_h256_bf16_kernelILb1ELb0ELb1ELb1EDF16bLi3E", "lstm_rec_fwd_h256_bf16_kernelILb0ELb0ELb1ELb0EfLi3E"):
+        body = [l.strip() for l in _function(lines, pat)]
+        mf = [i for i, l in enumerate(body) if l.startswith("v_mfma")]
+        if len(mf) != 64:
+            problems.append(f"{pat}: {len(mf)} MFMAs in the step, expected 64")
+            continue
+        seg = body[mf[0]:mf[-1] + 1]
+        nload = sum(1 for l in seg if l.startswith("global_load_dwordx4"))
+        if nload != 32:
+            problems.append(f"{pat}: {nload} 16-byte loads between the first and the last MFMA, expected the 32 streamed W fragments")
+        if any(l.startswith(("global_store", "global_load_ushort", "global_load_dword ")) for l in seg):
+            problems.append(f"{pat}: an HBM operation inside the MFMA loop (in-order retirement stalls the W stream)")
+        for l in seg:
+            m = re.match(r"s_waitcnt.*vmcnt\((\d+)\)", l)
+            if m and int(m.group(1)) < 6:
+                problems.append(f"{pat}: '{l}' inside the MFMA loop (the ring drains)")
+        after = body[mf[-1] + 1:mf[-1] + 60]
+        if not any(l.startswith("global_load_dwordx4") for l in after):
+            problems.append(f"{pat}: no P load right after the MFMA loop")
+    pat = "lstm_rec_bwd_h256_bf16_kernelIDF16bDF16bLi2ELi1E"
+    body = [l.strip() for l in _function(lines, pat)]
+    mf = [i for i, l in enumerate(body) if l.startswith("v_mfma")]
+    st = [i for i, l in enumerate(body) if l.startswith("global_store_dwordx4")]
+    if len(mf) != 64 or not st:
+        problems.append(f"{pat}: {len(mf)} MFMAs / {len(st)} dP stores (kernel changed?)")
+    else:
+        first_st = min(i for i in st if i > mf[-1])
+        if any(l.startswith(("s_cbranch", "s_branch")) for l in body[mf[-1]:first_st]):
+            problems.append(f"{pat}: a branch between the MFMA loop and the dP stores")
+    return problems
+
+
 def _inner_loops(body):
     """[(first_line, last_line)] of every loop hipcc annotates: from the first block tagged with the loop's header to the
     last branch that targets one of the loop's own labels."""
