@@ -19,6 +19,14 @@ from .synthetic import RATE_KEYS
 
 _COPY_THREADS = max(4, min(16, (os.cpu_count() or 8)))
 _pool = None
+#: tools/api_probe.py sets this to a list; predict_batch then appends (label, time.perf_counter()) at its phase boundaries
+_probe = None
+
+
+def _stamp(label):
+    if _probe is not None:
+        import time
+        _probe.append((label, time.perf_counter()))
 
 
 def _copy_pool():
@@ -27,6 +35,36 @@ def _copy_pool():
         from concurrent.futures import ThreadPoolExecutor
         _pool = ThreadPoolExecutor(max_workers=_COPY_THREADS, thread_name_prefix="lob-h2d")
     return _pool
+
+
+def _chunk_schedule(n, chunk, ramp):
+    """Sizes of the device chunks of an n-window host array: [ramp, 2 ramp, 4 ramp, ...] up to `chunk`, full chunks, and
+    the remainder split largest-first down to `ramp` (ramp <= 0 or a single chunk: equal chunks, as before round 4)."""
+    if n <= 0:
+        return []
+    if ramp <= 0 or n <= chunk or ramp >= chunk:
+        return [min(chunk, n - i) for i in range(0, n, chunk)]
+    head, sz, left = [], int(ramp), n
+    while sz < chunk and left > 2 * sz:          # keep at least one full-size pass' worth for the body
+        head.append(sz)
+        left -= sz
+        sz *= 2
+    body = [chunk] * (left // chunk)
+    left -= chunk * len(body)
+    if body and left and left < ramp:            # a sliver: give it to the last full chunk's successor as is
+        tail = [left]
+    else:
+        tail, sz = [], chunk // 2
+        while left > 0:
+            while sz > left and sz > ramp:
+                sz //= 2
+            take = min(left, max(sz, 1)) if left >= ramp else left
+            tail.append(take)
+            left -= take
+    out = head + body + tail
+    if len(out) > 1 and out[-1] < ramp and out[-2] + out[-1] <= chunk:      # no sliver pass at the end
+        out[-2:] = [out[-2] + out[-1]]
+    return out
 
 
 class LSTMODEIntegration:
@@ -42,6 +80,12 @@ class LSTMODEIntegration:
     #: <= 1e-5.  Left at ``None`` the calls run fp32 and say so ONCE (``warnings.warn``), naming the switch -- a
     #: maintainer who only swaps the import should learn that the reference's own GPU setting is the other one.
     use_amp = None
+    #: first device chunk of a multi-chunk host-array call (``predict_batch`` / ``predict_batch_device`` with numpy input):
+    #: the chunks grow ramp, 2 ramp, ... up to the device chunk and shrink again at the end, so that the pipeline's fill
+    #: (first upload) and drain (last download) are those of a small chunk.  0 = equal chunks.
+    ramp_chunk = 1024
+    #: windows per staging piece of an upload (page-locked copy of piece j+1 overlaps the H2D of piece j)
+    stage_piece = 1024
     _warned_fp32_default = False
 
     def __init__(self, lstm_model, ode_model, coupling_strength=0.5):
@@ -189,23 +233,37 @@ class LSTMODEIntegration:
         copy_stream, stage, dbuf = self._h2d_stream, self._h2d_stage, self._h2d_dbuf
         torch.cuda.current_stream(dev).synchronize()      # a previous call's kernels may still read dbuf
         done = [None, None]          # events: device buffer b may be overwritten (its consumer kernels finished)
-        starts = list(range(0, n, chunk))
+        # Chunk schedule.  With several chunks per call what the caller waits for beyond the kernels is the pipeline's FILL
+        # (staging + H2D of the first chunk: 2.2 + 4.4 ms for 4096 windows, tools/api_probe.py) and its DRAIN (download +
+        # host copy of the last chunk's results): the first chunks are therefore small and double in size -- each one's
+        # upload (1.6 us per window) fits under its predecessor's kernels (2.7-3.1 us per window) -- and what remains after
+        # the last full chunk is split the same way in reverse.  Every window's result is independent of the chunking.
+        sizes = _chunk_schedule(n, chunk, self.ramp_chunk)
+        starts = [0]
+        for sz in sizes[:-1]:
+            starts.append(starts[-1] + sz)
 
         pool = _copy_pool()
+        piece = max(int(self.stage_piece), 1)      # staging granule: the H2D of a piece runs while the next piece is staged
 
         def upload(k):
             b, i = k & 1, starts[k]
-            m = min(chunk, n - i)
+            m = sizes[k]
             # host-side cast + copy into pinned memory (float64 .npz arrays: half the PCIe bytes, 04:346), sliced
             # over a few threads (numpy releases the GIL in copyto; one thread moves only ~5 GB/s)
             dst = stage[b].numpy()
-            step = max(1, (m + _COPY_THREADS - 1) // _COPY_THREADS)
-            list(pool.map(lambda s: np.copyto(dst[s:min(m, s + step)], X_batch[i + s:i + min(m, s + step)],
-                                              casting="same_kind"), range(0, m, step)))
             with torch.cuda.stream(copy_stream):
                 if done[b] is not None:
                     copy_stream.wait_event(done[b])
-                dbuf[b][:m].copy_(stage[b][:m], non_blocking=True)
+            for p0 in range(0, m, piece):
+                pm = min(piece, m - p0)
+                step = max(1, (pm + _COPY_THREADS - 1) // _COPY_THREADS)
+                list(pool.map(lambda s: np.copyto(dst[p0 + s:p0 + min(pm, s + step)],
+                                                  X_batch[i + p0 + s:i + p0 + min(pm, s + step)], casting="same_kind"),
+                              range(0, pm, step)))
+                with torch.cuda.stream(copy_stream):
+                    dbuf[b][p0:p0 + pm].copy_(stage[b][p0:p0 + pm], non_blocking=True)
+            with torch.cuda.stream(copy_stream):
                 ev = torch.cuda.Event()
                 ev.record(copy_stream)
             return ev, m
@@ -241,6 +299,7 @@ class LSTMODEIntegration:
                                                           respect_batch_size=respect_batch_size)
             self.ode_model.params = self.base_params.copy()
             return traj.cpu().numpy(), probs.cpu().numpy(), pred.cpu().numpy()
+        _stamp("enter")
         chunk = self._chunk(batch_size, respect_batch_size)
         self.lstm_model.eval()
         dev = self._device()
@@ -262,19 +321,24 @@ class LSTMODEIntegration:
         def drain(p):
             """Chunk p's results: page-locked staging -> the returned arrays (sliced over the copy threads)."""
             i0, m, b, ev, _keep = p
+            _stamp("drain: wait for the download")
             ev.synchronize()
+            _stamp("drain: host copy")
             st, sp, sd = (t.numpy() for t in stage[b])
             step = max(1, (m + _COPY_THREADS - 1) // _COPY_THREADS)
             list(pool.map(lambda s0: np.copyto(traj[i0 + s0:i0 + min(m, s0 + step)], st[s0:min(m, s0 + step)]),
                           range(0, m, step)))
             probs[i0:i0 + m] = sp[:m]
             pred[i0:i0 + m] = sd[:m]
+            _stamp("drain: done")
 
         amp = self._resolve_amp(use_amp)
         with torch.no_grad(), ops.on_device(dev):
             main = torch.cuda.current_stream(dev)
             pending, i0, k = None, 0, 0
+            _stamp("buffers ready")
             for Xc in self._device_chunks(X_batch, n, chunk, dev):
+                _stamp("chunk uploaded (enqueued)")
                 m = Xc.shape[0]
                 probs_d, _ = self._probs_device(Xc, amp)
                 traj_d, _, pred_d = ops.ode_rk4(self._base_rates(), steps, 0.0, float(steps), self._substeps(),
@@ -297,7 +361,9 @@ class LSTMODEIntegration:
                 pending = (i0, m, b, ev, (traj_d, probs_d, pred_d))
                 i0 += m
                 k += 1
+            _stamp("all chunks enqueued")
             if pending is not None:
                 drain(pending)
         self.ode_model.params = self.base_params.copy()
+        _stamp("return")
         return traj, probs, pred

@@ -339,3 +339,20 @@ def test_model_with_attached_optimizer_state_stays_picklable():
     assert len(pickle.dumps(m)) > 0 and not hasattr(m, "_lob_grad_sink")
     del opt
     assert training.grad_sink_of(m) is None
+
+
+def test_chunk_schedule_of_host_array_calls():
+    """predict_batch on a host array: the device chunks ramp up (fill of the upload pipeline = a small chunk's), full chunks
+    follow, the remainder ramps down (drain = a small chunk's); every schedule covers exactly n windows in chunks the
+    staging buffers can hold; one-chunk calls, ramp 0 and respect_batch_size-style small chunks keep equal chunks."""
+    import random
+    from lstm_ode_bci_amd.integration import _chunk_schedule as cs
+    assert cs(12288, 4096, 1024) == [1024, 2048, 4096, 4096, 1024]
+    assert cs(4096, 4096, 1024) == [4096] and cs(100, 4096, 1024) == [100] and cs(0, 4096, 1024) == []
+    assert cs(4097, 4096, 1024) == [1024, 2048, 1025]                      # no sliver pass at the end
+    assert cs(12288, 4096, 0) == [4096, 4096, 4096] and cs(3000, 512, 1024) == [512] * 5 + [440]
+    rnd = random.Random(7)
+    for _ in range(5000):
+        n, c, r = rnd.randint(1, 70000), rnd.choice([512, 1000, 4096, 8192]), rnd.choice([0, 256, 1024, 5000])
+        s = cs(n, c, r)
+        assert sum(s) == n and all(0 < x <= c for x in s), (n, c, r, s)
