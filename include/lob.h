@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LOB_VERSION 205
+#define LOB_VERSION 206
 
 #define LOB_E_ARG   (-1)   /* null pointer / non-positive size                      */
 #define LOB_E_SHAPE (-2)   /* shape not supported by this kernel (see each entry)   */
@@ -109,11 +109,23 @@ int lob_debug_get_variant(int which);
 int lob_gemm_nt_f32(const float* A, int lda, const float* W, int ldw, const float* bias,
                     float* C, int ldc, int M, int N, int K, int act, void* stream);
 
+/* The same product with every fp32 multiply carried as a two-way fp16 split on the 16-bit matrix pipe (22-bit products,
+ * fp32 accumulate; as lob_gate_gemm_x_f32's default arithmetic): the backward GEMMs of the fp32 training step
+ * (dX = dP W_ih, 04_lstm_model.py:490).  amax_a / amax_w: DEVICE floats, upper bounds of max|A| / max|W| (power-of-two
+ * pre-scales are derived from them; lob_lstm_rec_bwd_f32_x produces the one of dP).  No bias / activation.  16-B aligned
+ * operands, lda % 4 == ldw % 4 == 0, K % 32 == 0, K >= 128, N <= 2048; anything else LOB_E_SHAPE.                        */
+int lob_gemm_nt_f32_split(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
+                          const float* amax_a, const float* amax_w, void* stream);
+
 /* C[M,N] (+)= A[Kc,M]^T * B[Kc,N]  (contraction over the leading/row index; weight
  * gradients dW = dY^T X).  Split over Kc across workgroups, fp32 atomics into C, so C
  * must be zeroed (or hold the value to accumulate into) before the call.             */
 int lob_gemm_tn_f32(const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                     int M, int N, int Kc, void* stream);
+/* lob_gemm_tn_f32 with two-way fp16 split products (see lob_gemm_nt_f32_split): dW = dP^T X of the fp32 training step.
+ * 16-B aligned operands, lda % 4 == ldb % 4 == 0, M % 4 == N % 4 == 0; anything else LOB_E_SHAPE.                      */
+int lob_gemm_tn_f32_split(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int Kc,
+                          const float* amax_a, const float* amax_b, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Input-side gate GEMM of one LSTM layer, both directions at once:
@@ -166,6 +178,14 @@ int lob_lstm_uses_fragment_layout(int H);
 int lob_lstm_rec_bwd_f32(const float* G, const float* Csave, const float* Whh,
                          const float* dY, void* dP, int dp_bf16, float* dbias,
                          int T, int Bp, int H, int D, void* stream);
+/* The same on the fp32 path's fp16-split arithmetic (two-way operand splits on the 16-bit matrix pipe, 22-bit products,
+ * fp32 accumulate; the dgates' pre-scale is re-derived from each tile every step): H == 128, Bp % 32 == 0 and
+ * LOB_VAR_F32_SPLIT != 0, else LOB_E_SHAPE (keep lob_lstm_rec_bwd_f32).  amax_out (may be NULL): a ZEROED device float that
+ * receives max|dP| of the launch -- the pre-scale input of lob_gemm_nt_f32_split / lob_gemm_tn_f32_split on dP.
+ * range (may be NULL): D device floats, max|W_hh| per direction (LOB_PREP_ABSMAX).                                      */
+int lob_lstm_rec_bwd_f32_x(const float* G, const float* Csave, const float* Whh, const float* dY, void* dP,
+                           int dp_bf16, float* dbias, float* amax_out, const float* range,
+                           int T, int Bp, int H, int D, void* stream);
 /*   dp_bf16  1: dP is written as bf16 (mixed-precision mode: its consumers are bf16 MFMA GEMMs)
  *   dbias    [D*4H] bias gradient, accumulated in-kernel with fp32 atomics (initialise it); may be
  *            NULL; must be NULL on the generic (H != 128) path -- use lob_colsum_f32/_bf16 there. */

@@ -137,7 +137,8 @@ def _forward_impl(x, ps, cfg, save):
             nxt = Y
         if save:
             sv["layers"].append({"inp": inp, "G": P, "C": Cs, "Y": Y16 if Y16 is not None else Y, "wih": wih,
-                                 "whh": whh, "fused_drop": fuse, "wihT": img.get(("wihT", layer))})
+                                 "whh": whh, "fused_drop": fuse, "wihT": img.get(("wihT", layer)),
+                                 "rec_range": r_rng, "bwd_range": img.get(("bwd_range", layer))})
         inp = nxt
     ln_g, ln_b = next(it), next(it)
     a0w, a0b, a2w, a2b = next(it), next(it), next(it), next(it)

@@ -196,13 +196,24 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad, sink=None):
         # themselves (two destinations); the fp32 kernels add into a temporary that is then added to both slices (the
         # slices hold earlier micro-batches: BPTT cannot add into one and copy to the other)
         two_dst = need_w and sink is not None and mixed and ops.bf16_rec(H, lay["G"].dtype == torch.bfloat16)
+        ax_in = ax_h = ax_w = None       # operand ranges of the fp16-split fp32 GEMMs (None: the exact-fp32 / bf16 kernels)
         if two_dst:
             dP, dbias = ops.lstm_rec_bwd(lay["G"], lay["C"], lay["whh"], dY, T, Bp, H, D, dp_bf16=True,
                                          dbias=tgt.span(base + 2, 4, D, (D * 4 * H,)),
                                          dbias2=tgt.span(base + 3, 4, D, (D * 4 * H,)))
         else:
+            # fp32 path, H = 128: BPTT and the three GEMMs on dP carry their fp32 products as two-way fp16 splits (as the
+            # forward's gate GEMMs do); the BPTT kernel reports max|dP|, the other operands' ranges come from the forward
+            br = lay.get("bwd_range")
+            split = bool(not mixed and br is not None and lay["G"].dtype == torch.float32 and dY.dtype == torch.float32
+                         and ops.f32_split_bwd_ok(H, Bp))
+            amax_dp = zeros((1,)) if split else None
             dP, dbias = ops.lstm_rec_bwd(lay["G"], lay["C"], lay["whh"], dY, T, Bp, H, D, dp_bf16=mixed,
-                                         dbias=zeros((D * 4 * H,)))
+                                         dbias=zeros((D * 4 * H,)), amax_out=amax_dp,
+                                         range=lay.get("rec_range") if split else None)
+            if split:
+                ax_in = (amax_dp, br[0]) if br[0] is not None else None       # dW_ih = dP^T x: x bounded by the LayerNorm / |h|
+                ax_h, ax_w = (amax_dp, br[2]), (amax_dp, br[1])
         inp, Y, wih = lay["inp"], lay["Y"], lay["wih"]
         fused_dw = need_w and ops.can_fuse_dw(dP, inp, Y, T, Bp, H, D)
         if fused_dw:     # one contiguous target over both directions (the sink lays the two directions out side by side)
@@ -210,7 +221,7 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad, sink=None):
                                                                         tgt.span(base + 1, 4, D, (D, 4 * H, H))))
         elif need_w:
             dwih = tgt.span(base, 4, D, wih.shape)
-            ops.gemm_tn(dP, inp, dwih, mixed=mixed)
+            ops.gemm_tn(dP, inp, dwih, mixed=mixed, amax=ax_in)
         if need_w and sink is not None and not two_dst:
             tgt.span(base + 2, 4, D, dbias.shape).add_(dbias)
             tgt.span(base + 3, 4, D, dbias.shape).add_(dbias)
@@ -223,9 +234,9 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad, sink=None):
                 a_sl = dP[:, d * 4 * H:(d + 1) * 4 * H]
                 y_sl = Y[:, d * H:(d + 1) * H]
                 if d == 0:      # h_prev(t) = h(t-1)
-                    ops.gemm_tn(a_sl[Bp:], y_sl[:(T - 1) * Bp], dwhh, mixed=mixed)
+                    ops.gemm_tn(a_sl[Bp:], y_sl[:(T - 1) * Bp], dwhh, mixed=mixed, amax=ax_h)
                 else:           # reverse direction: h_prev(t) = h(t+1)
-                    ops.gemm_tn(a_sl[:(T - 1) * Bp], y_sl[Bp:], dwhh, mixed=mixed)
+                    ops.gemm_tn(a_sl[:(T - 1) * Bp], y_sl[Bp:], dwhh, mixed=mixed, amax=ax_h)
             if sink is not None:
                 continue
             g[base + 4 * d + 0] = dwih[d * 4 * H:(d + 1) * 4 * H]
@@ -245,7 +256,7 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad, sink=None):
         # the consumer of a bf16 dX: the BPTT kernel of the layer below, or (layer 0) the projection LayerNorm backward
         dx16 = carry16 and want16 and (layer > 0 or width_ok(sv["pre"].shape[1]))
         dY = ops.gemm_nt(dP, wt, mixed=mixed, drop_p=p_lstm if below_fused else 0.0,
-                         seed=_seed(seed, 10 + layer - 1), out_bf16=dx16)
+                         seed=_seed(seed, 10 + layer - 1), out_bf16=dx16, amax=ax_w)
         del dP
 
     # ---- input projection: Linear -> LayerNorm -> GELU -> Dropout (04:173-178)

@@ -23,7 +23,34 @@ struct GemmNT {
     int lda, ldw, ldc, M, N, K, act, accumulate;
     // fragment epilogue (gate pre-activations): N = D*4H, M = T*Bp
     int T, Bp, H, D;
+    // SPLIT kernels: device floats, an upper bound of |A| and of |W| (the operands' power-of-two pre-scales derive from them)
+    const float* amax_a; const float* amax_w;
 };
+
+// ---- fp32 products on the 16-bit matrix pipe (round 4: the backward GEMMs of the fp32 path) ---------------------------
+// As gate_gemm_ws_split.hip / lstm_rec_f32_split.hip: every fp32 operand x is carried as hi = fp16(s), lo = fp16((s - hi) 2^11),
+// s = x 2^k with k from the tensor's |max| (lob_split_scale: both halves stay inside fp16's normal range for any finite
+// operand); x y = r_hh hi hi + r_sm (hi lo + lo hi), the two groups in SEPARATE fp32 accumulators: three
+// v_mfma_f32_32x32x16_f16 (96 cycles) per 16-deep k-step of a 32x32 block instead of eight v_mfma_f32_32x32x2_f32 (512).
+// Here the split happens where the fragments are read: a lane's 16 fp32 values of one k-tile (the same 16 k for the A lane
+// and the B lane of a lane half, in the same order: a dot product does not care which k a slot carries) become two hi
+// and two lo fragments.  The kernels are then bound by that conversion (7 vector operations per element), not by the MFMAs.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr float SPLIT_LO = 2048.f;
+
+__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, float scale, f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float s0 = a[e] * scale, s1 = b[e] * scale;
+        const _Float16 h0 = (_Float16)s0, h1 = (_Float16)s1;
+        hi[e] = h0; hi[4 + e] = h1;
+        lo[e] = (_Float16)((s0 - (float)h0) * SPLIT_LO);
+        lo[4 + e] = (_Float16)((s1 - (float)h1) * SPLIT_LO);
+    }
+}
+__device__ __forceinline__ f32x16 mfma_h(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
 
 template <bool VEC>
 __device__ __forceinline__ void load_tile(const float* __restrict__ G, int ld, int row0, int rows,
@@ -194,7 +221,7 @@ __device__ __forceinline__ void dma_rows8_f32(const float* G, int ld, int row0, 
     __builtin_amdgcn_global_load_lds((gbl_cvoid_f*)(G + (size_t)rr * ld + k0 + c * 4), (lds_void_f*)lds_rows, 16, 0, 0);
 }
 
-template <int EPI>
+template <int EPI, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_dma_f32_kernel(GemmNT g) {
     __shared__ __attribute__((aligned(1024))) float ring[FDS * 2 * FSLOT + 2048];     // 128 KB ring + 8 KB bias
     float* bias_s = ring + FDS * 2 * FSLOT;
@@ -229,12 +256,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_f32_kernel(GemmNT g) {
 
     int it = slot, kt = 0, since_epi = 99;
     f32x16 acc[2][2];
+    f32x16 asm_[SPLIT ? 2 : 1][SPLIT ? 2 : 1];       // SPLIT: the small terms (hi lo + lo hi); acc holds hi hi
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; if (SPLIT) asm_[i][j][r] = 0.f; }
+    float sa = 1.f, sw_ = 1.f, r_hh = 1.f, r_sm = 0.f;
+    if constexpr (SPLIT) {
+        sa = lob_split_scale(*g.amax_a); sw_ = lob_split_scale(*g.amax_w);
+        r_hh = 1.f / (sa * sw_); r_sm = r_hh * (1.f / SPLIT_LO);
+    }
 
     for (int q = 0; q < total; ++q) {
         // younger operations of this wave that may stay in flight: (FDS-2) k-tiles x 8 DMAs, plus the 16
@@ -260,6 +293,26 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_f32_kernel(GemmNT g) {
                 af[i][qq] = *reinterpret_cast<const f32x4*>(as + (64 * wr + 32 * i + r31) * FTK + pc);
                 bf[i][qq] = *reinterpret_cast<const f32x4*>(ws + (64 * wc + 32 * i + r31) * FTK + pc);
             }
+        if constexpr (SPLIT) {
+            f16x8 ah[2][2], al[2][2], bh[2][2], bl[2][2];      // [block][k-step]
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    split8(af[i][2 * ks], af[i][2 * ks + 1], sa, ah[i][ks], al[i][ks]);
+                    split8(bf[i][2 * ks], bf[i][2 * ks + 1], sw_, bh[i][ks], bl[i][ks]);
+                }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = mfma_h(ah[i][ks], bh[j][ks], acc[i][j]);
+                        asm_[i][j] = mfma_h(ah[i][ks], bl[j][ks], asm_[i][j]);
+                        asm_[i][j] = mfma_h(al[i][ks], bh[j][ks], asm_[i][j]);
+                    }
+        } else {
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq)
 #pragma unroll
@@ -269,7 +322,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_f32_kernel(GemmNT g) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = mfma32(af[i][qq][e], bf[j][qq][e], acc[i][j]);
+        }
         if (++kt < nk) continue;
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { acc[i][j][r] = acc[i][j][r] * r_hh + asm_[i][j][r] * r_sm; asm_[i][j][r] = 0.f; }
+        }
 
         kt = 0;
         const int cm0 = ((it / ntn) * 8 + xcd) * BM, cn0 = (it % ntn) * BN;
@@ -281,11 +343,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_f32_kernel(GemmNT g) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int col = cn0 + 64 * wc + 32 * j + (lane & 31);
-                    const float bv = lds_read_f32_opaque(bias_s + (col < 2048 ? col : 0));
+                    const float bv = SPLIT ? 0.f : lds_read_f32_opaque(bias_s + (col < 2048 ? col : 0));
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = cm0 + 64 * wr + 32 * i + acc_row(r, lane);
-                        if (row < g.M && col < g.N) g.C[(size_t)row * g.ldc + col] = apply_act(acc[i][j][r] + bv, g.act);
+                        // (SPLIT: no bias, no activation -- the generic epilogue's transcendentals would be a quarter of this
+                        // kernel's vector work)
+                        const float val = SPLIT ? acc[i][j][r] : apply_act(acc[i][j][r] + bv, g.act);
+                        if (row < g.M && col < g.N) g.C[(size_t)row * g.ldc + col] = val;
                         acc[i][j][r] = 0.f;
                     }
                 }
@@ -328,6 +393,7 @@ constexpr int TLD = 132;   // LDS row stride (floats) of a [32 k][128 m] tile
 struct GemmTN {
     const float* A; const float* B; float* C;
     int lda, ldb, ldc, M, N, Kc, kchunk;
+    const float* amax_a; const float* amax_b;      // SPLIT kernels (see GemmNT)
 };
 
 template <bool VEC>
@@ -360,7 +426,7 @@ __device__ __forceinline__ void store_tile_k(float* S, int tid, const f32x4 (&r)
     for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(S + (kk + 8 * i) * TLD + c4) = r[i];
 }
 
-template <bool VEC>
+template <bool VEC, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN g) {
     __shared__ __attribute__((aligned(16))) float lds[2 * 2 * 32 * TLD];
     float* As = lds;
@@ -380,6 +446,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    f32x16 asm_[SPLIT ? 2 : 1][SPLIT ? 2 : 1];
+    float sa = 1.f, sb = 1.f;
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) asm_[i][j][r] = 0.f;
+        sa = lob_split_scale(*g.amax_a); sb = lob_split_scale(*g.amax_b);
+    }
     f32x4 ra[4], rb[4];
     load_tile_k<VEC>(g.A, g.lda, kbeg, kend, m0, g.M, tid, ra);
     load_tile_k<VEC>(g.B, g.ldb, kbeg, kend, n0, g.N, tid, rb);
@@ -394,6 +471,31 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN g) {
         }
         const float* as = As + buf * 32 * TLD + (16 * (lane >> 5)) * TLD + 64 * wr + (lane & 31);
         const float* bs = Bs + buf * 32 * TLD + (16 * (lane >> 5)) * TLD + 64 * wc + (lane & 31);
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                f16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    f32x4 x0, x1, y0, y1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        x0[e] = as[(8 * ks + e) * TLD + 32 * i]; x1[e] = as[(8 * ks + 4 + e) * TLD + 32 * i];
+                        y0[e] = bs[(8 * ks + e) * TLD + 32 * i]; y1[e] = bs[(8 * ks + 4 + e) * TLD + 32 * i];
+                    }
+                    split8(x0, x1, sa, ah[i], al[i]);
+                    split8(y0, y1, sb, bh[i], bl[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = mfma_h(ah[i], bh[j], acc[i][j]);
+                        asm_[i][j] = mfma_h(ah[i], bl[j], asm_[i][j]);
+                        asm_[i][j] = mfma_h(al[i], bh[j], asm_[i][j]);
+                    }
+            }
+        } else {
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const float a0 = as[s * TLD], a1 = as[s * TLD + 32];
@@ -403,12 +505,22 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN g) {
             acc[1][0] = mfma32(a1, b0, acc[1][0]);
             acc[1][1] = mfma32(a1, b1, acc[1][1]);
         }
+        }
         if (k0 + 32 < kend) {
             store_tile_k(As + (buf ^ 1) * 32 * TLD, tid, ra);
             store_tile_k(Bs + (buf ^ 1) * 32 * TLD, tid, rb);
         }
         __syncthreads();
         buf ^= 1;
+    }
+    if constexpr (SPLIT) {
+        const float r_hh = 1.f / (sa * sb), r_sm = r_hh * (1.f / SPLIT_LO);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] * r_hh + asm_[i][j][r] * r_sm;
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -469,7 +581,8 @@ int launch_nt(const GemmNT& g, int epi, hipStream_t s) {
         long gsz = 512;
         const long tiles = (long)ntm * ntn;
         if (gsz > tiles) gsz = ((tiles + 7) / 8) * 8;
-        if (epi == 0) hipLaunchKernelGGL((gemm_nt_dma_f32_kernel<0>), dim3((unsigned)gsz), dim3(256), 0, s, g);
+        if (epi == 0 && g.amax_a && g.amax_w) hipLaunchKernelGGL((gemm_nt_dma_f32_kernel<0, true>), dim3((unsigned)gsz), dim3(256), 0, s, g);
+        else if (epi == 0) hipLaunchKernelGGL((gemm_nt_dma_f32_kernel<0>), dim3((unsigned)gsz), dim3(256), 0, s, g);
         else          hipLaunchKernelGGL((gemm_nt_dma_f32_kernel<1>), dim3((unsigned)gsz), dim3(256), 0, s, g);
         LOB_CHECK_LAUNCH();
         return 0;
@@ -494,8 +607,26 @@ extern "C" int lob_gemm_nt_f32(const float* A, int lda, const float* W, int ldw,
     if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return LOB_E_ARG;
     if (lda < K || ldw < K || ldc < N) return LOB_E_SHAPE;
     if ((act & 0xff) > LOB_ACT_GELU || act < 0) return LOB_E_ARG;
-    GemmNT g{A, W, bias, C, lda, ldw, ldc, M, N, K, act & 0xff, (act >> 8) & 1, 0, 0, 0, 0};
+    GemmNT g{A, W, bias, C, lda, ldw, ldc, M, N, K, act & 0xff, (act >> 8) & 1, 0, 0, 0, 0, nullptr, nullptr};
     return launch_nt(g, 0, (hipStream_t)stream);
+}
+
+// C = A W^T with the fp32 products carried as two-way fp16 splits (see above).  amax_a / amax_w: device floats >= max|A| /
+// max|W|.  Shapes the LDS-DMA kernel takes (16-B aligned operands, lda % 4 == ldw % 4 == 0, K % 32 == 0, K >= 128,
+// N <= 2048); anything else: LOB_E_SHAPE (the caller keeps lob_gemm_nt_f32).
+extern "C" int lob_gemm_nt_f32_split(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
+                                     const float* amax_a, const float* amax_w, void* stream) {
+    if (!A || !W || !C || !amax_a || !amax_w || M <= 0 || N <= 0 || K <= 0) return LOB_E_ARG;
+    if (lda < K || ldw < K || ldc < N) return LOB_E_SHAPE;
+    if (!(aligned16(A) && aligned16(W) && lda % 4 == 0 && ldw % 4 == 0 && K % FTK == 0 && K / FTK >= 4 && N <= 2048)) return LOB_E_SHAPE;
+    GemmNT g{A, W, nullptr, C, lda, ldw, ldc, M, N, K, LOB_ACT_NONE, 0, 0, 0, 0, 0, amax_a, amax_w};
+    const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
+    long gsz = 512;
+    const long tiles = (long)ntm * ntn;
+    if (gsz > tiles) gsz = ((tiles + 7) / 8) * 8;
+    hipLaunchKernelGGL((gemm_nt_dma_f32_kernel<0, true>), dim3((unsigned)gsz), dim3(256), 0, (hipStream_t)stream, g);
+    LOB_CHECK_LAUNCH();
+    return 0;
 }
 
 int lob_gate_gemm_ws_split(const float* X, int ldx, const float* Wih, const float* bias, float* P, int T, int Bp, int D,
@@ -518,7 +649,7 @@ extern "C" int lob_gate_gemm_x_f32(const float* X, int ldx, const float* Wih, co
         lob_variant(LOB_VAR_F32_SPLIT) != 0)
         return lob_gate_gemm_ws_split(X, ldx, Wih, bias, P, T, Bp, D, K, range, (hipStream_t)stream);
     frag &= 1;
-    GemmNT g{X, Wih, bias, P, ldx, K, N, T * Bp, N, K, LOB_ACT_NONE, 0, T, Bp, H, D};
+    GemmNT g{X, Wih, bias, P, ldx, K, N, T * Bp, N, K, LOB_ACT_NONE, 0, T, Bp, H, D, nullptr, nullptr};
     return launch_nt(g, frag ? 1 : 0, (hipStream_t)stream);
 }
 
@@ -533,11 +664,30 @@ extern "C" int lob_gemm_tn_f32(const float* A, int lda, const float* B, int ldb,
     kchunk = ((kchunk + 31) / 32) * 32;
     if (kchunk < 256) kchunk = 256;
     nchunk = (Kc + kchunk - 1) / kchunk;
-    GemmTN g{A, B, C, lda, ldb, ldc, M, N, Kc, kchunk};
+    GemmTN g{A, B, C, lda, ldb, ldc, M, N, Kc, kchunk, nullptr, nullptr};
     const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0) && (M % 4 == 0) && (N % 4 == 0);
     const dim3 grid((unsigned)(tiles * nchunk)), block(256);
     if (vec) hipLaunchKernelGGL((gemm_tn_kernel<true>), grid, block, 0, (hipStream_t)stream, g);
     else     hipLaunchKernelGGL((gemm_tn_kernel<false>), grid, block, 0, (hipStream_t)stream, g);
+    LOB_CHECK_LAUNCH();
+    return 0;
+}
+
+// C += A^T B with two-way fp16 split products (see lob_gemm_nt_f32_split).  16-B aligned operands, lda % 4 == ldb % 4 == 0,
+// M % 4 == N % 4 == 0; anything else: LOB_E_SHAPE.
+extern "C" int lob_gemm_tn_f32_split(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int Kc,
+                                     const float* amax_a, const float* amax_b, void* stream) {
+    if (!A || !B || !C || !amax_a || !amax_b || M <= 0 || N <= 0 || Kc <= 0) return LOB_E_ARG;
+    if (lda < M || ldb < N || ldc < N) return LOB_E_SHAPE;
+    if (!(aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0) && (M % 4 == 0) && (N % 4 == 0))) return LOB_E_SHAPE;
+    const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    int nchunk = (2048 + tiles - 1) / tiles;
+    int kchunk = (Kc + nchunk - 1) / nchunk;
+    kchunk = ((kchunk + 31) / 32) * 32;
+    if (kchunk < 256) kchunk = 256;
+    nchunk = (Kc + kchunk - 1) / kchunk;
+    GemmTN g{A, B, C, lda, ldb, ldc, M, N, Kc, kchunk, amax_a, amax_b};
+    hipLaunchKernelGGL((gemm_tn_kernel<true, true>), dim3((unsigned)(tiles * nchunk)), dim3(256), 0, (hipStream_t)stream, g);
     LOB_CHECK_LAUNCH();
     return 0;
 }

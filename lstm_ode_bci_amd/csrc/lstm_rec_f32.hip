@@ -514,6 +514,21 @@ extern "C" int lob_lstm_rec_bwd_f32(const float* G, const float* Csave, const fl
     return 0;
 }
 
+int lob_rec_bwd_split(const float* G, const float* Csave, const float* Whh, const float* dY, void* dP, int dp_bf16, float* dbias,
+                      float* amax_out, int T, int Bp, int D, const float* range, hipStream_t s);      // lstm_rec_f32_split.hip
+
+// lob_lstm_rec_bwd_f32 on the fp16-split arithmetic of the fp32 path (H == 128, Bp % 32 == 0, LOB_VAR_F32_SPLIT != 0;
+// anything else: LOB_E_SHAPE -- the caller keeps lob_lstm_rec_bwd_f32).  amax_out (may be NULL): a zeroed device float that
+// receives max|dP| of the launch (atomic max); range (may be NULL): D device floats, max|W_hh| per direction.
+extern "C" int lob_lstm_rec_bwd_f32_x(const float* G, const float* Csave, const float* Whh, const float* dY, void* dP,
+                                      int dp_bf16, float* dbias, float* amax_out, const float* range,
+                                      int T, int Bp, int H, int D, void* stream) {
+    if (!G || !Csave || !Whh || !dY || !dP || T <= 0 || Bp <= 0 || H <= 0 || (D != 1 && D != 2)) return LOB_E_ARG;
+    if (H != 128 || (Bp % 32) || lob_variant(LOB_VAR_F32_SPLIT) == 0) return LOB_E_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(Csave) | reinterpret_cast<uintptr_t>(dP)) & 15) return LOB_E_ALIGN;
+    return lob_rec_bwd_split(G, Csave, Whh, dY, dP, dp_bf16, dbias, amax_out, T, Bp, D, range, (hipStream_t)stream);
+}
+
 // 1 when the recurrent kernels for this H consume / produce the accumulator-fragment layout
 // (P from lob_gate_gemm_x_* with frag = 1, fused bias gradient), 0 for the row-major generic path.
 extern "C" int lob_lstm_uses_fragment_layout(int H) { return (H == 128 || lob_stream_supports(H)) ? 1 : 0; }

@@ -166,6 +166,190 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h128_split_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// BPTT on the same arithmetic (round 4).  dh_rec = dgates[16 x 512] W_hh[512 x 128] per step: the exact-fp32 kernel
+// (lstm_rec_f32.hip) spends 7.8 of its 12.7 us per step in 256 v_mfma_f32_32x32x2_f32; here W_hh^T sits in registers as
+// split fp16 fragments (128 VGPRs per wave: eight waves x 16 hidden columns, as in the forward) and the step costs 48
+// v_mfma_f32_16x16x32_f16 per wave.  The forward's operand h is bounded by 1; dgates are not bounded by anything known in
+// advance, so their pre-scale is taken from the tile itself EVERY step: each wave publishes the |max| of the 16 values
+// per lane it has just computed, and after a barrier every wave derives the same power of two from the eight maxima
+// (lob_split_scale: hi and lo stay inside fp16's normal range whatever the gradient's magnitude).  Three barriers per
+// step: maxima, split tile, dP staging.  dP leaves as fp32 rows (or bf16) through an fp32 LDS image; the kernel also
+// returns max|dP| over the launch (atomic max on the bit pattern into a zeroed word): the pre-scale of the dX and dW
+// GEMMs that consume dP (lob_gemm_nt_f32_split / lob_gemm_tn_f32_split).
+// Layouts: lob.h (fragment-order fp32 saved gates / cell states, row-major dY and dP), 16-row tiles like the forward.
+// ------------------------------------------------------------------------------------------
+constexpr int DGH_LD = 520;    // fp16 dgates tile row stride (1040 B = 65 x 16 B, odd -> conflict-free b128)
+constexpr int DPF_LD = 516;    // fp32 dP image row stride (2064 B = 129 x 16 B)
+
+template <bool DP_BF16>
+__global__ __launch_bounds__(512, 2) void lstm_rec_bwd_h128_split_kernel(
+    const float* __restrict__ G, const float* __restrict__ Csave, const float* __restrict__ Whh, const float* __restrict__ dY,
+    void* __restrict__ dPv, float* __restrict__ dbias, float* __restrict__ amax_out, int T, int Bp, const float* __restrict__ range) {
+    __shared__ __attribute__((aligned(16))) _Float16 dgs[2 * 16 * DGH_LD];      // [split][16 rows][DGH_LD]
+    __shared__ __attribute__((aligned(16))) float dpf[16 * DPF_LD];             // fp32 dgates = the dP image
+    __shared__ float wmax[2][8];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wcol = w8 >> 1, cbu = w8 & 1;
+    const int d = blockIdx.y, D = gridDim.y, NBT = Bp >> 5;
+    const int c16 = lane & 15, rq = lane >> 4;
+    const int bt = blockIdx.x >> 1, s0 = blockIdx.x & 1;
+    const int col = 32 * wcol + 16 * cbu + c16;               // this lane's hidden unit
+
+    const float sw = range ? lob_split_scale(range[d]) : S_OP;
+    // B fragments of dh = dgates W_hh: B[k][unit], k = 32 ks + 8 rq + j  (W_hh is [4H][H]: element (k, unit))
+    f16x8 whi[16], wlo[16];
+    {
+        const float* wb = Whh + (size_t)d * 4 * H * H + col;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            f16x8 h8, l8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                _Float16 hh, ll;
+                split2(wb[(size_t)(32 * ks + 8 * rq + j) * H], hh, ll, sw);
+                h8[j] = hh; l8[j] = ll;
+            }
+            whi[ks] = h8; wlo[ks] = l8;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const size_t gstep = (size_t)NBT * 16 * 1024, cstep = (size_t)NBT * 4096;
+    const unsigned lane_p = (unsigned)((2 * s0 + (rq >> 1)) * 256 + ((rq & 1) * 32 + 16 * cbu + c16) * 4);
+    const float* gblk = G + ((size_t)d * T * NBT + bt) * 16 * 1024 + (size_t)wcol * 4096 + lane_p;
+    const float* cblk = Csave + ((size_t)d * T * NBT + bt) * 4096 + (size_t)wcol * 1024 + lane_p;
+    const int DH = D * H, D4H = D * 4 * H;
+    const int row0 = bt * 32 + s0 * 16;
+    const float* dyl = dY + (size_t)(row0 + 4 * rq) * DH + d * H + col;
+    const int t_first = d ? 0 : T - 1, dt = d ? 1 : -1;
+
+    f32x4 gt[4], ct, cp, dyv;
+    float dhrec[4] = {0.f, 0.f, 0.f, 0.f}, dcarry[4] = {0.f, 0.f, 0.f, 0.f};
+    float dbsum[4] = {0.f, 0.f, 0.f, 0.f};
+    float runmax = 0.f;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto load_c = [&](int t) -> f32x4 {
+        const int tt = (t >= 0 && t < T) ? t : t_first;
+        return *reinterpret_cast<const f32x4*>(cblk + (size_t)tt * cstep);
+    };
+    auto load_step = [&](int t) {
+        const float* gp = gblk + (size_t)t * gstep;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gt[g] = *reinterpret_cast<const f32x4*>(gp + g * 1024);
+        cp = load_c(t + dt);
+        const float* dp = dyl + (size_t)t * Bp * DH;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dyv[j] = dp[(size_t)j * DH];
+    };
+    ct = load_c(t_first);
+    load_step(t_first);
+
+    for (int step = 0; step < T; ++step) {
+        const int t = t_first + dt * step;
+        const bool cp_ok = (t + dt) >= 0 && (t + dt) < T;       // c of the step before the first one is zero
+        float v[4][4];
+        float m = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float ig = gt[0][j], fg = gt[1][j], gg = gt[2][j], og = gt[3][j];
+            const float dh = dyv[j] + dhrec[j];
+            const float tc = fast_tanh(ct[j]);
+            const float dc = dcarry[j] + dh * og * (1.f - tc * tc);
+            dcarry[j] = dc * fg;
+            const float cpv = cp_ok ? cp[j] : 0.f;
+            v[0][j] = dc * gg * ig * (1.f - ig);
+            v[1][j] = dc * cpv * fg * (1.f - fg);
+            v[2][j] = dc * ig * (1.f - gg * gg);
+            v[3][j] = dh * tc * og * (1.f - og);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { dbsum[g] += v[g][j]; m = fmaxf(m, fabsf(v[g][j])); }
+        }
+        ct = cp;
+        runmax = fmaxf(runmax, m);
+        // the dP image (fp32): rows 4 rq + j, columns g * 128 + col
+        float* dpw = dpf + 4 * rq * DPF_LD + col;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dpw[j * DPF_LD + g * H] = v[g][j];
+        m = wave_max(m);
+        if (lane == 0) wmax[step & 1][w8] = m;
+        __syncthreads();                                         // (1) the eight maxima; the previous step's dP image was stored
+        float tm = wmax[step & 1][0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) tm = fmaxf(tm, wmax[step & 1][i]);
+        const float sg = lob_split_scale(tm);
+        const float r_hh = 1.f / (sg * sw), r_sm = r_hh * (1.f / S_LO);
+        _Float16* dgw = dgs + 4 * rq * DGH_LD + col;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                _Float16 hh, ll;
+                split2(v[g][j], hh, ll, sg);
+                dgw[j * DGH_LD + g * H] = hh;
+                dgw[16 * DGH_LD + j * DGH_LD + g * H] = ll;
+            }
+        __syncthreads();                                         // (2) the split tile and the fp32 image are complete
+        if (step + 1 < T) load_step(t + dt);
+        f32x4 ahh = zero4, asm_ = zero4;
+        const _Float16* arow = dgs + c16 * DGH_LD + 8 * rq;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(arow + 32 * ks);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(arow + 16 * DGH_LD + 32 * ks);
+            ahh = mfma16_f16(ah, whi[ks], ahh);
+            asm_ = mfma16_f16(ah, wlo[ks], asm_);
+            asm_ = mfma16_f16(al, whi[ks], asm_);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dhrec[j] = ahh[j] * r_hh + asm_[j] * r_sm;
+        // dP rows: 16 rows x 2 KB of fp32 (1 KB of bf16), 16 B per thread and pass
+        {
+            const int row = tid >> 5, c4 = (tid & 31) * 4;
+            const size_t o = ((size_t)t * Bp + row0 + row) * D4H + d * 4 * H;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(dpf + row * DPF_LD + c4 + 128 * i);
+                if constexpr (DP_BF16) {
+                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                    bf16x4 b = {(__bf16)x[0], (__bf16)x[1], (__bf16)x[2], (__bf16)x[3]};
+                    *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(dPv) + o + c4 + 128 * i) = b;
+                } else {
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(dPv) + o + c4 + 128 * i) = x;
+                }
+            }
+        }
+        __syncthreads();                                         // (3) the image and the tile may be overwritten
+    }
+    if (dbias) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float x = dbsum[g];
+            x += __shfl_xor(x, 16, 64);
+            x += __shfl_xor(x, 32, 64);
+            if (rq == 0) atomicAdd(dbias + (size_t)d * 4 * H + g * H + col, x);
+        }
+    }
+    if (amax_out) {
+        runmax = wave_max(runmax);
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(amax_out), __builtin_bit_cast(unsigned, runmax));
+    }
+}
+
+}  // namespace
+
+int lob_rec_bwd_split(const float* G, const float* Csave, const float* Whh, const float* dY, void* dP, int dp_bf16, float* dbias,
+                      float* amax_out, int T, int Bp, int D, const float* range, hipStream_t s) {
+    const dim3 grid(Bp / 16, D), block(512);
+    if (dp_bf16) hipLaunchKernelGGL((lstm_rec_bwd_h128_split_kernel<true>), grid, block, 0, s, G, Csave, Whh, dY, dP, dbias, amax_out, T, Bp, range);
+    else         hipLaunchKernelGGL((lstm_rec_bwd_h128_split_kernel<false>), grid, block, 0, s, G, Csave, Whh, dY, dP, dbias, amax_out, T, Bp, range);
+    LOB_CHECK_LAUNCH();
+    return 0;
+}
+
+namespace {
 }  // namespace
 
 // Internal entry point used by lob_lstm_rec_fwd_f32 (lstm_rec_f32.hip): 16-row tiles, eight waves, grid Bp/16 x D.

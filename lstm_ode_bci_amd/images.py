@@ -95,7 +95,10 @@ def build(ps, cfg, x_shape, need_grad):
     # sqrt(H) max|gain| + max|bias| (no bound with nn.Identity in its place: that layer's GEMM runs exact); the other
     # layers see |h| < 1 (times the dropout scale in train mode).
     want_range = bool(not mixed and frag and H == 128 and _lib.get_variant("F32_SPLIT") != 0)
-    rng = torch.zeros((L * (2 * D + 1),), device=dev, dtype=f32) if want_range else None      # atomic-max targets
+    # per layer: [max|W_ih| per direction (D)] [activation bound] [max|W_hh| per direction (D)] [max|W_ih| over the
+    # directions] [1.0 = the bound of |h|]: the last two are operand ranges of the backward's fp16-split GEMMs
+    RS = 2 * D + 3
+    rng = torch.zeros((L * RS,), device=dev, dtype=f32) if want_range else None      # atomic-max targets
     base = 4
     for layer in range(L):
         dirs = [ps[base + 4 * d: base + 4 * d + 4] for d in range(D)]
@@ -113,10 +116,12 @@ def build(ps, cfg, x_shape, need_grad):
             wt16 = bool(mixed and ops.dma_ok(N, K, rows))
             wt = new((K, N), bf16 if wt16 else f32)
         if rng is not None:
-            r0 = layer * (2 * D + 1)
+            r0 = layer * RS
             for d, (w_ih, w_hh, _bi, _bh) in enumerate(dirs):
                 plan.add_range(rng, r0 + d, w_ih)
                 plan.add_range(rng, r0 + D + 1 + d, w_hh)
+                plan.add_range(rng, r0 + 2 * D + 1, w_ih)
+            plan.add_range(rng, r0 + 2 * D + 2, lnbound=True, factor=1.0)
             if layer == 0:
                 if ps[2] is not None:
                     plan.add_range(rng, r0 + D, ps[2], ps[3], lnbound=True, factor=1.0 / (1.0 - p_in) if p_in < 1 else 1.0)
@@ -126,6 +131,9 @@ def build(ps, cfg, x_shape, need_grad):
                 plan.add_range(rng, r0 + D, lnbound=True, factor=1.0 / (1.0 - p_lstm) if p_lstm < 1 else 1.0)
                 img[("gate_range", layer)] = rng[r0:r0 + D + 1]
             img[("rec_range", layer)] = rng[r0 + D + 1:r0 + 2 * D + 1]
+            # backward: (bound of the layer's input activations | None, max|W_ih| over the directions, bound of |h|)
+            img[("bwd_range", layer)] = (rng[r0 + D:r0 + D + 1] if ("gate_range", layer) in img else None,
+                                         rng[r0 + 2 * D + 1:r0 + 2 * D + 2], rng[r0 + 2 * D + 2:r0 + 2 * D + 3])
         for d, (w_ih, w_hh, b_ih, b_hh) in enumerate(dirs):
             plan.add(w_ih, wih, dst_ptr_off=d * 4 * H * K)
             if w16 is not None:

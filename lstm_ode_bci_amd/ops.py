@@ -101,10 +101,34 @@ def _bf16_ok(a, K, lda):
     return K % 8 == 0 and lda % 8 == 0 and a.data_ptr() % 16 == 0
 
 
-def gemm_nt(a, w, bias=None, act=ACT_NONE, out=None, accumulate=False, mixed=False, drop_p=0.0, seed=0, out_bf16=False):
+def f32_split_gemm_ok(M, N, K, nt=True):
+    """Shapes the fp16-split fp32 GEMMs take (lob_gemm_nt_f32_split / lob_gemm_tn_f32_split) when LOB_VAR_F32_SPLIT is on."""
+    if _lib.get_variant("F32_SPLIT") == 0:
+        return False
+    return (K % 32 == 0 and K >= 128 and N <= 2048) if nt else (M % 4 == 0 and N % 4 == 0)
+
+
+def gemm_nt(a, w, bias=None, act=ACT_NONE, out=None, accumulate=False, mixed=False, drop_p=0.0, seed=0, out_bf16=False,
+            amax=None):
     """out[M,N] (+)= act(a[M,K] @ w[N,K]^T + bias).  mixed=True (or a bf16 `a`): bf16 MFMA inputs,
     fp32 accumulate/output; falls back to the exact-fp32 kernel for shapes the bf16 kernel refuses.
-    out_bf16 (bf16 a AND w only): the result is stored as bf16."""
+    out_bf16 (bf16 a AND w only): the result is stored as bf16.
+    amax = (device float >= max|a|, device float >= max|w|), fp32 operands, no bias / act / accumulate: the products run
+    as two-way fp16 splits on the 16-bit matrix pipe (22-bit products: the fp32 path's backward GEMMs)."""
+    if (amax is not None and not mixed and a.dtype == torch.float32 and w.dtype == torch.float32 and bias is None
+            and act == ACT_NONE and not accumulate and drop_p == 0 and not out_bf16
+            and f32_split_gemm_ok(a.shape[0], w.shape[0], a.shape[1]) and a.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0
+            and a.shape[1] % 4 == 0):
+        _chk(a, "a"); _chk(w, "w"); _chk(amax[0], "amax_a"); _chk(amax[1], "amax_w")
+        M, K = a.shape
+        N = w.shape[0]
+        if out is None:
+            out = torch.empty((M, N), device=a.device, dtype=torch.float32)
+        _chk(out, "out")
+        rc = _lib.lib().lob_gemm_nt_f32_split(_ptr(a), K, _ptr(w), K, _ptr(out), N, M, N, K, _ptr(amax[0]), _ptr(amax[1]),
+                                              _stream())
+        _lib.check(rc, "lob_gemm_nt_f32_split")
+        return out
     a_bf16 = a.dtype == torch.bfloat16
     w_bf16 = w.dtype == torch.bfloat16
     _chk(a, "a", a.dtype if a_bf16 else torch.float32); _chk(w, "w", w.dtype if w_bf16 else torch.float32)
@@ -137,14 +161,22 @@ def gemm_nt(a, w, bias=None, act=ACT_NONE, out=None, accumulate=False, mixed=Fal
     return out
 
 
-def gemm_tn(a, b, out, mixed=False):
+def gemm_tn(a, b, out, mixed=False, amax=None):
     """out[M,N] += a[Kc,M]^T @ b[Kc,N]; a, b may be column slices of wider row-major tensors
-    (fp32 or bf16 storage).  mixed=True or any bf16 operand -> bf16 MFMA, fp32 accumulate."""
+    (fp32 or bf16 storage).  mixed=True or any bf16 operand -> bf16 MFMA, fp32 accumulate.
+    amax = (device float >= max|a|, device float >= max|b|) with fp32 operands: two-way fp16 split products (gemm_nt)."""
     Kc, M = a.shape
     N = b.shape[1]
     assert b.shape[0] == Kc and a.stride(1) == 1 and b.stride(1) == 1
     _chk(out, "out")
     a16, b16 = a.dtype == torch.bfloat16, b.dtype == torch.bfloat16
+    if (amax is not None and not mixed and not a16 and not b16 and f32_split_gemm_ok(M, N, Kc, nt=False)
+            and a.stride(0) % 4 == 0 and b.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0):
+        _chk(amax[0], "amax_a"); _chk(amax[1], "amax_b")
+        rc = _lib.lib().lob_gemm_tn_f32_split(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), out.stride(0),
+                                              M, N, Kc, _ptr(amax[0]), _ptr(amax[1]), _stream())
+        _lib.check(rc, "lob_gemm_tn_f32_split")
+        return out
     am, bm = (8 if a16 else 4), (8 if b16 else 4)
     ok16 = (M % am == 0 and a.stride(0) % am == 0 and N % bm == 0 and b.stride(0) % bm == 0
             and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0)
@@ -518,9 +550,16 @@ def ode_rk4(base_rates, n_points, t0, t1, substeps, *, probs=None, alpha=0.0, y0
 # ---------------------------------------------------------------------------------------------
 # backward-side wrappers
 # ---------------------------------------------------------------------------------------------
-def lstm_rec_bwd(G, Cs, whh, dY, T, Bp, H, D, dp_bf16=False, dbias=None, dbias2=None):
+def f32_split_bwd_ok(H, Bp):
+    """The fp32 path's BPTT on the fp16-split arithmetic (lob_lstm_rec_bwd_f32_x)."""
+    return H == 128 and Bp % 32 == 0 and _lib.get_variant("F32_SPLIT") != 0
+
+
+def lstm_rec_bwd(G, Cs, whh, dY, T, Bp, H, D, dp_bf16=False, dbias=None, dbias2=None, amax_out=None, range=None):
     """BPTT through one layer; returns (dP[T*Bp, D*4H] row-major fp32|bf16, dbias[D*4H]); dbias: zeroed destination.
-    dbias2 (mixed kernels only, see ``rec_bwd_two_bias_ok``): a second destination that receives the same adds."""
+    dbias2 (mixed kernels only, see ``rec_bwd_two_bias_ok``): a second destination that receives the same adds.
+    fp32 saved gates at H == 128 (``f32_split_bwd_ok``): the fp16-split kernel; amax_out (a zeroed device float) then
+    receives max|dP|, range = D device floats max|W_hh| per direction."""
     g16 = G.dtype == torch.bfloat16
     dy16 = dY.dtype == torch.bfloat16
     c16 = Cs.dtype == torch.bfloat16
@@ -542,7 +581,13 @@ def lstm_rec_bwd(G, Cs, whh, dY, T, Bp, H, D, dp_bf16=False, dbias=None, dbias2=
             whht16 = (whh.to(torch.bfloat16).reshape(D, 64, 2, 8, 8, 32).permute(0, 4, 1, 2, 5, 3).contiguous())
         rc = _lib.lib().lob_lstm_rec_bwd_bf16(_ptr(G), int(g16), _ptr(Cs), int(c16), _ptr(whh), _ptr(whht16), _ptr(dY),
                                               int(dy16), _ptr(dP), _ptr(dbias), _ptr(dbias2), T, Bp, H, D, _stream())
+    elif not g16 and not dy16 and not c16 and f32_split_bwd_ok(H, Bp):
+        _chk(amax_out, "amax_out"); _chk(range, "range")
+        rc = _lib.lib().lob_lstm_rec_bwd_f32_x(_ptr(G), _ptr(Cs), _ptr(whh), _ptr(dY), _ptr(dP), int(dp_bf16), _ptr(dbias),
+                                               _ptr(amax_out), _ptr(range), T, Bp, H, D, _stream())
     else:
+        if amax_out is not None:
+            raise _lib.LobError("lstm_rec_bwd: max|dP| is produced by the fp16-split fp32 kernel only (H = 128, LOB_VAR_F32_SPLIT)")
         rc = _lib.lib().lob_lstm_rec_bwd_f32(_ptr(G), _ptr(Cs), _ptr(whh), _ptr(dY), _ptr(dP), int(dp_bf16),
                                              _ptr(dbias) if fused_bias else _ptr(None), T, Bp, H, D, _stream())
     _lib.check(rc, "lob_lstm_rec_bwd")

@@ -1,0 +1,119 @@
+"""GPU: the fp32 path's BACKWARD on the 16-bit matrix pipe (round 4) -- two-way fp16 operand splits, 22-bit
+products, fp32 accumulate, as the forward's gate GEMMs and recurrent kernel since round 2:
+lob_gemm_nt_f32_split (dX = dP W_ih), lob_gemm_tn_f32_split (dW = dP^T x), lob_lstm_rec_bwd_f32_x (BPTT; the dgates'
+pre-scale re-derived per tile and step).  Each kernel against a float64 product / its exact-fp32 twin (LOB_VAR_F32_SPLIT = 0),
+at gradient-like magnitudes far outside fp16's range; the model-level parity tests (tests/test_gpu_parity.py,
+tests/test_gpu_training.py: goldens g1 / g2 / g6 / g7 at the unchanged tolerances) run THROUGH these kernels at H = 128."""
+import numpy as np
+import pytest
+import torch
+
+from tests import conftest  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _rnd(shape, scale, dev, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dev)
+
+
+@pytest.mark.parametrize("M,K,N,scale", [(8192 + 96, 1024, 256, 1e-4), (4096, 1024, 128, 3e-9), (1000, 256, 512, 40.0)])
+def test_split_nt_gemm_vs_float64(dev, M, K, N, scale):
+    from lstm_ode_bci_amd import _lib, ops
+    a = _rnd((M, K), scale, dev, 1)
+    a[5, 7] *= 60.0                                    # an outlier sets the range: the bulk sits 2^-6 below it
+    w = _rnd((N, K), 0.05, dev, 2)
+    ref = a.double() @ w.double().t()
+    amax = (a.abs().max().reshape(1), w.abs().max().reshape(1))
+    out = ops.gemm_nt(a, w, amax=amax)
+    with _lib.variant(F32_SPLIT=0):
+        exact = ops.gemm_nt(a, w, amax=amax)           # the switch routes this call to the exact-fp32 MFMA kernel
+    mx = ref.abs().max().item()
+    e_split, e_exact = (out.double() - ref).abs().max().item() / mx, (exact.double() - ref).abs().max().item() / mx
+    assert torch.isfinite(out).all()
+    assert e_split < 2e-6 and e_split < 4 * e_exact + 2e-7, (e_split, e_exact)
+    # a loose bound (x 8: pre-scales are powers of two) changes nothing beyond rounding
+    out8 = ops.gemm_nt(a, w, amax=(amax[0] * 7.9, amax[1] * 3.0))
+    assert (out8.double() - ref).abs().max().item() / mx < 4e-6
+
+
+@pytest.mark.parametrize("Kc,M,N,scale", [(16384, 1024, 256, 1e-5), (4096 + 32, 512, 128, 2e-3)])
+def test_split_tn_gemm_vs_float64(dev, Kc, M, N, scale):
+    from lstm_ode_bci_amd import ops
+    a_full = _rnd((Kc, 2 * M), scale, dev, 3)           # column slices of wider row-major tensors, as dW_hh takes them
+    b_full = _rnd((Kc, 2 * N), 0.5, dev, 4)
+    a, b = a_full[:, M:], b_full[:, :N]
+    ref = a.double().t() @ b.double()
+    out = torch.zeros((M, N), device=dev)
+    ops.gemm_tn(a, b, out, amax=(a.abs().max().reshape(1), torch.ones(1, device=dev) * b.abs().max()))
+    exact = torch.zeros((M, N), device=dev)
+    ops.gemm_tn(a, b, exact)
+    mx = ref.abs().max().item()
+    e_split, e_exact = (out.double() - ref).abs().max().item() / mx, (exact.double() - ref).abs().max().item() / mx
+    assert e_split < 3e-6 and e_split < 4 * e_exact + 3e-7, (e_split, e_exact)
+    ops.gemm_tn(a, b, out, amax=(a.abs().max().reshape(1), b.abs().max().reshape(1)))       # accumulates
+    assert (out.double() - 2 * ref).abs().max().item() / mx < 6e-6
+
+
+@pytest.mark.parametrize("T,Bp,D,dyscale", [(24, 64, 2, 1e-3), (5, 32, 1, 1e-9), (40, 96, 2, 300.0)])
+def test_split_bptt_vs_exact_twin(dev, T, Bp, D, dyscale):
+    """Same saved gates / cell states / dY through lob_lstm_rec_bwd_f32_x and through the exact-fp32 MFMA kernel: dP, the bias
+    gradient and the reported max|dP|, at gradient magnitudes from 1e-9 to 3e2 (the per-step tile scale keeps both fp16 halves
+    in range)."""
+    from lstm_ode_bci_amd import _lib, ops
+    H = 128
+    whh = _rnd((D, 4 * H, H), 0.08, dev, 5)
+    x = _rnd((T * Bp, H), 1.0, dev, 6)
+    wih = _rnd((D * 4 * H, H), 0.08, dev, 7)
+    bias = _rnd((D * 4 * H,), 0.1, dev, 8)
+    P = ops.gate_gemm_x(x, wih, bias, T, Bp, H, D, True, mixed=False, exact=True)
+    Y, Cs, _, _ = ops.lstm_rec_fwd(P, whh, T, Bp, H, D, True)         # P now holds the activated gates
+    dY = _rnd((T * Bp, D * H), dyscale, dev, 9)
+    rng = whh.abs().amax(dim=(1, 2)).contiguous()
+    amax = torch.zeros(1, device=dev)
+    dP, db = ops.lstm_rec_bwd(P, Cs, whh, dY, T, Bp, H, D, amax_out=amax, range=rng)
+    with _lib.variant(F32_SPLIT=0):
+        dPr, dbr = ops.lstm_rec_bwd(P, Cs, whh, dY, T, Bp, H, D)
+    assert torch.isfinite(dP).all() and torch.isfinite(db).all()
+    mx = dPr.abs().max().item()
+    assert (dP - dPr).abs().max().item() <= 3e-6 * mx, ((dP - dPr).abs().max().item(), mx)
+    assert (db - dbr).abs().max().item() <= 1e-5 * dbr.abs().max().item()
+    assert amax.item() == dP.abs().max().item()
+    # without a range the kernel's default weight scale applies: same result for weights of ordinary size
+    dP2, _ = ops.lstm_rec_bwd(P, Cs, whh, dY, T, Bp, H, D)
+    assert (dP2 - dPr).abs().max().item() <= 3e-6 * mx
+
+
+def test_fp32_training_step_runs_the_split_backward_and_matches_the_exact_one(dev):
+    """Whole model, fp32, H = 128, B = 64, T = 48, dropout off: every parameter gradient and the input gradient of the
+    split backward against the exact-fp32 kernels (the same comparison the goldens make against the reference, here
+    kernel set against kernel set)."""
+    from lstm_ode_bci_amd import EnhancedLSTMModel, _lib
+    from lstm_ode_bci_amd import synthetic as syn
+    sd = syn.make_state_dict(61, 128, 3, 2, True)
+    x, y = syn.make_windows(64, 48, 61, seed=4)
+    m = EnhancedLSTMModel(61, 128, 3, 2, 0.4, True)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m = m.to(dev).eval()
+
+    def grads():
+        m.zero_grad(set_to_none=True)
+        xg = torch.from_numpy(x).to(dev).requires_grad_(True)
+        torch.nn.functional.cross_entropy(m(xg), torch.from_numpy(y).to(dev)).backward()
+        return {**{k: p.grad.clone() for k, p in m.named_parameters()}, "x": xg.grad.clone()}
+    gs = grads()
+    with _lib.variant(F32_SPLIT=0):
+        ge = grads()
+    for k in ge:
+        mx = ge[k].abs().max().item()
+        if mx < 1e-9:
+            continue
+        assert (gs[k] - ge[k]).abs().max().item() <= 2e-5 * mx + 1e-9, (k, (gs[k] - ge[k]).abs().max().item(), mx)
