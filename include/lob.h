@@ -83,8 +83,10 @@ const char* lob_build_id(void);
 #define LOB_VAR_NT_TK        11  /* its k-tile: 32 or 64                                                          */
 #define LOB_VAR_NT_STAGGER   12  /* start stagger of the NT LDS-DMA GEMM (units of s_sleep(32)); 0 = off           */
 #define LOB_VAR_FUSED_DW     13  /* read by the Python host: 1 = dW_ih and dW_hh from one pass (lob_lstm_dw_bf16)  */
-#define LOB_VAR_F32_SPLIT    14  /* 1: fp32 gate GEMMs / recurrent forward (H=128) carry each operand as two fp16 halves
-                                  *    (22 bits) on the 16-bit matrix pipe; 0: exact-fp32 MFMA                     */
+#define LOB_VAR_F32_SPLIT    14  /* 1: fp32 gate GEMMs / recurrent kernels / backward GEMMs (H=128) carry each operand as two
+                                  *    fp16 halves (22 bits) on the 16-bit matrix pipe; 0: exact-fp32 MFMA; 2: as 1, with
+                                  *    lob_gemm_nt_f32_split / lob_gemm_tn_f32_split on their twins that split at every fragment
+                                  *    read instead of once while staging (same arithmetic up to the summation order)        */
 #define LOB_VAR_H256_LDSW    15  /* H=256 recurrent kernels: 0 = all W_hh fragments streamed; 1 = part of them resident in LDS      */
 #define LOB_VAR_DX_KSPLIT    16  /* 1: dX = dP W_ih on the k-split weight-stationary kernel; 0: tiled LDS-DMA NT GEMM          */
 #define LOB_VAR_REC_FEW      17  /* 1: mixed inference forward with fewer than 4 windows skips the padding registers' cell update */

@@ -536,6 +536,265 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN g) {
         }
 }
 
+// ------------------------------------------------------------------------------------
+// The same product, fp16-split, with the split done ONCE per element while the tile is staged (the structure of
+// gemm_tn_bf16_kernel in gemm_bf16.hip, which rounds fp32 sources to bf16 on their way into LDS): every [32 k][128 cols]
+// source tile becomes a hi and a lo fp16 image ([k][col], 320-B rows), the MFMA fragments (8 consecutive k of one column per
+// lane) come out of gfx950's transposing LDS read ds_read_b64_tr_b16, three v_mfma_f32_32x32x16_f16 per fragment pair.
+// Against gemm_tn_kernel<.., SPLIT = true> (split at every fragment read: each element converted by two waves): half the
+// conversions, 16-B LDS stores instead of 64 scalar fragment reads per k-tile and lane.
+// ------------------------------------------------------------------------------------
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __fp16 fp16x4v __attribute__((__vector_size__(4 * sizeof(__fp16))));      // the transposing read's builtin type
+typedef __attribute__((address_space(3))) fp16x4v lds_f16x4;
+constexpr int STK = 32, SLDK = 160;          // contraction rows per stage; LDS row stride in fp16 elements (320 B)
+
+__device__ __forceinline__ void ldk_f32s(const float* __restrict__ G, int ld, int k0, int kend, int c0, int cols, int tid,
+                                         f32x4 (&r)[4]) {
+    const int kk = tid >> 5, c4 = (tid & 31) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = k0 + kk + 8 * i, c = c0 + c4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k < kend && c < cols) v = *reinterpret_cast<const f32x4*>(G + (size_t)k * ld + c);
+        r[i] = v;
+    }
+}
+__device__ __forceinline__ void stk_split(_Float16* Shi, _Float16* Slo, int tid, const f32x4 (&r)[4], float scale) {
+    const int kk = tid >> 5, c4 = (tid & 31) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f16x4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float sv = r[i][e] * scale;
+            const _Float16 hh = (_Float16)sv;
+            h[e] = hh;
+            l[e] = (_Float16)((sv - (float)hh) * SPLIT_LO);
+        }
+        *reinterpret_cast<f16x4*>(Shi + (kk + 8 * i) * SLDK + c4) = h;
+        *reinterpret_cast<f16x4*>(Slo + (kk + 8 * i) * SLDK + c4) = l;
+    }
+}
+// fragment of the 32-column block starting at column `cb`, k-step s (16 rows) of a [k][col] fp16 LDS image
+__device__ __forceinline__ f16x8 tr_frag_h(const _Float16* S, int cb, int s, int lane) {
+    const int h = lane >> 5, mh = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
+    const _Float16* a = S + (16 * s + 8 * h + q) * SLDK + cb + 16 * mh + 4 * p;
+    const f16x4 lo = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_f16x4*)a));
+    const f16x4 hi = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_f16x4*)(a + 4 * SLDK)));
+    f16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return f;
+}
+
+struct GemmTNS {
+    const float* A; const float* B; float* C;
+    int lda, ldb, ldc, M, N, Kc, kchunk, tiles;
+    const float* amax_a; const float* amax_b;
+};
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_split_kernel(GemmTNS g) {
+    __shared__ __attribute__((aligned(16))) _Float16 lds[2 * 4 * STK * SLDK];      // [buf][A hi, A lo, B hi, B lo][32][160]: 80 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int ntn = (g.N + 127) / 128;
+    const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+    const int tile = rest % g.tiles, chunk = (rest / g.tiles) * 8 + xcd;
+    const int m0 = (tile / ntn) * 128, n0 = (tile % ntn) * 128;
+    const int kbeg = chunk * g.kchunk, kend = min(g.Kc, kbeg + g.kchunk);
+    if (kbeg >= kend) return;
+    const float sa = lob_split_scale(*g.amax_a), sb = lob_split_scale(*g.amax_b);
+
+    f32x16 acc[2][2], asm_[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; asm_[i][j][r] = 0.f; }
+
+    f32x4 ra[4], rb[4];
+    auto load = [&](int k0) {
+        ldk_f32s(g.A, g.lda, k0, kend, m0, g.M, tid, ra);
+        ldk_f32s(g.B, g.ldb, k0, kend, n0, g.N, tid, rb);
+    };
+    auto store = [&](int b) {
+        _Float16* base = lds + b * 4 * STK * SLDK;
+        stk_split(base, base + STK * SLDK, tid, ra, sa);
+        stk_split(base + 2 * STK * SLDK, base + 3 * STK * SLDK, tid, rb, sb);
+    };
+    load(kbeg);
+    store(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += STK) {
+        const bool more = k0 + STK < kend;
+        if (more) load(k0 + STK);
+        const _Float16* ah_s = lds + buf * 4 * STK * SLDK;
+        const _Float16* al_s = ah_s + STK * SLDK;
+        const _Float16* bh_s = ah_s + 2 * STK * SLDK;
+        const _Float16* bl_s = ah_s + 3 * STK * SLDK;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = tr_frag_h(ah_s, 64 * wr + 32 * i, s, lane);
+                al[i] = tr_frag_h(al_s, 64 * wr + 32 * i, s, lane);
+                bh[i] = tr_frag_h(bh_s, 64 * wc + 32 * i, s, lane);
+                bl[i] = tr_frag_h(bl_s, 64 * wc + 32 * i, s, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = mfma_h(ah[i], bh[j], acc[i][j]);
+                    asm_[i][j] = mfma_h(ah[i], bl[j], asm_[i][j]);
+                    asm_[i][j] = mfma_h(al[i], bh[j], asm_[i][j]);
+                }
+        }
+        if (more) store(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    const float r_hh = 1.f / (sa * sb), r_sm = r_hh * (1.f / SPLIT_LO);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + 64 * wc + 32 * j + (lane & 31);
+            if (col >= g.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + 64 * wr + 32 * i + acc_row(r, lane);
+                if (row < g.M) atomicAdd(g.C + (size_t)row * g.ldc + col, acc[i][j][r] * r_hh + asm_[i][j][r] * r_sm);
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------
+// C[M,N] = A[M,K] W[N,K]^T, fp16-split, the split done once per element while the tiles are staged (the structure of
+// gemm_nt_bf16_kernel: persistent workgroups, register-staged 128 x 32 operand tiles, the next tile's first loads issued
+// before the epilogue's stores; XCD-aware tile order).  hi and lo images [row][k] with 80-B rows (conflict-free
+// ds_read_b128 fragments).  Row-major fp32 output, no bias / activation: dX = dP W_ih of the fp32 training step.
+// ------------------------------------------------------------------------------------
+constexpr int NKT = 32, NLD = NKT + 8;
+
+__device__ __forceinline__ void ld_rows_s(const float* __restrict__ G, int ld, int row0, int rows, int k0, int K, int tid,
+                                          f32x4 (&r)[4]) {
+    const int rr = tid >> 3, c4 = (tid & 7) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = row0 + rr + 32 * i, k = k0 + c4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < rows && k < K) v = *reinterpret_cast<const f32x4*>(G + (size_t)row * ld + k);
+        r[i] = v;
+    }
+}
+__device__ __forceinline__ void st_rows_s(_Float16* Shi, _Float16* Slo, int tid, const f32x4 (&r)[4], float scale) {
+    const int rr = tid >> 3, c4 = (tid & 7) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f16x4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float sv = r[i][e] * scale;
+            const _Float16 hh = (_Float16)sv;
+            h[e] = hh;
+            l[e] = (_Float16)((sv - (float)hh) * SPLIT_LO);
+        }
+        *reinterpret_cast<f16x4*>(Shi + (rr + 32 * i) * NLD + c4) = h;
+        *reinterpret_cast<f16x4*>(Slo + (rr + 32 * i) * NLD + c4) = l;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_nt_split_kernel(GemmNT g) {
+    __shared__ __attribute__((aligned(16))) _Float16 lds[2 * 4 * 128 * NLD];       // [buf][A hi, A lo, W hi, W lo][128][40]: 80 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+    const int panels = (ntm - xcd + 7) / 8, ntile = panels * ntn;
+    const int nk = (g.K + NKT - 1) / NKT;
+    const float sa = lob_split_scale(*g.amax_a), sw_ = lob_split_scale(*g.amax_w);
+    const float r_hh = 1.f / (sa * sw_), r_sm = r_hh * (1.f / SPLIT_LO);
+
+    f32x4 ra[4], rw[4];
+    auto load = [&](int m0, int n0, int k0) {
+        ld_rows_s(g.A, g.lda, m0, g.M, k0, g.K, tid, ra);
+        ld_rows_s(g.W, g.ldw, n0, g.N, k0, g.K, tid, rw);
+    };
+    auto store = [&](int b) {
+        _Float16* base = lds + b * 4 * 128 * NLD;
+        st_rows_s(base, base + 128 * NLD, tid, ra, sa);
+        st_rows_s(base + 2 * 128 * NLD, base + 3 * 128 * NLD, tid, rw, sw_);
+    };
+    int it = slot;
+    if (it >= ntile) return;
+    int m0 = ((it / ntn) * 8 + xcd) * BM, n0 = (it % ntn) * BN;
+    load(m0, n0, 0);
+    while (true) {
+        f32x16 acc[2][2], asm_[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; asm_[i][j][r] = 0.f; }
+        store(0);
+        __syncthreads();
+        int buf = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) load(m0, n0, (kt + 1) * NKT);
+            const _Float16* base = lds + buf * 4 * 128 * NLD;
+            const _Float16* ap = base + (64 * wr + (lane & 31)) * NLD + 8 * (lane >> 5);
+            const _Float16* bp = base + 2 * 128 * NLD + (64 * wc + (lane & 31)) * NLD + 8 * (lane >> 5);
+#pragma unroll
+            for (int ks = 0; ks < NKT / 16; ++ks) {
+                f16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    ah[i] = *reinterpret_cast<const f16x8*>(ap + 32 * i * NLD + 16 * ks);
+                    al[i] = *reinterpret_cast<const f16x8*>(ap + 128 * NLD + 32 * i * NLD + 16 * ks);
+                    bh[i] = *reinterpret_cast<const f16x8*>(bp + 32 * i * NLD + 16 * ks);
+                    bl[i] = *reinterpret_cast<const f16x8*>(bp + 128 * NLD + 32 * i * NLD + 16 * ks);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = mfma_h(ah[i], bh[j], acc[i][j]);
+                        asm_[i][j] = mfma_h(ah[i], bl[j], asm_[i][j]);
+                        asm_[i][j] = mfma_h(al[i], bh[j], asm_[i][j]);
+                    }
+            }
+            if (kt + 1 < nk) store(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+        const int nit = it + nslot;
+        const bool more = nit < ntile;
+        const int cm0 = m0, cn0 = n0;
+        if (more) {                                   // the next tile's first operand tiles are requested before this tile's stores
+            m0 = ((nit / ntn) * 8 + xcd) * BM; n0 = (nit % ntn) * BN;
+            load(m0, n0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = cn0 + 64 * wc + 32 * j + (lane & 31);
+                if (col >= g.N) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = cm0 + 64 * wr + 32 * i + acc_row(r, lane);
+                    if (row < g.M) g.C[(size_t)row * g.ldc + col] = acc[i][j][r] * r_hh + asm_[i][j][r] * r_sm;
+                }
+            }
+        if (!more) break;
+        it = nit;
+    }
+}
+
 // out[n] += sum_m A[m][n]  (bias gradients).  Block = 256 threads = 64 column-lanes x 4 row-groups.
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A, int lda, int M, int N,
                                                      int rows_per_block, float* __restrict__ out) {
@@ -624,7 +883,11 @@ extern "C" int lob_gemm_nt_f32_split(const float* A, int lda, const float* W, in
     long gsz = 512;
     const long tiles = (long)ntm * ntn;
     if (gsz > tiles) gsz = ((tiles + 7) / 8) * 8;
-    hipLaunchKernelGGL((gemm_nt_dma_f32_kernel<0, true>), dim3((unsigned)gsz), dim3(256), 0, (hipStream_t)stream, g);
+    // LOB_VAR_F32_SPLIT = 2: the twin that splits at every fragment read (LDS-DMA'd fp32 tiles)
+    if (lob_variant(LOB_VAR_F32_SPLIT) == 2)
+        hipLaunchKernelGGL((gemm_nt_dma_f32_kernel<0, true>), dim3((unsigned)gsz), dim3(256), 0, (hipStream_t)stream, g);
+    else
+        hipLaunchKernelGGL(gemm_nt_split_kernel, dim3((unsigned)gsz), dim3(256), 0, (hipStream_t)stream, g);
     LOB_CHECK_LAUNCH();
     return 0;
 }
@@ -681,13 +944,26 @@ extern "C" int lob_gemm_tn_f32_split(const float* A, int lda, const float* B, in
     if (lda < M || ldb < N || ldc < N) return LOB_E_SHAPE;
     if (!(aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0) && (M % 4 == 0) && (N % 4 == 0))) return LOB_E_SHAPE;
     const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    if (lob_variant(LOB_VAR_F32_SPLIT) == 2) {          // the twin: split at every fragment read (tests, A/B)
+        int nchunk = (2048 + tiles - 1) / tiles;
+        int kchunk = (Kc + nchunk - 1) / nchunk;
+        kchunk = ((kchunk + 31) / 32) * 32;
+        if (kchunk < 256) kchunk = 256;
+        nchunk = (Kc + kchunk - 1) / kchunk;
+        GemmTN g{A, B, C, lda, ldb, ldc, M, N, Kc, kchunk, amax_a, amax_b};
+        hipLaunchKernelGGL((gemm_tn_kernel<true, true>), dim3((unsigned)(tiles * nchunk)), dim3(256), 0, (hipStream_t)stream, g);
+        LOB_CHECK_LAUNCH();
+        return 0;
+    }
+    // split once while staging; the chunks of one contraction range sit 8 apart in blockIdx (one XCD: shared source tiles)
     int nchunk = (2048 + tiles - 1) / tiles;
     int kchunk = (Kc + nchunk - 1) / nchunk;
-    kchunk = ((kchunk + 31) / 32) * 32;
-    if (kchunk < 256) kchunk = 256;
+    kchunk = ((kchunk + STK - 1) / STK) * STK;
+    if (kchunk < 512) kchunk = 512;
     nchunk = (Kc + kchunk - 1) / kchunk;
-    GemmTN g{A, B, C, lda, ldb, ldc, M, N, Kc, kchunk, amax_a, amax_b};
-    hipLaunchKernelGGL((gemm_tn_kernel<true, true>), dim3((unsigned)(tiles * nchunk)), dim3(256), 0, (hipStream_t)stream, g);
+    const int nchunk8 = ((nchunk + 7) / 8) * 8;
+    GemmTNS g{A, B, C, lda, ldb, ldc, M, N, Kc, kchunk, tiles, amax_a, amax_b};
+    hipLaunchKernelGGL(gemm_tn_split_kernel, dim3((unsigned)(tiles * nchunk8)), dim3(256), 0, (hipStream_t)stream, g);
     LOB_CHECK_LAUNCH();
     return 0;
 }

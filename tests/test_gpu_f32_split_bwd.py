@@ -43,6 +43,9 @@ def test_split_nt_gemm_vs_float64(dev, M, K, N, scale):
     # a loose bound (x 8: pre-scales are powers of two) changes nothing beyond rounding
     out8 = ops.gemm_nt(a, w, amax=(amax[0] * 7.9, amax[1] * 3.0))
     assert (out8.double() - ref).abs().max().item() / mx < 4e-6
+    with _lib.variant(F32_SPLIT=2):                    # the twin that splits at every fragment read
+        twin = ops.gemm_nt(a, w, amax=amax)
+    assert (twin.double() - ref).abs().max().item() / mx < 2e-6 and (twin - out).abs().max().item() <= 2e-6 * mx
 
 
 @pytest.mark.parametrize("Kc,M,N,scale", [(16384, 1024, 256, 1e-5), (4096 + 32, 512, 128, 2e-3)])
@@ -61,6 +64,11 @@ def test_split_tn_gemm_vs_float64(dev, Kc, M, N, scale):
     assert e_split < 3e-6 and e_split < 4 * e_exact + 3e-7, (e_split, e_exact)
     ops.gemm_tn(a, b, out, amax=(a.abs().max().reshape(1), b.abs().max().reshape(1)))       # accumulates
     assert (out.double() - 2 * ref).abs().max().item() / mx < 6e-6
+    from lstm_ode_bci_amd import _lib
+    twin = torch.zeros((M, N), device=dev)
+    with _lib.variant(F32_SPLIT=2):                    # the twin that splits at every fragment read
+        ops.gemm_tn(a, b, twin, amax=(a.abs().max().reshape(1), b.abs().max().reshape(1)))
+    assert (twin.double() - ref).abs().max().item() / mx < 3e-6
 
 
 @pytest.mark.parametrize("T,Bp,D,dyscale", [(24, 64, 2, 1e-3), (5, 32, 1, 1e-9), (40, 96, 2, 300.0)])

@@ -33,7 +33,11 @@ for K in (256, 128):
     with _lib.variant(F32_SPLIT=0):
         e_nt = timeit(lambda: ops.gemm_nt(dP, wt))
         e_tn = timeit(lambda: ops.gemm_tn(dP, x, dw))
-    print(f"K_in={K}: dX split {s_nt:.3f} ms (exact {e_nt:.3f}) | dW_ih split {s_tn:.3f} ms (exact {e_tn:.3f})", flush=True)
+    with _lib.variant(F32_SPLIT=2):
+        f_nt = timeit(lambda: ops.gemm_nt(dP, wt, amax=(amax_dp, aw)))
+        f_tn = timeit(lambda: ops.gemm_tn(dP, x, dw, amax=(amax_dp, one)))
+    print(f"K_in={K}: dX split {s_nt:.3f} ms (split at fragment read {f_nt:.3f}, exact {e_nt:.3f}) | dW_ih split {s_tn:.3f} ms "
+          f"(fragment {f_tn:.3f}, exact {e_tn:.3f})", flush=True)
 y = rnd((rows, D * H), 0.5)
 dwh = torch.zeros((4 * H, H), device=dev)
 a_sl, y_sl = dP[:, :4 * H], y[:, :H]
