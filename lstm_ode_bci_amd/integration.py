@@ -227,7 +227,10 @@ class LSTMODEIntegration:
         key = (nb,) + shape + (str(dev),)
         if getattr(self, "_h2d_key", None) != key:
             self._h2d_key = key
-            self._h2d_stream = torch.cuda.Stream(device=dev)
+            # high priority: HIP maps streams onto a few hardware queues, and a copy stream that lands on the compute
+            # stream's queue has its copies dispatched BEHIND the kernels already queued there (seen as the GPU idling for
+            # one H2D per chunk, tools/api_probe.py); priority streams get queues of their own
+            self._h2d_stream = torch.cuda.Stream(device=dev, priority=-1)
             self._h2d_stage = [torch.empty((nb,) + shape, dtype=torch.float32).pin_memory() for _ in range(2)]
             self._h2d_dbuf = [torch.empty((nb,) + shape, dtype=torch.float32, device=dev) for _ in range(2)]
         copy_stream, stage, dbuf = self._h2d_stream, self._h2d_stage, self._h2d_dbuf
@@ -311,7 +314,7 @@ class LSTMODEIntegration:
         key = (nb, steps, str(dev))
         if getattr(self, "_d2h_key", None) != key:
             self._d2h_key = key
-            self._d2h_stream = torch.cuda.Stream(device=dev)
+            self._d2h_stream = torch.cuda.Stream(device=dev, priority=-1)
             self._d2h_stage = [(torch.empty((nb, steps, 3), dtype=torch.float64).pin_memory(),
                                 torch.empty((nb, 2), dtype=torch.float32).pin_memory(),
                                 torch.empty((nb,), dtype=torch.int64).pin_memory()) for _ in range(2)]

@@ -7,7 +7,7 @@
 #                                              them into profiles/<tag>_*.csv here, after the call)
 set -e -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}
-TAG=${1:-r03}
+TAG=${1:-r04}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
@@ -26,6 +26,8 @@ for H in 128 256; do
 done
 # the fp32 forward (configs[1] arithmetic) for its own kernel table
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_fwd32 -o run -- python3 $R/bench.py --mode fwd --precision fp32 --steps 7 --warmup 2 --no-extra --no-cpu-baseline > $O/stats_fwd32.log 2>&1
+# the fp32 training step (the fp16-split backward kernels of round 4)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_train32 -o run -- python3 $R/bench.py --mode train --precision fp32 --steps 4 --warmup 2 --no-extra --no-cpu-baseline --no-roofline > $O/stats_train32.log 2>&1
 cd $R
 # keep only the small summaries (the traces are tens of MB)
 find $O -name "*kernel_trace.csv" -delete
@@ -36,4 +38,5 @@ timeout -k 10 200 python3 bench.py --steps 6 --warmup 2 --mode train --precision
 timeout -k 10 200 python3 bench.py --steps 10 --warmup 3 --mode fwd --precision mixed --no-extra --no-cpu-baseline > $O/b_fwd_mixed.json 2> /dev/null
 timeout -k 10 200 python3 bench.py --steps 6 --warmup 2 --hidden 256 --no-extra --no-cpu-baseline > $O/b_train_h256.json 2> /dev/null
 python3 tools/latency_probe.py > $O/latency_probe.txt 2>&1
+{ python3 tools/api_probe.py 3 300; python3 tools/api_probe.py 8 300; } 2>&1 | grep -v amdgpu.ids > $O/api_probe.txt
 echo done > $O/done.txt

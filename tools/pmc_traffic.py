@@ -27,10 +27,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # bench label -> (precision, substring of the profiler's kernel name)
 KERNELS = {
-    "lstm_rec_fwd(save)": [("mixed", "lstm_rec_fwd_h128_bf16_s16_kernelILb1ELb1ELb0ELb0"), ("fp32", "lstm_rec_fwd_h128_s16_kernel<true")],
+    "lstm_rec_fwd(save)": [("mixed", "lstm_rec_fwd_h128_bf16_s16_kernelILb1ELb0ELb1ELb1E"), ("fp32", "lstm_rec_fwd_h128_s16_kernel<true")],
     "lstm_rec_fwd": [("mixed", "lstm_rec_fwd_h128_bf16_s16_kernelILb0ELb0"), ("fp32", "lstm_rec_fwd_h128_split_kernel<false")],
     "lstm_rec_bwd": [("mixed", "lstm_rec_bwd_h128_bf16_s16_dma_kernel"), ("fp32", "lstm_rec_bwd_h128_kernel")],
-    "gate_gemm_x(K=256)": [("mixed", "gate_gemm_ws_kernel<256>"), ("fp32", "gate_gemm_ws_split_kernel<256>")],
+    "gate_gemm_x(K=256)": [("mixed", "gate_gemm_ws_kernel<256, 0, 128>"), ("fp32", "gate_gemm_ws_split_kernel<256>")],
     "gemm_nt(dX)": [("mixed", "dx_ksplit_kernel<4>")],
     "lstm_dw(dW_ih+dW_hh)": [("mixed", "lstm_dw_h128_kernel<256>")],
 }
