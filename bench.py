@@ -338,31 +338,36 @@ def cpu_baseline(mode, sd, forecast_steps=300, H=128, budget_s=100.0):
                     m(xt, return_attention=True)
         return fn
 
-    # thread count: quick probe at B = 32
-    probe = {}
-    for nt in sorted({min(ncores, n) for n in (8, 16, 32, 64)}):
-        torch.set_num_threads(nt)
-        ts = _time_cpu(one(32), budget_s=budget_s / 12, min_iters=2, warmup=1)
-        probe[nt] = 32 / min(ts)
-    best_n = max(probe, key=probe.get)
+    # thread count: probed at EACH batch size that is reported (the B = 32 optimum was reused at B = 256)
+    probe, best_nb = {}, {}
+    for Bc in (32, 256):
+        probe[Bc] = {}
+        for nt in sorted({min(ncores, n) for n in (8, 16, 32, 64)}):
+            torch.set_num_threads(nt)
+            ts = _time_cpu(one(Bc), budget_s=budget_s / (12 if Bc == 32 else 8), min_iters=2, warmup=1)
+            probe[Bc][nt] = Bc / min(ts)
+        best_nb[Bc] = max(probe[Bc], key=probe[Bc].get)
     table = {}
-    share = budget_s * 0.8 / 4
-    for nt, tag in ((best_n, "best_n"), (1, "n1")):
-        torch.set_num_threads(nt)
+    share = budget_s * 0.6 / 4
+    for tag in ("best_n", "n1"):
         for Bc in (32, 256):
+            nt = best_nb[Bc] if tag == "best_n" else 1
+            torch.set_num_threads(nt)
             ts = _time_cpu(one(Bc), budget_s=share)
             table[f"{tag}_B{Bc}"] = {"threads": nt, "batch": Bc, "iters": len(ts), "windows_per_s_min_time": Bc / min(ts),
                                      "windows_per_s_median": Bc / float(np.median(ts))}
-    torch.set_num_threads(best_n)
     bestk = max((k for k in table if k.startswith("best_n")), key=lambda k: table[k]["windows_per_s_min_time"])
     best = table[bestk]["windows_per_s_min_time"]
+    best_n = table[bestk]["threads"]
+    torch.set_num_threads(best_n)
     what = (("fwd+bwd train-mode (dropout on, weighted CE)" if mode == "train" else "fwd eval-mode no_grad") +
-            f", H={H}, B=32 and 256, n=1 and n={best_n} threads (best of 8/16/32/64 probed at B=32), 2 warm-ups + "
+            f", H={H}, B=32 and 256, n=1 and best-n threads (best of 8/16/32/64 probed at each B: {best_nb[32]} at B=32, "
+            f"{best_nb[256]} at B=256), 2 warm-ups + "
             f"{'/'.join(str(table[k]['iters']) for k in table)} timed iterations; value = best (min-time) rate, {bestk}")
     out = {"value": best, "median": table[bestk]["windows_per_s_median"], "unit": "windows/s", "cores": best_n,
            "kind": "port", "host_cpus": os.cpu_count(), "cpu_model": _cpu_model_name(),
            "n1_value": max(table["n1_B32"]["windows_per_s_min_time"], table["n1_B256"]["windows_per_s_min_time"]),
-           "table": table, "thread_probe_B32": probe}
+           "table": table, "thread_probe": {f"B{b}": v for b, v in probe.items()}}
     if mode == "coupled":
         from oracle import restatement as R
         n = 256
