@@ -135,7 +135,7 @@ def _check_build_id(l):
 # kernel-variant switches (include/lob.h LOB_VAR_*): test-only
 VAR = {"REC_BWD_DMA": 0, "NT_DMA": 1, "DMA_TILE": 2, "DMA_KT": 3, "NT_ADEEP": 4, "GATE_WS": 5, "REC_BF16_ROWS": 6,
        "F32_DMA": 7, "REC_FWD_ROWS": 8, "LN_LPR": 9, "NT_WGS": 10, "NT_TK": 11, "NT_STAGGER": 12, "FUSED_DW": 13,
-       "F32_SPLIT": 14, "H256_LDSW": 15, "DX_KSPLIT": 16, "REC_FEW": 17, "GEMM_PP": 18}
+       "F32_SPLIT": 14, "H256_LDSW": 15, "DX_KSPLIT": 16, "REC_FEW": 17, "GEMM_PP": 18, "REC_HALF": 19}
 
 
 def get_variant(name):

@@ -34,6 +34,7 @@ const VarDef kVars[LOB_VAR_COUNT] = {
     {"LOB_REC_FEW", 1},       // LOB_VAR_REC_FEW
     {"LOB_GEMM_PP", 517},     // LOB_VAR_GEMM_PP: dX (bit 0, on v_mfma_16x16x32: bit 9) + weight gradients (bit 2); the gate GEMM
                               // (bit 1) stays weight-stationary: measured faster
+    {"LOB_REC_HALF", 1},      // LOB_VAR_REC_HALF
 };
 std::atomic<int> g_vals[LOB_VAR_COUNT];
 std::atomic<int> g_init{0};

@@ -97,7 +97,7 @@ template <bool SAVE, bool YF32, bool Y16, bool DROP, typename PE, typename CE, b
 __global__ __launch_bounds__(256, 2) void lstm_rec_fwd_h128_bf16_s16_kernel(
     PE* __restrict__ P, const float* __restrict__ Whh, float* __restrict__ Y,
     CE* __restrict__ Csave, __bf16* __restrict__ Y16p, __bf16* __restrict__ Yd, float drop_p, uint64_t seed,
-    int T, int Bp, int nvalid) {
+    int T, int Bp, int nvalid, int half = 0) {
     static_assert(!FEW || (!SAVE && !DROP), "FEW: inference only");
     __shared__ __attribute__((aligned(16))) __bf16 hs[2 * 16 * HB_LD];
     // fp32 h of the step (last layer only), staged so that it leaves as 32-B-per-lane row segments instead of eight
@@ -107,8 +107,14 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_fwd_h128_bf16_s16_kernel(
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int d = blockIdx.y, D = gridDim.y, NBT = Bp >> 5;
     const int c16 = lane & 15, rq = lane >> 4;
-    const int bt = blockIdx.x >> 1, s0 = blockIdx.x & 1;      // 32-row fragment block, 16-row half
-    const int nj = FEW ? nvalid - (bt * 32 + s0 * 16) : 4;   // FEW: registers j < nj hold windows (nvalid < 4)
+    // FEW with half != 0 (round 4, LOB_VAR_REC_HALF): TWO workgroups share each 16-row tile, workgroup jh runs the cell
+    // update of registers j in {2 jh, 2 jh + 1} only and stores only those rows -- for batches whose full tiles would
+    // occupy a quarter of the CUs or less: twice the workgroups, half the activations on each step's serial chain
+    const int bxx = (FEW && half) ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+    const int jh = (FEW && half) ? (int)(blockIdx.x & 1) : 0;
+    const int bt = bxx >> 1, s0 = bxx & 1;                    // 32-row fragment block, 16-row half
+    const int nj = FEW ? (half ? 2 * jh + 2 : nvalid - (bt * 32 + s0 * 16)) : 4;   // FEW: registers jlo <= j < nj are updated
+    const int jlo = (FEW && half) ? 2 * jh : 0;
     if (FEW && nj <= 0) {                                     // a tile of padding rows: zeros for every step
         const int row = tid >> 4, c8 = (tid & 15) * 8;
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -182,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_fwd_h128_bf16_s16_kernel(
         for (int cbu = 0; cbu < 2; ++cbu)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (FEW && j >= nj) continue;              // wave-uniform: a register of padding rows only
+                if (FEW && (j >= nj || j < jlo)) continue; // wave-uniform: a register of padding rows / of the partner workgroup
                 const float ig = fast_sigmoid(acc[0][cbu][j]);
                 const float fg = fast_sigmoid(acc[1][cbu][j]);
                 const float gg = fast_tanh(acc[2][cbu][j]);
@@ -209,14 +215,15 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_fwd_h128_bf16_s16_kernel(
             }
         }
         __syncthreads();
-        if (YF32) {
+        const bool mine = !(FEW && half) || (((tid >> 4) & 3) >> 1) == jh;      // half tiles: only this workgroup's rows leave
+        if (YF32 && mine) {
             const int row = tid >> 4, c8 = (tid & 15) * 8;
             const float* ysrc = yfs + (cur ^ 1) * 16 * YF_LD + row * YF_LD + c8;
             float* dst = Y + ((size_t)t * Bp + row0 + row) * DH + d * H + c8;
             *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(ysrc);
             *reinterpret_cast<f32x4*>(dst + 4) = *reinterpret_cast<const f32x4*>(ysrc + 4);
         }
-        if (Y16 || DROP) {       // h_t is complete in hs[cur ^ 1]: emit the bf16 row segments (16 rows x 256 B)
+        if ((Y16 || DROP) && mine) {       // h_t is complete in hs[cur ^ 1]: emit the bf16 row segments (16 rows x 256 B)
             const __bf16* hsrc = hs + (cur ^ 1) * 16 * HB_LD;
             const int row = tid >> 4, c8 = (tid & 15) * 8;
             const bf16x8 hv = *reinterpret_cast<const bf16x8*>(hsrc + row * HB_LD + c8);
@@ -664,6 +671,17 @@ int lob_rec_fwd_bf16_s16(void* P, int pg_bf16, const float* Whh, float* Y, void*
         0, s, reinterpret_cast<__bf16*>(P), Whh, Y, (float*)nullptr, y16, yd, 0.f, (uint64_t)0, T, Bp, nvalid)
         if (Y && y16) LOB_FEW(true, true); else if (Y) LOB_FEW(true, false); else LOB_FEW(false, true);
 #undef LOB_FEW
+        LOB_CHECK_LAUNCH();
+        return 0;
+    }
+    // inference on few full tiles (at most a quarter of the CUs would hold one): two workgroups per tile (the FEW kernel's
+    // register skipping with a fixed half of the registers each)
+    if (!save && !yd && pg_bf16 && (Bp / 16) * D <= 64 && lob_variant(LOB_VAR_REC_HALF)) {
+        const dim3 grid2(Bp / 8, D);
+#define LOB_HALF(YF, Y6) hipLaunchKernelGGL((lstm_rec_fwd_h128_bf16_s16_kernel<false, YF, Y6, false, __bf16, float, true>), grid2, block, \
+        0, s, reinterpret_cast<__bf16*>(P), Whh, Y, (float*)nullptr, y16, yd, 0.f, (uint64_t)0, T, Bp, Bp, 1)
+        if (Y && y16) LOB_HALF(true, true); else if (Y) LOB_HALF(true, false); else LOB_HALF(false, true);
+#undef LOB_HALF
         LOB_CHECK_LAUNCH();
         return 0;
     }

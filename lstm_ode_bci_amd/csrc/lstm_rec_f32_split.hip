@@ -40,10 +40,18 @@ __device__ __forceinline__ f32x4 mfma16_f16(f16x8 a, f16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
-template <bool SAVE>
+// HALF (round 4): when the 16-row tiles of a batch fill no more than a quarter of the CUs (Bp <= 512 with two directions) TWO
+// workgroups share each tile: a lane of the MFMA's D layout holds rows 4 rq + j, j < 4, of its column; workgroup jh takes
+// j in {2 jh, 2 jh + 1}, i.e. tile rows {0,1,4,5,8,9,12,13} or {2,3,6,7,...}.  Twice the workgroups (every CU busy), half the
+// cell-update work per lane and step (the step is a serial chain: MFMAs -> activations -> LDS -> barrier, and the
+// activations are a third of it); the other half of its h tile stays zero, the MFMAs on it are wasted.  Same arithmetic
+// per row: bit-identical to the full-tile kernel (tests/test_gpu_twins.py).  LOB_VAR_REC_HALF = 0 keeps full tiles.
+template <bool SAVE, bool HALF = false>
 __global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h128_split_kernel(
     float* __restrict__ P, const float* __restrict__ Whh, float* __restrict__ Y, float* __restrict__ Csave, int T, int Bp,
     const float* __restrict__ range) {
+    constexpr int NJ = HALF ? 2 : 4;
+    typedef float fvec __attribute__((ext_vector_type(NJ)));
     __shared__ __attribute__((aligned(16))) _Float16 hs[2 * 2 * 16 * HB_LD];      // [buf][split][16 rows][HB_LD]
     __shared__ __attribute__((aligned(16))) float yfs[2 * 16 * YF_LD];            // fp32 h of the step, for wide stores
     const int tid = threadIdx.x, lane = tid & 63;
@@ -51,7 +59,9 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h128_split_kernel(
     const int wcol = w8 >> 1, cbu = w8 & 1;
     const int d = blockIdx.y, D = gridDim.y, NBT = Bp >> 5;
     const int c16 = lane & 15, rq = lane >> 4;
-    const int bt = blockIdx.x >> 1, s0 = blockIdx.x & 1;      // 32-row fragment block, 16-row half
+    const int bx = HALF ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+    const int jb = HALF ? 2 * (int)(blockIdx.x & 1) : 0;      // first of this workgroup's rows j
+    const int bt = bx >> 1, s0 = bx & 1;                      // 32-row fragment block, 16-row half
     const int col = 32 * wcol + 16 * cbu + c16;               // this lane's hidden column
 
     // weight pre-scale from the range of this direction's W_hh (lob.h; h keeps 2^8: |h| < 1);
@@ -81,31 +91,33 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h128_split_kernel(
         }
     }
     for (int i = tid; i < 2 * 2 * 16 * HB_LD; i += 512) hs[i] = (_Float16)0.f;
-    float c[4] = {0.f, 0.f, 0.f, 0.f};
+    float c[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) c[j] = 0.f;
 
     // fragment addressing (lob.h): gate g, 16-row half s0: rows 4 rq .. + 3 of column `col` are ONE float4 at
-    // [wcol][g][q = 2 s0 + (rq >> 1)][lane' = (rq & 1) * 32 + 16 cbu + c16][0..3]
+    // [wcol][g][q = 2 s0 + (rq >> 1)][lane' = (rq & 1) * 32 + 16 cbu + c16][0..3]  (HALF: its components jb, jb + 1)
     const size_t pstep = (size_t)NBT * 16 * 1024, cstep = (size_t)NBT * 4096;
-    const unsigned lane_p = (unsigned)((2 * s0 + (rq >> 1)) * 256 + ((rq & 1) * 32 + 16 * cbu + c16) * 4);
+    const unsigned lane_p = (unsigned)((2 * s0 + (rq >> 1)) * 256 + ((rq & 1) * 32 + 16 * cbu + c16) * 4 + jb);
     float* pblk = P + ((size_t)d * T * NBT + bt) * 16 * 1024 + (size_t)wcol * 4096 + lane_p;
     float* cblk = SAVE ? Csave + ((size_t)d * T * NBT + bt) * 4096 + (size_t)wcol * 1024 + lane_p : nullptr;
     const int DH = D * H;
     const int t_first = d ? T - 1 : 0, dt = d ? -1 : 1;
     const int row0 = bt * 32 + s0 * 16;
 
-    f32x4 pa[4], pb[4];            // P two steps ahead
-    auto load_p = [&](int t, f32x4 (&dst)[4]) {
+    fvec pa[4], pb[4];            // P two steps ahead
+    auto load_p = [&](int t, fvec (&dst)[4]) {
         const float* p = pblk + (size_t)t * pstep;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) dst[g] = *reinterpret_cast<const f32x4*>(p + g * 1024);
+        for (int g = 0; g < 4; ++g) dst[g] = *reinterpret_cast<const fvec*>(p + g * 1024);
     };
     load_p(t_first, pa);
     if (T > 1) load_p(t_first + dt, pb);
     __syncthreads();
 
-    auto one_step = [&](int step, f32x4 (&praw)[4], int cur) {
+    auto one_step = [&](int step, fvec (&praw)[4], int cur) {
         const int t = t_first + dt * step;
-        f32x4 pz[4];
+        fvec pz[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) pz[g] = praw[g];
         if (step + 2 < T) load_p(t + 2 * dt, praw);
@@ -124,39 +136,56 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h128_split_kernel(
                 asm_[g] = mfma16_f16(al, whi[g][ks], asm_[g]);
             }
         }
-        _Float16* hnext = hs + (cur ^ 1) * 2 * 16 * HB_LD + 4 * rq * HB_LD + col;
-        float* ynext = yfs + (cur ^ 1) * 16 * YF_LD + 4 * rq * YF_LD + col;
-        f32x4 gi, gf, gg_, go;
+        _Float16* hnext = hs + (cur ^ 1) * 2 * 16 * HB_LD + (4 * rq + jb) * HB_LD + col;
+        float* ynext = yfs + (cur ^ 1) * 16 * YF_LD + (4 * rq + jb) * YF_LD + col;
+        fvec gi, gf, gg_, go;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float zi = pz[0][j] + (ahh[0][j] * R_HH + asm_[0][j] * R_SM);
-            const float zf = pz[1][j] + (ahh[1][j] * R_HH + asm_[1][j] * R_SM);
-            const float zg = pz[2][j] + (ahh[2][j] * R_HH + asm_[2][j] * R_SM);
-            const float zo = pz[3][j] + (ahh[3][j] * R_HH + asm_[3][j] * R_SM);
+        for (int jj = 0; jj < NJ; ++jj) {
+            // accumulator component of row 4 rq + jb + jj (HALF: jb is 0 or 2 -- a select, not a dynamic register index)
+            const int ja = jj;
+            float a_hh[4], a_sm[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if constexpr (HALF) {
+                    a_hh[g] = jb ? ahh[g][2 + ja] : ahh[g][ja];
+                    a_sm[g] = jb ? asm_[g][2 + ja] : asm_[g][ja];
+                } else {
+                    a_hh[g] = ahh[g][ja]; a_sm[g] = asm_[g][ja];
+                }
+            }
+            const float zi = pz[0][jj] + (a_hh[0] * R_HH + a_sm[0] * R_SM);
+            const float zf = pz[1][jj] + (a_hh[1] * R_HH + a_sm[1] * R_SM);
+            const float zg = pz[2][jj] + (a_hh[2] * R_HH + a_sm[2] * R_SM);
+            const float zo = pz[3][jj] + (a_hh[3] * R_HH + a_sm[3] * R_SM);
             const float ig = fast_sigmoid(zi), fg = fast_sigmoid(zf), gg = fast_tanh(zg), og = fast_sigmoid(zo);
-            c[j] = __builtin_fmaf(fg, c[j], ig * gg);
-            const float h = og * fast_tanh(c[j]);
+            c[jj] = __builtin_fmaf(fg, c[jj], ig * gg);
+            const float h = og * fast_tanh(c[jj]);
             _Float16 hh, hl;
             split2(h, hh, hl);
-            hnext[j * HB_LD] = hh;
-            hnext[16 * HB_LD + j * HB_LD] = hl;
-            ynext[j * YF_LD] = h;
-            if (SAVE) { gi[j] = ig; gf[j] = fg; gg_[j] = gg; go[j] = og; }
+            hnext[jj * HB_LD] = hh;
+            hnext[16 * HB_LD + jj * HB_LD] = hl;
+            ynext[jj * YF_LD] = h;
+            if (SAVE) { gi[jj] = ig; gf[jj] = fg; gg_[jj] = gg; go[jj] = og; }
         }
         if (SAVE) {
             float* p = pblk + (size_t)t * pstep;
-            *reinterpret_cast<f32x4*>(p) = gi;
-            *reinterpret_cast<f32x4*>(p + 1024) = gf;
-            *reinterpret_cast<f32x4*>(p + 2048) = gg_;
-            *reinterpret_cast<f32x4*>(p + 3072) = go;
-            f32x4 cv = {c[0], c[1], c[2], c[3]};
-            *reinterpret_cast<f32x4*>(cblk + (size_t)t * cstep) = cv;
+            *reinterpret_cast<fvec*>(p) = gi;
+            *reinterpret_cast<fvec*>(p + 1024) = gf;
+            *reinterpret_cast<fvec*>(p + 2048) = gg_;
+            *reinterpret_cast<fvec*>(p + 3072) = go;
+            fvec cv;
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) cv[jj] = c[jj];
+            *reinterpret_cast<fvec*>(cblk + (size_t)t * cstep) = cv;
         }
         __syncthreads();
-        {   // h_t is complete in yfs[cur ^ 1]: 16 rows x 512 B leave as one 16-B store per thread
-            const int row = tid >> 5, c4 = (tid & 31) * 4;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(yfs + (cur ^ 1) * 16 * YF_LD + row * YF_LD + c4);
-            *reinterpret_cast<f32x4*>(Y + ((size_t)t * Bp + row0 + row) * DH + d * H + c4) = v;
+        {   // h_t is complete in yfs[cur ^ 1]: the tile's rows (HALF: this workgroup's 8) x 512 B leave as one 16-B store per thread
+            const int r8 = tid >> 5, c4 = (tid & 31) * 4;
+            const int row = HALF ? 4 * (r8 >> 1) + jb + (r8 & 1) : r8;
+            if (!HALF || tid < 256) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(yfs + (cur ^ 1) * 16 * YF_LD + row * YF_LD + c4);
+                *reinterpret_cast<f32x4*>(Y + ((size_t)t * Bp + row0 + row) * DH + d * H + c4) = v;
+            }
         }
     };
 
@@ -355,9 +384,18 @@ namespace {
 // Internal entry point used by lob_lstm_rec_fwd_f32 (lstm_rec_f32.hip): 16-row tiles, eight waves, grid Bp/16 x D.
 int lob_rec_fwd_split(float* P, const float* Whh, float* Y, float* Csave, int T, int Bp, int D, int save, const float* range,
                       hipStream_t s) {
-    const dim3 grid(Bp / 16, D), block(512);
-    if (save) hipLaunchKernelGGL((lstm_rec_fwd_h128_split_kernel<true>), grid, block, 0, s, P, Whh, Y, Csave, T, Bp, range);
-    else      hipLaunchKernelGGL((lstm_rec_fwd_h128_split_kernel<false>), grid, block, 0, s, P, Whh, Y, Csave, T, Bp, range);
+    // half tiles (two workgroups per 16-row tile) while full tiles would occupy at most a quarter of the 256 CUs: measured
+    // +10 % (B = 512) / +14 % (B = 256) on the fp32 forward; at B = 1024 (128 full tiles -> 256 half tiles) the per-step gain
+    // is lost again (-1 %: every CU busy, lower clock), so the switch-over sits at 64 tiles (tools/half_tile_ab.py)
+    const bool half = lob_variant(LOB_VAR_REC_HALF) != 0 && (Bp / 16) * D <= 64;
+    const dim3 grid(half ? Bp / 8 : Bp / 16, D), block(512);
+    if (half) {
+        if (save) hipLaunchKernelGGL((lstm_rec_fwd_h128_split_kernel<true, true>), grid, block, 0, s, P, Whh, Y, Csave, T, Bp, range);
+        else      hipLaunchKernelGGL((lstm_rec_fwd_h128_split_kernel<false, true>), grid, block, 0, s, P, Whh, Y, Csave, T, Bp, range);
+    } else {
+        if (save) hipLaunchKernelGGL((lstm_rec_fwd_h128_split_kernel<true>), grid, block, 0, s, P, Whh, Y, Csave, T, Bp, range);
+        else      hipLaunchKernelGGL((lstm_rec_fwd_h128_split_kernel<false>), grid, block, 0, s, P, Whh, Y, Csave, T, Bp, range);
+    }
     LOB_CHECK_LAUNCH();
     return 0;
 }

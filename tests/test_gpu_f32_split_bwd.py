@@ -125,3 +125,52 @@ def test_fp32_training_step_runs_the_split_backward_and_matches_the_exact_one(de
         if mx < 1e-9:
             continue
         assert (gs[k] - ge[k]).abs().max().item() <= 2e-5 * mx + 1e-9, (k, (gs[k] - ge[k]).abs().max().item(), mx)
+
+
+@pytest.mark.parametrize("T,Bp,D,save", [(20, 1024, 2, False), (7, 96, 2, True), (33, 32, 1, True), (256, 1024, 2, True)])
+def test_half_tile_recurrent_forward_is_bit_identical(dev, T, Bp, D, save):
+    """LOB_VAR_REC_HALF (round 4): below B = 2048 two workgroups share each 16-row tile of the fp32
+    recurrent forward (rows j < 2 / j >= 2 of the MFMA's D layout).  Same arithmetic per row: outputs, saved gates and cell
+    states equal the full-tile kernel's to the last bit."""
+    from lstm_ode_bci_amd import _lib, ops
+    H = 128
+    whh = _rnd((D, 4 * H, H), 0.08, dev, 15)
+    x = _rnd((T * Bp, H), 1.0, dev, 16)
+    wih = _rnd((D * 4 * H, H), 0.08, dev, 17)
+    bias = _rnd((D * 4 * H,), 0.1, dev, 18)
+    P0 = ops.gate_gemm_x(x, wih, bias, T, Bp, H, D, True, mixed=False, exact=True)
+    out = {}
+    for v in (1, 0):
+        P = P0.clone()
+        with _lib.variant(REC_HALF=v):
+            Y, Cs, _, _ = ops.lstm_rec_fwd(P, whh, T, Bp, H, D, save)
+        out[v] = (Y, Cs, P)
+    assert torch.equal(out[1][0], out[0][0])
+    if save:
+        assert torch.equal(out[1][1], out[0][1]) and torch.equal(out[1][2], out[0][2])
+    assert torch.isfinite(out[1][0]).all() and out[1][0].abs().max().item() > 0.01
+
+
+@pytest.mark.parametrize("T,B", [(20, 512), (9, 96), (33, 17), (256, 256)])
+def test_half_tile_mixed_inference_forward_is_bit_identical(dev, T, B):
+    """The mixed inference forward (the reference's GPU inference arithmetic, 06:349) on half tiles below B = 1024: whole
+    model under autocast + no_grad, LOB_VAR_REC_HALF = 1 against 0: logits and attention weights equal to the last bit (the
+    fp32 path's recurrent forward runs half tiles in the same call range: covered by the second comparison)."""
+    from lstm_ode_bci_amd import EnhancedLSTMModel, _lib
+    from lstm_ode_bci_amd import synthetic as syn
+    sd = syn.make_state_dict(61, 128, 3, 2, True)
+    x, _ = syn.make_windows(B, T, 61, seed=6)
+    m = EnhancedLSTMModel(61, 128, 3, 2, 0.4, True)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m = m.to(dev).eval()
+    xd = torch.from_numpy(x).to(dev)
+    res = {}
+    for v in (1, 0):
+        with _lib.variant(REC_HALF=v), torch.no_grad():
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                lm, am = m(xd, return_attention=True)
+            lf, af = m(xd, return_attention=True)
+        res[v] = (lm.clone(), am.clone(), lf.clone(), af.clone())
+    for a, b in zip(res[1], res[0]):
+        assert torch.equal(a, b)
+    assert torch.isfinite(res[1][0]).all()
