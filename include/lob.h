@@ -97,9 +97,10 @@ const char* lob_build_id(void);
                                   *    instantiations that compute garbage (16..64 = ablations, 1024 / 2048 = operand DMA alone,
                                   *    tools/pp_bench.py) exist only in builds with -DLOB_PP_DIAG; the product library ignores
                                   *    those bits                                                                                */
-#define LOB_VAR_REC_HALF     19  /* 1: recurrent forward kernels (H=128; fp32 split and mixed) put TWO workgroups on each 16-row tile
-                                  *    (rows j < 2 / j >= 2 of the MFMA's D layout) while full tiles would occupy at most a quarter of
-                                  *    the CUs (Bp <= 512 with two directions; the mixed kernel: inference only); 0: always full tiles (the twin, bit-identical)  */
+#define LOB_VAR_REC_HALF     19  /* recurrent forward kernels at H=128 (fp32 split; mixed: inference only) on few tiles: 1 = FOUR
+                                  *    workgroups share each 16-row tile (one row j of the MFMA's D layout each) up to 64 tiles
+                                  *    (B <= 512 with two directions), the mixed kernel two per tile up to 128 tiles; 2 / 4 force
+                                  *    that split up to 128 tiles (A/B); 0: always full tiles (the twin, bit-identical)       */
 #define LOB_VAR_COUNT        20
 int lob_debug_set_variant(int which, int value);
 int lob_debug_get_variant(int which);

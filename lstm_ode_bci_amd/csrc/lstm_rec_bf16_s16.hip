@@ -93,12 +93,22 @@ __device__ __forceinline__ void store_frag16(E* p, unsigned off, const f32x4 (&s
 // its 8 elements per lane (80 transcendentals).  The MFMA's D layout puts tile row 4 rq + j in register j, so with
 // nvalid rows only registers j < nvalid hold a window: the cell update of the other registers is skipped (their h
 // rows stay zero in LDS, so padding rows leave as zeros), and a tile without any window only writes zeros.
-template <bool SAVE, bool YF32, bool Y16, bool DROP, typename PE, typename CE, bool FEW = false>
+//
+// PARTS = 2 / 4 (round 4, inference, LOB_VAR_REC_HALF): that many workgroups share each 16-row tile; workgroup jh runs the
+// cell update of the registers j in [jh * 4 / PARTS, (jh + 1) * 4 / PARTS) only (its rows of the h tile; the others stay zero in
+// ITS tile, the MFMAs on them are wasted) and stores only those rows.  For batches whose full tiles would occupy a quarter
+// of the CUs or less: PARTS times the workgroups, 1 / PARTS of the activations on each step's serial chain (-14 % per mixed
+// forward at B <= 512 with PARTS = 4, -5 % at B = 1024 with PARTS = 2; tools/half_tile_ab.py).  The accumulator register of
+// a row is picked by selects on the workgroup-uniform jh, not by a branch per register as in FEW (a first version that
+// extended FEW's branches made the one-window call 16 % slower).  Bit-identical to full tiles.
+template <bool SAVE, bool YF32, bool Y16, bool DROP, typename PE, typename CE, bool FEW = false, int PARTS = 1>
 __global__ __launch_bounds__(256, 2) void lstm_rec_fwd_h128_bf16_s16_kernel(
     PE* __restrict__ P, const float* __restrict__ Whh, float* __restrict__ Y,
     CE* __restrict__ Csave, __bf16* __restrict__ Y16p, __bf16* __restrict__ Yd, float drop_p, uint64_t seed,
-    int T, int Bp, int nvalid, int half = 0) {
+    int T, int Bp, int nvalid) {
     static_assert(!FEW || (!SAVE && !DROP), "FEW: inference only");
+    static_assert(PARTS == 1 || (!SAVE && !DROP && !FEW), "PARTS: inference only, full batches");
+    constexpr int RPP = 4 / PARTS;                             // registers (tile rows j) per workgroup
     __shared__ __attribute__((aligned(16))) __bf16 hs[2 * 16 * HB_LD];
     // fp32 h of the step (last layer only), staged so that it leaves as 32-B-per-lane row segments instead of eight
     // 4-byte stores per lane; double-buffered like hs (one barrier per step)
@@ -107,14 +117,10 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_fwd_h128_bf16_s16_kernel(
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int d = blockIdx.y, D = gridDim.y, NBT = Bp >> 5;
     const int c16 = lane & 15, rq = lane >> 4;
-    // FEW with half != 0 (round 4, LOB_VAR_REC_HALF): TWO workgroups share each 16-row tile, workgroup jh runs the cell
-    // update of registers j in {2 jh, 2 jh + 1} only and stores only those rows -- for batches whose full tiles would
-    // occupy a quarter of the CUs or less: twice the workgroups, half the activations on each step's serial chain
-    const int bxx = (FEW && half) ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
-    const int jh = (FEW && half) ? (int)(blockIdx.x & 1) : 0;
+    const int bxx = (int)blockIdx.x / PARTS, jh = (int)blockIdx.x % PARTS, jlo = RPP * jh;
     const int bt = bxx >> 1, s0 = bxx & 1;                    // 32-row fragment block, 16-row half
-    const int nj = FEW ? (half ? 2 * jh + 2 : nvalid - (bt * 32 + s0 * 16)) : 4;   // FEW: registers jlo <= j < nj are updated
-    const int jlo = (FEW && half) ? 2 * jh : 0;
+    const int nj = FEW ? nvalid - (bt * 32 + s0 * 16) : 4;   // FEW: registers j < nj hold windows (nvalid < 4)
+    const bool mine = PARTS == 1 || ((((tid >> 4) & 3) / RPP) == jh);      // PARTS: only this workgroup's rows leave
     if (FEW && nj <= 0) {                                     // a tile of padding rows: zeros for every step
         const int row = tid >> 4, c8 = (tid & 15) * 8;
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_fwd_h128_bf16_s16_kernel(
             }
     }
     for (int i = tid; i < 2 * 16 * HB_LD; i += 256) hs[i] = (__bf16)0.f;
-    if (FEW && YF32)
+    if ((FEW || PARTS > 1) && YF32)
         for (int i = tid; i < 2 * 16 * YF_LD; i += 256) yfs[i] = 0.f;
     float c[2][4];
 #pragma unroll
@@ -184,11 +190,30 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_fwd_h128_bf16_s16_kernel(
         }
         __bf16* hnext = hs + (cur ^ 1) * 16 * HB_LD + 4 * rq * HB_LD + 32 * w + c16;
         float* ynext = yfs + (YF32 ? (cur ^ 1) * 16 * YF_LD + 4 * rq * YF_LD + 32 * w + c16 : 0);
+        if constexpr (PARTS > 1) {
+            auto pick = [&](const f32x4& v, int jj) -> float {      // register jlo + jj (jlo is workgroup-uniform: selects)
+                if constexpr (PARTS == 2) return jlo ? v[2 + jj] : v[jj];
+                else return jlo == 0 ? v[0] : (jlo == 1 ? v[1] : (jlo == 2 ? v[2] : v[3]));
+            };
+#pragma unroll
+            for (int cbu = 0; cbu < 2; ++cbu)
+#pragma unroll
+                for (int jj = 0; jj < RPP; ++jj) {
+                    const float ig = fast_sigmoid(pick(acc[0][cbu], jj));
+                    const float fg = fast_sigmoid(pick(acc[1][cbu], jj));
+                    const float gg = fast_tanh(pick(acc[2][cbu], jj));
+                    const float og = fast_sigmoid(pick(acc[3][cbu], jj));
+                    c[cbu][jj] = __builtin_fmaf(fg, c[cbu][jj], ig * gg);
+                    const float h = og * fast_tanh(c[cbu][jj]);
+                    hnext[(jlo + jj) * HB_LD + 16 * cbu] = (__bf16)h;
+                    if (YF32) ynext[(jlo + jj) * YF_LD + 16 * cbu] = h;
+                }
+        } else
 #pragma unroll
         for (int cbu = 0; cbu < 2; ++cbu)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (FEW && (j >= nj || j < jlo)) continue; // wave-uniform: a register of padding rows / of the partner workgroup
+                if (FEW && j >= nj) continue;              // wave-uniform: a register of padding rows only
                 const float ig = fast_sigmoid(acc[0][cbu][j]);
                 const float fg = fast_sigmoid(acc[1][cbu][j]);
                 const float gg = fast_tanh(acc[2][cbu][j]);
@@ -215,7 +240,6 @@ __global__ __launch_bounds__(256, 2) void lstm_rec_fwd_h128_bf16_s16_kernel(
             }
         }
         __syncthreads();
-        const bool mine = !(FEW && half) || (((tid >> 4) & 3) >> 1) == jh;      // half tiles: only this workgroup's rows leave
         if (YF32 && mine) {
             const int row = tid >> 4, c8 = (tid & 15) * 8;
             const float* ysrc = yfs + (cur ^ 1) * 16 * YF_LD + row * YF_LD + c8;
@@ -666,7 +690,10 @@ int lob_rec_fwd_bf16_s16(void* P, int pg_bf16, const float* Whh, float* Y, void*
     __bf16* y16 = reinterpret_cast<__bf16*>(Y16);
     __bf16* yd = reinterpret_cast<__bf16*>(Yd);
     if (c_bf16 && !(pg_bf16 && save)) return LOB_E_SHAPE;          // bf16 c: with bf16 saved gates only
-    if (!save && !yd && pg_bf16 && nvalid > 0 && nvalid < 4 && lob_variant(LOB_VAR_REC_FEW)) {
+    // FEW: one window per call (with two or three windows four workgroups per tile -- PARTS = 4 below -- are faster: 0.85 ms per
+    // forward against 0.89 / 1.00; LOB_VAR_REC_HALF = 0 keeps FEW for them)
+    if (!save && !yd && pg_bf16 && nvalid > 0 && (nvalid < 2 || (nvalid < 4 && !lob_variant(LOB_VAR_REC_HALF))) &&
+        lob_variant(LOB_VAR_REC_FEW)) {
 #define LOB_FEW(YF, Y6) hipLaunchKernelGGL((lstm_rec_fwd_h128_bf16_s16_kernel<false, YF, Y6, false, __bf16, float, true>), grid, block, \
         0, s, reinterpret_cast<__bf16*>(P), Whh, Y, (float*)nullptr, y16, yd, 0.f, (uint64_t)0, T, Bp, nvalid)
         if (Y && y16) LOB_FEW(true, true); else if (Y) LOB_FEW(true, false); else LOB_FEW(false, true);
@@ -674,14 +701,18 @@ int lob_rec_fwd_bf16_s16(void* P, int pg_bf16, const float* Whh, float* Y, void*
         LOB_CHECK_LAUNCH();
         return 0;
     }
-    // inference on few full tiles (at most a quarter of the CUs would hold one): two workgroups per tile (the FEW kernel's
-    // register skipping with a fixed half of the registers each)
-    if (!save && !yd && pg_bf16 && (Bp / 16) * D <= 64 && lob_variant(LOB_VAR_REC_HALF)) {
-        const dim3 grid2(Bp / 8, D);
-#define LOB_HALF(YF, Y6) hipLaunchKernelGGL((lstm_rec_fwd_h128_bf16_s16_kernel<false, YF, Y6, false, __bf16, float, true>), grid2, block, \
-        0, s, reinterpret_cast<__bf16*>(P), Whh, Y, (float*)nullptr, y16, yd, 0.f, (uint64_t)0, T, Bp, Bp, 1)
-        if (Y && y16) LOB_HALF(true, true); else if (Y) LOB_HALF(true, false); else LOB_HALF(false, true);
-#undef LOB_HALF
+    const int hv = lob_variant(LOB_VAR_REC_HALF), htiles = (Bp / 16) * D;
+    if (!save && !yd && pg_bf16 && hv && htiles <= 128) {
+        // LOB_VAR_REC_HALF: 1 = four workgroups per tile up to 64 tiles (B <= 512: -14 % per forward), two up to 128 tiles
+        // (B = 1024: -5 %; four there: +9 %); 2 / 4 force that split (A/B, tools/half_tile_ab.py)
+        const int parts = (hv == 2 || hv == 4) ? hv : (htiles <= 64 ? 4 : 2);
+        const dim3 gridp((Bp / 16) * parts, D);
+#define LOB_PART(YF, Y6, NP) hipLaunchKernelGGL((lstm_rec_fwd_h128_bf16_s16_kernel<false, YF, Y6, false, __bf16, float, false, NP>), gridp, \
+        block, 0, s, reinterpret_cast<__bf16*>(P), Whh, Y, (float*)nullptr, y16, yd, 0.f, (uint64_t)0, T, Bp, Bp)
+#define LOB_PART_OUT(NP) do { if (Y && y16) LOB_PART(true, true, NP); else if (Y) LOB_PART(true, false, NP); else LOB_PART(false, true, NP); } while (0)
+        if (parts == 4) LOB_PART_OUT(4); else LOB_PART_OUT(2);
+#undef LOB_PART_OUT
+#undef LOB_PART
         LOB_CHECK_LAUNCH();
         return 0;
     }

@@ -46,11 +46,13 @@ __device__ __forceinline__ f32x4 mfma16_f16(f16x8 a, f16x8 b, f32x4 c) {
 // cell-update work per lane and step (the step is a serial chain: MFMAs -> activations -> LDS -> barrier, and the
 // activations are a third of it); the other half of its h tile stays zero, the MFMAs on it are wasted.  Same arithmetic
 // per row: bit-identical to the full-tile kernel (tests/test_gpu_twins.py).  LOB_VAR_REC_HALF = 0 keeps full tiles.
-template <bool SAVE, bool HALF = false>
+// PARTS = 4 (quarter tiles: four workgroups per tile, one row j each) where full tiles would fill an eighth of the CUs.
+template <bool SAVE, int PARTS = 1>
 __global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h128_split_kernel(
     float* __restrict__ P, const float* __restrict__ Whh, float* __restrict__ Y, float* __restrict__ Csave, int T, int Bp,
     const float* __restrict__ range) {
-    constexpr int NJ = HALF ? 2 : 4;
+    constexpr bool HALF = PARTS > 1;
+    constexpr int NJ = 4 / PARTS;
     typedef float fvec __attribute__((ext_vector_type(NJ)));
     __shared__ __attribute__((aligned(16))) _Float16 hs[2 * 2 * 16 * HB_LD];      // [buf][split][16 rows][HB_LD]
     __shared__ __attribute__((aligned(16))) float yfs[2 * 16 * YF_LD];            // fp32 h of the step, for wide stores
@@ -59,8 +61,8 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h128_split_kernel(
     const int wcol = w8 >> 1, cbu = w8 & 1;
     const int d = blockIdx.y, D = gridDim.y, NBT = Bp >> 5;
     const int c16 = lane & 15, rq = lane >> 4;
-    const int bx = HALF ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
-    const int jb = HALF ? 2 * (int)(blockIdx.x & 1) : 0;      // first of this workgroup's rows j
+    const int bx = (int)blockIdx.x / PARTS;
+    const int jb = NJ * ((int)blockIdx.x % PARTS);            // first of this workgroup's rows j
     const int bt = bx >> 1, s0 = bx & 1;                      // 32-row fragment block, 16-row half
     const int col = 32 * wcol + 16 * cbu + c16;               // this lane's hidden column
 
@@ -146,9 +148,12 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h128_split_kernel(
             float a_hh[4], a_sm[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                if constexpr (HALF) {
+                if constexpr (PARTS == 2) {
                     a_hh[g] = jb ? ahh[g][2 + ja] : ahh[g][ja];
                     a_sm[g] = jb ? asm_[g][2 + ja] : asm_[g][ja];
+                } else if constexpr (PARTS == 4) {
+                    a_hh[g] = jb == 0 ? ahh[g][0] : (jb == 1 ? ahh[g][1] : (jb == 2 ? ahh[g][2] : ahh[g][3]));
+                    a_sm[g] = jb == 0 ? asm_[g][0] : (jb == 1 ? asm_[g][1] : (jb == 2 ? asm_[g][2] : asm_[g][3]));
                 } else {
                     a_hh[g] = ahh[g][ja]; a_sm[g] = asm_[g][ja];
                 }
@@ -181,8 +186,8 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h128_split_kernel(
         __syncthreads();
         {   // h_t is complete in yfs[cur ^ 1]: the tile's rows (HALF: this workgroup's 8) x 512 B leave as one 16-B store per thread
             const int r8 = tid >> 5, c4 = (tid & 31) * 4;
-            const int row = HALF ? 4 * (r8 >> 1) + jb + (r8 & 1) : r8;
-            if (!HALF || tid < 256) {
+            const int row = PARTS == 1 ? r8 : (PARTS == 2 ? 4 * (r8 >> 1) + jb + (r8 & 1) : 4 * r8 + jb);
+            if (tid < 512 / PARTS) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(yfs + (cur ^ 1) * 16 * YF_LD + row * YF_LD + c4);
                 *reinterpret_cast<f32x4*>(Y + ((size_t)t * Bp + row0 + row) * DH + d * H + c4) = v;
             }
@@ -384,14 +389,20 @@ namespace {
 // Internal entry point used by lob_lstm_rec_fwd_f32 (lstm_rec_f32.hip): 16-row tiles, eight waves, grid Bp/16 x D.
 int lob_rec_fwd_split(float* P, const float* Whh, float* Y, float* Csave, int T, int Bp, int D, int save, const float* range,
                       hipStream_t s) {
-    // half tiles (two workgroups per 16-row tile) while full tiles would occupy at most a quarter of the 256 CUs: measured
-    // +10 % (B = 512) / +14 % (B = 256) on the fp32 forward; at B = 1024 (128 full tiles -> 256 half tiles) the per-step gain
-    // is lost again (-1 %: every CU busy, lower clock), so the switch-over sits at 64 tiles (tools/half_tile_ab.py)
-    const bool half = lob_variant(LOB_VAR_REC_HALF) != 0 && (Bp / 16) * D <= 64;
-    const dim3 grid(half ? Bp / 8 : Bp / 16, D), block(512);
-    if (half) {
-        if (save) hipLaunchKernelGGL((lstm_rec_fwd_h128_split_kernel<true, true>), grid, block, 0, s, P, Whh, Y, Csave, T, Bp, range);
-        else      hipLaunchKernelGGL((lstm_rec_fwd_h128_split_kernel<false, true>), grid, block, 0, s, P, Whh, Y, Csave, T, Bp, range);
+    // part tiles while full tiles would occupy at most a quarter of the 256 CUs: four workgroups per 16-row tile, measured
+    // -13 % (B = 512), -25 % (B = 256), -31 % (B = 32) per fp32 forward; at B = 1024 (128 tiles) two per tile change nothing and
+    // four cost +24 % (two 8-wave workgroups per CU), so the switch-over sits at 64 tiles (tools/half_tile_ab.py)
+    const int v = lob_variant(LOB_VAR_REC_HALF);
+    const int tiles = (Bp / 16) * D;
+    // LOB_VAR_REC_HALF: 1 = four workgroups per tile up to 64 tiles; 2 / 4 force that split (up to 128 tiles: A/B)
+    const int parts = (v == 2 || v == 4) ? (tiles <= 128 ? v : 1) : ((v == 0 || tiles > 64) ? 1 : 4);
+    const dim3 grid((Bp / 16) * parts, D), block(512);
+    if (parts == 2) {
+        if (save) hipLaunchKernelGGL((lstm_rec_fwd_h128_split_kernel<true, 2>), grid, block, 0, s, P, Whh, Y, Csave, T, Bp, range);
+        else      hipLaunchKernelGGL((lstm_rec_fwd_h128_split_kernel<false, 2>), grid, block, 0, s, P, Whh, Y, Csave, T, Bp, range);
+    } else if (parts == 4) {
+        if (save) hipLaunchKernelGGL((lstm_rec_fwd_h128_split_kernel<true, 4>), grid, block, 0, s, P, Whh, Y, Csave, T, Bp, range);
+        else      hipLaunchKernelGGL((lstm_rec_fwd_h128_split_kernel<false, 4>), grid, block, 0, s, P, Whh, Y, Csave, T, Bp, range);
     } else {
         if (save) hipLaunchKernelGGL((lstm_rec_fwd_h128_split_kernel<true>), grid, block, 0, s, P, Whh, Y, Csave, T, Bp, range);
         else      hipLaunchKernelGGL((lstm_rec_fwd_h128_split_kernel<false>), grid, block, 0, s, P, Whh, Y, Csave, T, Bp, range);

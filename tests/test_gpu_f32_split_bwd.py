@@ -140,14 +140,15 @@ def test_half_tile_recurrent_forward_is_bit_identical(dev, T, Bp, D, save):
     bias = _rnd((D * 4 * H,), 0.1, dev, 18)
     P0 = ops.gate_gemm_x(x, wih, bias, T, Bp, H, D, True, mixed=False, exact=True)
     out = {}
-    for v in (1, 0):
+    for v in (1, 2, 4, 0):           # the default split for this tile count, two / four workgroups per tile forced, full tiles
         P = P0.clone()
         with _lib.variant(REC_HALF=v):
             Y, Cs, _, _ = ops.lstm_rec_fwd(P, whh, T, Bp, H, D, save)
         out[v] = (Y, Cs, P)
-    assert torch.equal(out[1][0], out[0][0])
-    if save:
-        assert torch.equal(out[1][1], out[0][1]) and torch.equal(out[1][2], out[0][2])
+    for v in (1, 2, 4):
+        assert torch.equal(out[v][0], out[0][0])
+        if save:
+            assert torch.equal(out[v][1], out[0][1]) and torch.equal(out[v][2], out[0][2])
     assert torch.isfinite(out[1][0]).all() and out[1][0].abs().max().item() > 0.01
 
 
@@ -165,12 +166,13 @@ def test_half_tile_mixed_inference_forward_is_bit_identical(dev, T, B):
     m = m.to(dev).eval()
     xd = torch.from_numpy(x).to(dev)
     res = {}
-    for v in (1, 0):
+    for v in (1, 2, 4, 0):
         with _lib.variant(REC_HALF=v), torch.no_grad():
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 lm, am = m(xd, return_attention=True)
             lf, af = m(xd, return_attention=True)
         res[v] = (lm.clone(), am.clone(), lf.clone(), af.clone())
-    for a, b in zip(res[1], res[0]):
-        assert torch.equal(a, b)
+    for v in (1, 2, 4):
+        for a, b in zip(res[v], res[0]):
+            assert torch.equal(a, b)
     assert torch.isfinite(res[1][0]).all()

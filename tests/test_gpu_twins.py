@@ -526,10 +526,17 @@ def test_few_window_inference_kernel_vs_full_tile_twin(dev, nwin, outs):
     P = _rand((D * T * Bp * 4 * H,), dev, 120 + nwin, 0.8).to(torch.bfloat16)
     whh = _rand((D, 4 * H, H), dev, 121, 0.08)
     kw = dict(want_f32=outs in ("f32", "both"), want_bf16=outs in ("bf16", "both"))
-    with _lib.variant(REC_FEW=1):
+    # (REC_HALF = 0: since round 4 two or three windows -- and every batch below 1024 -- run on part tiles by default; FEW stays
+    # the product kernel of the one-window call and selectable for 2 / 3 windows, the full-tile kernel is the twin of both)
+    with _lib.variant(REC_FEW=1, REC_HALF=0):
         Yf, _, Y16f, _ = ops.lstm_rec_fwd(P, whh, T, Bp, H, D, False, mixed=True, nvalid=nwin, **kw)
-    with _lib.variant(REC_FEW=0):
+    with _lib.variant(REC_FEW=0, REC_HALF=0):
         Yt, _, Y16t, _ = ops.lstm_rec_fwd(P, whh, T, Bp, H, D, False, mixed=True, nvalid=nwin, **kw)
+    with _lib.variant(REC_FEW=1, REC_HALF=1):       # the product's choice: FEW for one window, four workgroups per tile otherwise
+        Yp, _, Y16p, _ = ops.lstm_rec_fwd(P, whh, T, Bp, H, D, False, mixed=True, nvalid=nwin, **kw)
+    for prod, twin in ((Yp, Yt), (Y16p, Y16t)):
+        if prod is not None:
+            assert torch.equal(prod.reshape(T, Bp, D * H)[:, :nwin], twin.reshape(T, Bp, D * H)[:, :nwin])
     # same arithmetic in the same order (the cell update's contraction is pinned with an explicit fma in every forward
     # kernel: left to hipcc, one instantiation fused fg*c, the other ig*gg, and a last fp32 bit now and then flipped
     # a bf16 rounding of the fed-back h -- 4e-4 after 256 steps): bit-identical
