@@ -28,6 +28,10 @@ done
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_fwd32 -o run -- python3 $R/bench.py --mode fwd --precision fp32 --steps 7 --warmup 2 --no-extra --no-cpu-baseline > $O/stats_fwd32.log 2>&1
 # the fp32 training step (the fp16-split backward kernels of round 4)
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_train32 -o run -- python3 $R/bench.py --mode train --precision fp32 --steps 4 --warmup 2 --no-extra --no-cpu-baseline --no-roofline > $O/stats_train32.log 2>&1
+# the mixed inference forward (the reference's GPU inference arithmetic, 06:349): what stops it -- kernel times and where its waves' cycles go
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_fwdmix -o run -- python3 $R/bench.py --mode fwd --precision mixed --steps 8 --warmup 2 --no-extra --no-cpu-baseline --no-roofline > $O/stats_fwdmix.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $O/sq_fwdmix -o run -- python3 $R/bench.py --mode fwd --precision mixed --steps 3 --warmup 1 $STEPS > $O/sq_fwdmix.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC --kernel-trace --output-format csv -d $O/sq2_fwdmix -o run -- python3 $R/bench.py --mode fwd --precision mixed --steps 3 --warmup 1 $STEPS > $O/sq2_fwdmix.log 2>&1 || true
 cd $R
 # keep only the small summaries (the traces are tens of MB)
 find $O -name "*kernel_trace.csv" -delete

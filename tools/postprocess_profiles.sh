@@ -17,6 +17,8 @@ python3 $R/tools/pmc_traffic.py $O/fetch/run_counter_collection.csv $O/write/run
 python3 $R/tools/pmc_traffic.py $O/fetch_h256/run_counter_collection.csv $O/write_h256/run_counter_collection.csv ${TAG}_train_mixed_B4096_H256 4096 256 4 mixed > /dev/null
 python3 $R/tools/sq_counters.py $O/sq/run_counter_collection.csv $P/${TAG}_train_mixed_B4096_sq_counters.csv > /dev/null
 python3 $R/tools/sq_counters.py $O/sq_h256/run_counter_collection.csv $P/${TAG}_train_mixed_B4096_H256_sq_counters.csv > /dev/null
+[ -f $O/stats_fwdmix/run_kernel_stats.csv ] && cp $O/stats_fwdmix/run_kernel_stats.csv $P/${TAG}_fwd_mixed_B4096_kernel_stats.csv
+[ -f $O/sq_fwdmix/run_counter_collection.csv ] && python3 $R/tools/sq_counters.py $O/sq_fwdmix/run_counter_collection.csv $P/${TAG}_fwd_mixed_B4096_sq_counters.csv > /dev/null
 cp $O/b_default.json $P/${TAG}_default_bench.json
 cp $O/b_default_detail.json $P/${TAG}_default_bench_detail.json
 cp $O/b_train_b1024.json $P/${TAG}_train_mixed_B1024_bench.json
