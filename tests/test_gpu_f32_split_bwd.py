@@ -176,3 +176,36 @@ def test_half_tile_mixed_inference_forward_is_bit_identical(dev, T, B):
         for a, b in zip(res[v], res[0]):
             assert torch.equal(a, b)
     assert torch.isfinite(res[1][0]).all()
+
+
+@pytest.mark.parametrize("T,Bp,D,drop", [(12, 64, 2, 0.4), (5, 32, 1, 0.0), (40, 512, 2, 0.4)])
+def test_h256_part_tiles_forward_and_bptt_are_bit_identical(dev, T, Bp, D, drop):
+    """H = 256 (the reference's checkpoint size) on few tiles -- its own training batch of 512 windows is 16 tiles per direction:
+    four workgroups per 32-row tile (LOB_VAR_REC_HALF) in the saving forward (with the fused dropout copy) and in BPTT against
+    full tiles: saved gates, cell states, outputs and dP equal to the last bit; the bias gradient (atomics over four times the
+    workgroups) to fp32 rounding."""
+    from lstm_ode_bci_amd import _lib, ops
+    H = 256
+    whh = _rnd((D, 4 * H, H), 0.05, dev, 25)
+    x = _rnd((T * Bp, 2 * H), 1.0, dev, 26).to(torch.bfloat16)
+    wih = _rnd((D * 4 * H, 2 * H), 0.05, dev, 27).to(torch.bfloat16)
+    bias = _rnd((D * 4 * H,), 0.1, dev, 28)
+    P0 = ops.gate_gemm_x(x, wih, bias, T, Bp, H, D, True, mixed=True)
+    dY = _rnd((T * Bp, D * H), 1e-3, dev, 29).to(torch.bfloat16)
+    res = {}
+    for v in (1, 0):
+        with _lib.variant(REC_HALF=v):
+            P = P0.clone()
+            Y, Cs, Y16, Yd = ops.lstm_rec_fwd(P, whh, T, Bp, H, D, True, mixed=True, drop_p=drop, seed=11, want_f32=False,
+                                              want_bf16=True)
+            dP, db = ops.lstm_rec_bwd(P, Cs, whh, dY, T, Bp, H, D, dp_bf16=True)
+            Yi, _, Y16i, _ = ops.lstm_rec_fwd(P0.clone(), whh, T, Bp, H, D, False, mixed=True, want_f32=True, want_bf16=True)
+        res[v] = (P, Cs, Y16, Yd, dP, db, Yi, Y16i)
+    for i, (a, b) in enumerate(zip(res[1], res[0])):
+        if a is None:
+            assert b is None
+        elif i == 5:
+            assert (a - b).abs().max().item() <= 1e-5 * max(b.abs().max().item(), 1e-12)
+        else:
+            assert torch.equal(a, b), i
+    assert torch.isfinite(res[1][4].float()).all() and res[1][4].float().abs().max().item() > 0

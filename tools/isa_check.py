@@ -272,7 +272,7 @@ def check_h256_rec(path=None):
         if any("scratch_" in l for l in body):
             problems.append(f"{n}: scratch (spill) traffic")
     # product forward: saving, bf16 outputs, dropout, bf16 cell states, NQL = 3
-    for pat in ("lstm_rec_fwd_h256_bf16_kernelILb1ELb0ELb1ELb1EDF16bLi3E", "lstm_rec_fwd_h256_bf16_kernelILb0ELb0ELb1ELb0EfLi3E"):
+    for pat in ("lstm_rec_fwd_h256_bf16_kernelILb1ELb0ELb1ELb1EDF16bLi3ELi1E", "lstm_rec_fwd_h256_bf16_kernelILb0ELb0ELb1ELb0EfLi3ELi1E"):
         body = [l.strip() for l in _function(lines, pat)]
         mf = [i for i, l in enumerate(body) if l.startswith("v_mfma")]
         if len(mf) != 64:
