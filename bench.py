@@ -594,6 +594,8 @@ def extra_legs(dev, forecast_steps, cpu=True):
          dict(mode="coupled", precision="fp32", B=4096, H=128, api_level=True), 3, 1),
         ("H=256 mixed training step, B=4096 (the reference's checkpoint size, 04:877)",
          dict(mode="train", precision="mixed", B=4096, H=256), 5, 2),
+        ("H=256 mixed training step, B=512 (the reference's own training batch and hidden size, 04:866-877)",
+         dict(mode="train", precision="mixed", B=512, H=256), 8, 3),
         ("configs[4] per-rank shard: forward, B=8192, fp32", dict(mode="fwd", precision="fp32", B=8192, H=128), 4, 2),
         ("configs[4] per-rank shard: forward, B=8192, mixed", dict(mode="fwd", precision="mixed", B=8192, H=128), 5, 2),
         ("H=256 mixed forward, B=4096 (a real checkpoint under the reference's inference autocast, 06:349)",
