@@ -36,7 +36,9 @@ KERNELS = {
 }
 # H = 256 (bench --hidden 256): the kernels of the reference's checkpoint size
 KERNELS_H256 = {
-    "lstm_rec_fwd(save)": [("mixed", "lstm_rec_fwd_h256_bf16_kernelILb1ELb0ELb1ELb1E")],
+    # rocprofv3 half-demangles this one (its DF16b argument defeats the demangler): both spellings
+    "lstm_rec_fwd(save)": [("mixed", "lstm_rec_fwd_h256_bf16_kernelILb1ELb0ELb1ELb1E"),
+                           ("mixed", "lstm_rec_fwd_h256_bf16_kernel<true, false, true, true")],
     "lstm_rec_bwd": [("mixed", "lstm_rec_bwd_h256_bf16_kernel")],
     "gate_gemm_x(K=512)": [("mixed", "gate_gemm_ws_kernel<512, 0, 256>")],
     "gemm_nt(dX)": [("mixed", "gemm_nt_pp16_kernel")],
