@@ -849,6 +849,16 @@ __global__ __launch_bounds__(256, 2) void input_proj_ln_kernel(
     }
 }
 
+// (t, b) of the time-major row r = t * Bp + b.  The fused tail kernels below need it for every row (the score / attention
+// element of window b at time t); as `r / Bp` on a 64-bit row index that was ~70 instructions per row in kernels whose time
+// IS their vector instruction count (round 4).  One 32-bit division per tile and wave, then steps of 1 or 2 rows
+// (step <= 32 <= Bp).  The entry points refuse T * Bp >= 2^31.
+struct RowTB {
+    int t, b;
+    __device__ RowTB(long r, int Bp) { t = (int)((unsigned)r / (unsigned)Bp); b = (int)((unsigned)r - (unsigned)t * (unsigned)Bp); }
+    __device__ void step(int inc, int Bp) { b += inc; if (b >= Bp) { b -= Bp; ++t; } }
+};
+
 // ------------------------------------------------------------------------------------------
 // Fused tail of the mixed forward at H = 128 (round 3): post-LSTM LayerNorm (04_lstm_model.py:192) + the attention's
 // score layer u = tanh(W1 v + b1), s = w2 . u + b2 (Attention.forward, 04:123-125) in one pass over the last layer's bf16
@@ -946,7 +956,8 @@ __global__ __launch_bounds__(256, 2) void attn_score_kernel(
                 lds[(32 * rb + (i & 3) + 8 * (i >> 2) + 4 * hi) * AS_LDU + 32 * w + l31] = fast_tanh(acc[rb][i] + b1v);
         __syncthreads();
         // ---- 3. scores of this wave's 32 rows (the pooling kernel's order: two columns per lane, wave reduction)
-        for (int rr = 0; rr < 32; ++rr) {
+        RowTB tb(r0, Bp);
+        for (int rr = 0; rr < 32; ++rr, tb.step(1, Bp)) {
             const long r = r0 + rr;
             if (r >= rows) break;
             const float u0 = lds[(32 * w + rr) * AS_LDU + 2 * lane], u1 = lds[(32 * w + rr) * AS_LDU + 2 * lane + 1];
@@ -954,8 +965,7 @@ __global__ __launch_bounds__(256, 2) void attn_score_kernel(
             float sc = u0 * w2v[0];
             sc = fmaf(u1, w2v[1], sc);
             sc = wave_sum(sc);
-            const int t = (int)(r / Bp), b = (int)(r - (long)t * Bp);
-            if (lane == 0 && b < B) S[(size_t)b * T + t] = sc + bias2;
+            if (lane == 0 && tb.b < B) S[(size_t)tb.b * T + tb.t] = sc + bias2;
         }
         __syncthreads();                       // the block is free for the next tile's v
     }
@@ -982,8 +992,17 @@ __global__ __launch_bounds__(512) void attn_ln_bwd_kernel(
     int T, int B, int Bp, float eps) {
     constexpr int W = 256, W2 = 128;
     // EIGHT waves: wave w owns 32 of dV's columns (8 B fragments + 64 accumulator registers: two waves per SIMD fit) and
-    // the LayerNorm backward of 16 of the tile's rows
-    __shared__ __attribute__((aligned(16))) __bf16 lds[128 * AB_LDV];
+    // the LayerNorm backward of 16 of the tile's rows.
+    // Round 4: the kernel ran at 2.8 TB/s with one workgroup per CU in lock-step phases, every phase opening with an exposed
+    // round trip (dU at the top of a tile, the attention weight and the dctx row of every pass).  Now
+    //  * a tile is 16 windows x 8 time steps instead of 128 consecutive rows: a wave's lane half keeps ONE window for the
+    //    tile's eight passes, so its dctx row and its eight attention weights are loaded once per tile, not per pass;
+    //  * every load runs one tile ahead: the LayerNorm input of pass p is re-requested for the NEXT tile as soon as pass p
+    //    has consumed it (same registers), the next tile's dU rows, dctx row and attention weights during this tile's passes;
+    //  * the dU tile has an LDS region of its own: two barriers per tile instead of four.
+    // dx is bit-identical to the old kernel's (same arithmetic per row); dgamma / dbeta sum the rows in another order.
+    __shared__ __attribute__((aligned(16))) __bf16 lds[128 * AB_LDV];          // dV tile (the affine partials at the end)
+    __shared__ __attribute__((aligned(16))) __bf16 ldu[128 * AB_LDA];          // dU tile
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     // B fragments of this wave's 32 dV columns: W1^T[32 w + l31][16 ks + 8 hi + j]
@@ -991,38 +1010,63 @@ __global__ __launch_bounds__(512) void attn_ln_bwd_kernel(
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks)
         wf[ks] = *reinterpret_cast<const ip_bf16x8*>(W1T + (size_t)(32 * w + l31) * W2 + 16 * ks + 8 * hi);
-    float gm[8], bt[8], dga[8], dba[8];
+    float gm[8], dga[8], dba[8];
     ldv<8>(gamma + l31 * 8, gm);
-    ldv<8>(beta + l31 * 8, bt);
 #pragma unroll
     for (int i = 0; i < 8; ++i) { dga[i] = 0.f; dba[i] = 0.f; }
-    const long rows = (long)T * Bp;
-    const long ntile = (rows + 127) >> 7;
+    const int nbb = Bp >> 4;                             // window blocks (Bp is a multiple of 32)
+    const long ntile = (long)((T + 7) >> 3) * nbb;
     const float invw = 1.0f / (float)W;
+    // tile -> (first time step, first window); rows of the tile: (t0 + p) * Bp + b0 + j, p < 8, j < 16; local index 16 p + j
+    auto origin = [&](long tl, int& t0, int& b0) {
+        const int tb = (int)((unsigned)tl / (unsigned)nbb);
+        t0 = 8 * tb;
+        b0 = 16 * ((int)tl - tb * nbb);
+    };
+    auto row_of = [&](int t0, int b0, int p, int j) -> size_t {      // clamped to the last time step (results masked)
+        const int t = t0 + p < T ? t0 + p : T - 1;
+        return (size_t)t * Bp + b0 + j;
+    };
+    ip_bf16x8 du[4], xr[8];
+    float dcv[8], av[8];
+    // wave w brings in the dU rows of time step t0 + w (16 consecutive rows, 4 KB): lane -> (row l / 16 + 4 i, chunk l % 16)
+    auto load_du = [&](int t0, int b0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            du[i] = *reinterpret_cast<const ip_bf16x8*>(dU + row_of(t0, b0, w, (lane >> 4) + 4 * i) * W2 + 8 * (lane & 15));
+    };
+    // this lane half's window: b0 + 2 w + hi; its dctx row and its eight attention weights (0 for a padding window)
+    auto load_ctx = [&](int t0, int b0) {
+        const int b = b0 + 2 * w + hi;
+        const int bb = b < B ? b : 0;
+        ldv<8>(dctx + (size_t)bb * W + l31 * 8, dcv);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) av[p] = attn[(size_t)bb * T + (t0 + p < T ? t0 + p : T - 1)];
+    };
+    auto load_x = [&](int t0, int b0, int p) {
+        xr[p] = *reinterpret_cast<const ip_bf16x8*>(X + row_of(t0, b0, p, 2 * w + hi) * W + l31 * 8);
+    };
+    if ((long)blockIdx.x < ntile) {
+        int t0, b0;
+        origin(blockIdx.x, t0, b0);
+        load_du(t0, b0);
+        load_ctx(t0, b0);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) load_x(t0, b0, p);
+    }
     for (long tl = blockIdx.x; tl < ntile; tl += gridDim.x) {
-        const long r0 = tl * 128 + 16 * w;
-        // ---- 0. this wave's 16 rows of dU (256 B each) into the tile: lane -> (row l / 16 + 4 i, 16-byte chunk l % 16)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int rr = (lane >> 4) + 4 * i, ch = lane & 15;
-            const long r = r0 + rr;
-            ip_bf16x8 z;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.f;
-            if (r < rows) z = *reinterpret_cast<const ip_bf16x8*>(dU + (size_t)r * W2 + 8 * ch);
-            *reinterpret_cast<ip_bf16x8*>(lds + (16 * w + rr) * AB_LDA + 8 * ch) = z;
+        int t0, b0, nt0, nb0;
+        origin(tl, t0, b0);
+        {
+            const long nx = tl + gridDim.x;
+            origin(nx < ntile ? nx : tl, nt0, nb0);
         }
-        // the LayerNorm inputs of this wave's 16 rows: requested now, used after the matrix phase
-        ip_bf16x8 xr[8];
+        // ---- 0. dU rows (requested a tile ago) into their LDS tile
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const long r = r0 + 2 * p + hi;
-            ip_bf16x8 z;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.f;
-            xr[p] = r < rows ? *reinterpret_cast<const ip_bf16x8*>(X + (size_t)r * W + l31 * 8) : z;
-        }
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<ip_bf16x8*>(ldu + (16 * w + (lane >> 4) + 4 * i) * AB_LDA + 8 * (lane & 15)) = du[i];
         __syncthreads();
+        load_du(nt0, nb0);
         // ---- 1. dV = dU W1: this wave's 32 columns for all 128 rows
         f32x16 acc[4];
 #pragma unroll
@@ -1033,12 +1077,11 @@ __global__ __launch_bounds__(512) void attn_ln_bwd_kernel(
         for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
             for (int rb = 0; rb < 4; ++rb) {
-                const ip_bf16x8 a = *reinterpret_cast<const ip_bf16x8*>(lds + (32 * rb + l31) * AB_LDA + 16 * ks + 8 * hi);
+                const ip_bf16x8 a = *reinterpret_cast<const ip_bf16x8*>(ldu + (32 * rb + l31) * AB_LDA + 16 * ks + 8 * hi);
                 // operands SWAPPED like the unfused weight-stationary GEMM: D[n][r] -- this lane holds row r = l31 of the
                 // block, columns n = (i & 3) + 8 (i >> 2) + 4 hi
                 acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], a, acc[rb], 0, 0, 0);
             }
-        __syncthreads();                       // the dU tile is consumed: the block now takes dV (bf16, row-major)
         typedef __bf16 ab_bf16x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb)
@@ -1049,52 +1092,53 @@ __global__ __launch_bounds__(512) void attn_ln_bwd_kernel(
                 *reinterpret_cast<ab_bf16x4*>(lds + (32 * rb + l31) * AB_LDV + 32 * w + 8 * q4 + 4 * hi) = pk;
             }
         __syncthreads();
-        // ---- 3. LayerNorm backward of rows 16 w .. + 15 (layernorm_act_bwd_vec_kernel<8, 32, bf16, bf16, bf16>)
+        // ---- 2. LayerNorm backward of this lane half's window, time steps t0 .. t0 + 7
+        //         (layernorm_act_bwd_vec_kernel<8, 32, bf16, bf16, bf16>'s arithmetic)
+        const bool real = b0 + 2 * w + hi < B;
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
-            const long r = r0 + 2 * p + hi;
-            if (r >= rows) continue;
-            float v[8], go[8];
+            if (t0 + p < T) {
+                float v[8], go[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = (float)xr[p][i];
-            ldv_bf16<8>(lds + (16 * w + 2 * p + hi) * AB_LDV + l31 * 8, go);
-            {      // context path of the attention pooling: dy += attn[b][t] * dctx[b][:]
-                const int t = (int)(r / Bp), b = (int)(r - (long)t * Bp);
-                if (b < B) {
-                    const float a = attn[(size_t)b * T + t];
-                    float dcv[8];
-                    ldv<8>(dctx + (size_t)b * W + l31 * 8, dcv);
+                for (int i = 0; i < 8; ++i) v[i] = (float)xr[p][i];
+                ldv_bf16<8>(lds + (16 * p + 2 * w + hi) * AB_LDV + l31 * 8, go);
+                if (real) {      // context path of the attention pooling: dy += attn[b][t] * dctx[b][:]
+                    const float a = av[p];
 #pragma unroll
                     for (int i = 0; i < 8; ++i) go[i] = fmaf(a, dcv[i], go[i]);
                 }
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s += v[i];
+                const float mean = row_sum<32>(s) * invw;
+                float q = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const float dl = v[i] - mean; q = __builtin_fmaf(dl, dl, q); }
+                const float rstd = rsqrtf(__builtin_fmaf(row_sum<32>(q), invw, eps));
+                float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float xh = (v[i] - mean) * rstd;
+                    const float g = go[i];
+                    dga[i] = __builtin_fmaf(g, xh, dga[i]);
+                    dba[i] += g;
+                    const float dxh = g * gm[i];
+                    v[i] = xh; go[i] = dxh;
+                    m1 += dxh; m2 = __builtin_fmaf(dxh, xh, m2);
+                }
+                m1 = row_sum<32>(m1) * invw;
+                m2 = row_sum<32>(m2) * invw;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = rstd * __builtin_fmaf(-v[i], m2, go[i] - m1);
+                stv_bf16<8>(dX + ((size_t)(t0 + p) * Bp + b0 + 2 * w + hi) * W + l31 * 8, v);
             }
-            float s = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) s += v[i];
-            const float mean = row_sum<32>(s) * invw;
-            float q = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { const float dl = v[i] - mean; q = __builtin_fmaf(dl, dl, q); }
-            const float rstd = rsqrtf(__builtin_fmaf(row_sum<32>(q), invw, eps));
-            float m1 = 0.f, m2 = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float xh = (v[i] - mean) * rstd;
-                const float g = go[i];
-                dga[i] = __builtin_fmaf(g, xh, dga[i]);
-                dba[i] += g;
-                const float dxh = g * gm[i];
-                v[i] = xh; go[i] = dxh;
-                m1 += dxh; m2 = __builtin_fmaf(dxh, xh, m2);
-            }
-            m1 = row_sum<32>(m1) * invw;
-            m2 = row_sum<32>(m2) * invw;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = rstd * __builtin_fmaf(-v[i], m2, go[i] - m1);
-            stv_bf16<8>(dX + (size_t)r * W + l31 * 8, v);
+            load_x(nt0, nb0, p);                 // the same pass of the next tile, into the registers just released
         }
-        __syncthreads();                       // the block is free for the next tile's dU
+        load_ctx(nt0, nb0);
+        // no barrier here: the next tile's dU writes go to `ldu`, last read before the barrier above; its dV writes come
+        // after its own first barrier, which every wave reaches only when it has finished reading this tile's dV rows
     }
+    __syncthreads();
     // block-level reduction of the affine gradients (in the tile's LDS block), then ONE atomic per column per block
     float* red = reinterpret_cast<float*>(lds);          // [2][16][W] floats = 32 KB
     const int wib = 2 * w + hi;
@@ -1307,24 +1351,29 @@ __global__ __launch_bounds__(512) void attn_score_h256_kernel(
     const long rows = (long)T * Bp;
     const long ntile = (rows + 63) >> 6;
     const float invw = 1.0f / (float)W;
+    // The rows of a tile are requested one tile AHEAD (round 4): the loads of tile q + 1 are issued right after the barrier
+    // that ends tile q's LayerNorm phase and land during its 64 MFMAs; before, every tile started with an exposed HBM
+    // round trip (one workgroup per CU, all eight waves in the same phase: 0.82 ms for 3.2 GB).  Rows past the end are
+    // clamped to the last row (their results are never stored).
+    ip_bf16x8 raw[8];
+    auto load_rows = [&](long tl) {
+        const long r0 = tl * 64 + 8 * w;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const long r = r0 + p < rows ? r0 + p : rows - 1;
+            raw[p] = *reinterpret_cast<const ip_bf16x8*>(Y + (size_t)r * W + lane * 8);
+        }
+    };
+    if ((long)blockIdx.x < ntile) load_rows(blockIdx.x);
     for (long tl = blockIdx.x; tl < ntile; tl += gridDim.x) {
         const long r0 = tl * 64 + 8 * w;
         // ---- 1. LayerNorm of this wave's 8 rows (layernorm_act_vec_kernel<8, true, 64, bf16>)
-        ip_bf16x8 raw[8];
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const long r = r0 + p;
-            ip_bf16x8 z;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) z[i] = (__bf16)0.f;
-            raw[p] = r < rows ? *reinterpret_cast<const ip_bf16x8*>(Y + (size_t)r * W + lane * 8) : z;
-        }
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             const long r = r0 + p;
             float v[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = (float)raw[p][i];
+            for (int i = 0; i < 8; ++i) v[i] = r < rows ? (float)raw[p][i] : 0.f;
             float s = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) s += v[i];
@@ -1340,6 +1389,10 @@ __global__ __launch_bounds__(512) void attn_score_h256_kernel(
             if (r < rows) *reinterpret_cast<ip_bf16x8*>(V + (size_t)r * W + lane * 8) = *reinterpret_cast<const ip_bf16x8*>(arow);
         }
         __syncthreads();
+        {
+            const long nx = tl + gridDim.x;
+            load_rows(nx < ntile ? nx : tl);
+        }
         // ---- 2. this wave's 32 score columns for the 64 rows
         f32x16 acc[2];
 #pragma unroll
@@ -1361,8 +1414,9 @@ __global__ __launch_bounds__(512) void attn_score_h256_kernel(
                 lds[(32 * rb + (i & 3) + 8 * (i >> 2) + 4 * hi) * AS2_LDU + 32 * w + l31] = fast_tanh(acc[rb][i] + b1v);
         __syncthreads();
         // ---- 3. scores of this wave's 8 rows (the pooling kernel's order: four columns per lane, wave reduction)
+        RowTB tb(r0, Bp);
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
+        for (int rr = 0; rr < 8; ++rr, tb.step(1, Bp)) {
             const long r = r0 + rr;
             if (r >= rows) break;
             float uu[4];
@@ -1375,8 +1429,7 @@ __global__ __launch_bounds__(512) void attn_score_h256_kernel(
 #pragma unroll
             for (int i = 1; i < 4; ++i) sc = fmaf(uu[i], w2v[i], sc);
             sc = wave_sum(sc);
-            const int t = (int)(r / Bp), b = (int)(r - (long)t * Bp);
-            if (lane == 0 && b < B) S[(size_t)b * T + t] = sc + bias2;
+            if (lane == 0 && tb.b < B) S[(size_t)tb.b * T + tb.t] = sc + bias2;
         }
         __syncthreads();
     }
@@ -1385,6 +1438,11 @@ __global__ __launch_bounds__(512) void attn_score_h256_kernel(
 // The backward tail at H = 256 (width 512, dU 256 wide): eight waves per 64-row tile; wave w owns 64 of dV's 512 columns
 // (2 column blocks x 16 k-steps = 32 B fragments of W1^T) and the LayerNorm backward of rows 8 w .. + 7 with the width-512
 // kernel's lane assignment (64 lanes x 8 columns, one row per pass).
+// Round 4: one workgroup per CU with all eight waves in the same phase left every HBM round trip exposed (1.03 ms for
+// 2.7 GB).  Now (i) the LayerNorm inputs of tile q are requested BEFORE its MFMAs and land behind them, the dU rows of
+// tile q + 1 before its LayerNorm phase, (ii) the dU tile has an LDS region of its own, so a tile costs two barriers instead of four, (iii)
+// the two 32-row blocks are multiplied one after the other (32 accumulator registers live instead of 64: room for the
+// rows in flight), (iv) gamma / beta sit in LDS.  Same arithmetic in the same order: bit-identical dx.
 constexpr int AB2_LDA = 264;           // bf16 row stride of the dU tile (528 B)
 constexpr int AB2_LDV = 520;           // bf16 row stride of the dV tile (1040 B)
 
@@ -1394,7 +1452,9 @@ __global__ __launch_bounds__(512) void attn_ln_bwd_h256_kernel(
     float* __restrict__ dgamma, float* __restrict__ dbeta, const float* __restrict__ attn, const float* __restrict__ dctx,
     int T, int B, int Bp, float eps) {
     constexpr int W = 512, W2 = 256;
-    __shared__ __attribute__((aligned(16))) __bf16 lds[64 * AB2_LDV];
+    __shared__ __attribute__((aligned(16))) __bf16 lds[64 * AB2_LDV];          // dV tile; the dgamma / dbeta partials at the end
+    __shared__ __attribute__((aligned(16))) __bf16 ldu[64 * AB2_LDA];          // dU tile
+    __shared__ __attribute__((aligned(16))) float lgb[W];                       // gamma
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     ip_bf16x8 wf[2][16];
@@ -1403,70 +1463,75 @@ __global__ __launch_bounds__(512) void attn_ln_bwd_h256_kernel(
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks)
             wf[cb][ks] = *reinterpret_cast<const ip_bf16x8*>(W1T + (size_t)(64 * w + 32 * cb + l31) * W2 + 16 * ks + 8 * hi);
-    float gm[8], bt[8], dga[8], dba[8];
-    ldv<8>(gamma + lane * 8, gm);
-    ldv<8>(beta + lane * 8, bt);
+    lgb[tid] = gamma[tid];
+    float dga[8], dba[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { dga[i] = 0.f; dba[i] = 0.f; }
     const long rows = (long)T * Bp;
     const long ntile = (rows + 63) >> 6;
     const float invw = 1.0f / (float)W;
-    for (long tl = blockIdx.x; tl < ntile; tl += gridDim.x) {
+    // this wave's 8 rows of dU (512 B each): lane -> (row l / 32 + 2 i, 16-byte chunk l % 32); rows past the end are
+    // clamped (they only feed dV rows that nobody reads)
+    ip_bf16x8 du[4];
+    auto load_du = [&](long tl) {
         const long r0 = tl * 64 + 8 * w;
-        // ---- 0. this wave's 8 rows of dU (512 B each): lane -> (row l / 32 + 2 i, 16-byte chunk l % 32)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int rr = (lane >> 5) + 2 * i, ch = lane & 31;
-            const long r = r0 + rr;
-            ip_bf16x8 z;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.f;
-            if (r < rows) z = *reinterpret_cast<const ip_bf16x8*>(dU + (size_t)r * W2 + 8 * ch);
-            *reinterpret_cast<ip_bf16x8*>(lds + (8 * w + rr) * AB2_LDA + 8 * ch) = z;
+            const long r = r0 + (lane >> 5) + 2 * i;
+            du[i] = *reinterpret_cast<const ip_bf16x8*>(dU + (size_t)(r < rows ? r : rows - 1) * W2 + 8 * (lane & 31));
         }
-        __syncthreads();
-        // ---- 1. dV = dU W1: this wave's 64 columns for the 64 rows (operands swapped like the unfused GEMM)
-        f32x16 acc[2][2];
+    };
+    if ((long)blockIdx.x < ntile) load_du(blockIdx.x);
+    for (long tl = blockIdx.x; tl < ntile; tl += gridDim.x) {
+        const long r0 = tl * 64 + 8 * w;
+        // ---- 0. dU rows (requested a tile ago) into their LDS tile
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[rb][cb][i] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks)
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb) {
-                const ip_bf16x8 a = *reinterpret_cast<const ip_bf16x8*>(lds + (32 * rb + l31) * AB2_LDA + 16 * ks + 8 * hi);
-                acc[rb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][ks], a, acc[rb][0], 0, 0, 0);
-                acc[rb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1][ks], a, acc[rb][1], 0, 0, 0);
-            }
-        __syncthreads();
-        typedef __bf16 ab_bf16x4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    ab_bf16x4 pk = {(__bf16)acc[rb][cb][4 * q4], (__bf16)acc[rb][cb][4 * q4 + 1], (__bf16)acc[rb][cb][4 * q4 + 2],
-                                    (__bf16)acc[rb][cb][4 * q4 + 3]};
-                    *reinterpret_cast<ab_bf16x4*>(lds + (32 * rb + l31) * AB2_LDV + 64 * w + 32 * cb + 8 * q4 + 4 * hi) = pk;
-                }
-        // the LayerNorm inputs of this wave's 8 rows: requested now (the accumulators are dead), used after the barrier
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<ip_bf16x8*>(ldu + (8 * w + (lane >> 5) + 2 * i) * AB2_LDA + 8 * (lane & 31)) = du[i];
+        // the LayerNorm inputs of this wave's 8 rows: in flight during the MFMAs
         ip_bf16x8 xr[8];
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             const long r = r0 + p;
-            ip_bf16x8 z;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.f;
-            xr[p] = r < rows ? *reinterpret_cast<const ip_bf16x8*>(X + (size_t)r * W + lane * 8) : z;
+            xr[p] = *reinterpret_cast<const ip_bf16x8*>(X + (size_t)(r < rows ? r : rows - 1) * W + lane * 8);
         }
         __syncthreads();
-        // ---- 3. LayerNorm backward of rows 8 w .. + 7 (layernorm_act_bwd_vec_kernel<8, 64, bf16, bf16, bf16>)
+        // ---- 1. dV = dU W1: this wave's 64 columns for the 64 rows (operands swapped like the unfused GEMM), rounded to
+        //         bf16 as the unfused GEMM stores it, row-major into the dV tile
+        typedef __bf16 ab_bf16x4 __attribute__((ext_vector_type(4)));
+#pragma nounroll
+        for (int rb = 0; rb < 2; ++rb) {
+            f32x16 acc[2];
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[cb][i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const ip_bf16x8 a = *reinterpret_cast<const ip_bf16x8*>(ldu + (32 * rb + l31) * AB2_LDA + 16 * ks + 8 * hi);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][ks], a, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1][ks], a, acc[1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    ab_bf16x4 pk = {(__bf16)acc[cb][4 * q4], (__bf16)acc[cb][4 * q4 + 1], (__bf16)acc[cb][4 * q4 + 2],
+                                    (__bf16)acc[cb][4 * q4 + 3]};
+                    *reinterpret_cast<ab_bf16x4*>(lds + (32 * rb + l31) * AB2_LDV + 64 * w + 32 * cb + 8 * q4 + 4 * hi) = pk;
+                }
+        }
+        {   // the next tile's dU rows: in flight during the LayerNorm phase
+            const long nx = tl + gridDim.x;
+            load_du(nx < ntile ? nx : tl);
+        }
+        __syncthreads();
+        // ---- 2. LayerNorm backward of rows 8 w .. + 7 (layernorm_act_bwd_vec_kernel<8, 64, bf16, bf16, bf16>)
+        float gm[8];
+        ldv<8>(lgb + lane * 8, gm);
+        RowTB tb(r0, Bp);
+#pragma unroll
+        for (int p = 0; p < 8; ++p, tb.step(1, Bp)) {
             const long r = r0 + p;
             if (r >= rows) continue;
             float v[8], go[8];
@@ -1474,7 +1539,7 @@ __global__ __launch_bounds__(512) void attn_ln_bwd_h256_kernel(
             for (int i = 0; i < 8; ++i) v[i] = (float)xr[p][i];
             ldv_bf16<8>(lds + (8 * w + p) * AB2_LDV + lane * 8, go);
             {
-                const int t = (int)(r / Bp), b = (int)(r - (long)t * Bp);
+                const int t = tb.t, b = tb.b;
                 if (b < B) {
                     const float a = attn[(size_t)b * T + t];
                     float dcv[8];
@@ -1508,8 +1573,10 @@ __global__ __launch_bounds__(512) void attn_ln_bwd_h256_kernel(
             for (int i = 0; i < 8; ++i) v[i] = rstd * __builtin_fmaf(-v[i], m2, go[i] - m1);
             stv_bf16<8>(dX + (size_t)r * W + lane * 8, v);
         }
-        __syncthreads();
+        // no barrier here: the next tile's dU writes go to `ldu`, last read before the barrier above; its dV writes come
+        // after its own first barrier, which every wave reaches only when it has finished reading this tile's dV rows
     }
+    __syncthreads();
     float* red = reinterpret_cast<float*>(lds);          // [2][8][W] floats = 32 KB
 #pragma unroll
     for (int i = 0; i < 8; ++i) { red[(0 * 8 + w) * W + lane * 8 + i] = dga[i]; red[(1 * 8 + w) * W + lane * 8 + i] = dba[i]; }
@@ -1710,7 +1777,7 @@ extern "C" int lob_attn_ln_bwd_bf16(const void* X16, const float* gamma, const f
                                     const float* dctx, int T, int B, int Bp, int H, int D, float eps, void* stream) {
     if (!X16 || !gamma || !beta || !dU16 || !W1T_16 || !dX16 || !dgamma || !dbeta || !attn || !dctx || T <= 0 || B <= 0 ||
         Bp < B) return LOB_E_ARG;
-    if ((H != 128 && H != 256) || D != 2 || (Bp % 32)) return LOB_E_SHAPE;
+    if ((H != 128 && H != 256) || D != 2 || (Bp % 32) || (long)T * Bp >= (1L << 31)) return LOB_E_SHAPE;
     if ((reinterpret_cast<uintptr_t>(X16) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta) |
          reinterpret_cast<uintptr_t>(dU16) | reinterpret_cast<uintptr_t>(W1T_16) | reinterpret_cast<uintptr_t>(dX16) |
          reinterpret_cast<uintptr_t>(dctx)) & 15) return LOB_E_ALIGN;
@@ -1738,7 +1805,7 @@ extern "C" int lob_attn_scores_bf16(const void* Y16, const float* gamma, const f
                                     const float* b1, const float* w2, const float* b2, void* V, float* U, float* S,
                                     int T, int B, int Bp, int H, int D, float eps, void* stream) {
     if (!Y16 || !gamma || !beta || !W1_16 || !w2 || !V || !S || T <= 0 || B <= 0 || Bp < B) return LOB_E_ARG;
-    if ((H != 128 && H != 256) || D != 2 || (Bp % 32)) return LOB_E_SHAPE;
+    if ((H != 128 && H != 256) || D != 2 || (Bp % 32) || (long)T * Bp >= (1L << 31)) return LOB_E_SHAPE;
     if ((reinterpret_cast<uintptr_t>(Y16) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta) |
          reinterpret_cast<uintptr_t>(W1_16) | reinterpret_cast<uintptr_t>(w2) | reinterpret_cast<uintptr_t>(V) |
          reinterpret_cast<uintptr_t>(U)) & 15) return LOB_E_ALIGN;
