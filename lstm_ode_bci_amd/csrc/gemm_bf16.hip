@@ -1147,8 +1147,11 @@ extern "C" int lob_gemm_tn_bf16(const void* A, int a_bf16, int lda, const void* 
     const bool dma = a_bf16 && b_bf16 && nt_dma_enabled() && M % 256 == 0 && N % 256 == 0 && Kc % 32 == 0;
     const int tm = dma ? 256 : 128, tn = dma ? 256 : 128;
     const int tiles = ((M + tm - 1) / tm) * ((N + tn - 1) / tn);
-    const int target = dma ? 256 : 2048;                  // workgroups: one per CU for the big tiles (fewer, larger
-                                                          // partial sums = fewer atomics), 8 per CU otherwise
+    const int target = dma ? 256 : 1024;                  // workgroups: one per CU for the big tiles (fewer, larger
+                                                          // partial sums = fewer atomics), 4 per CU otherwise (round 4: the
+                                                          // two small weight gradients of the mixed step, 128 x 256 and
+                                                          // 128 x 64 over 2^20 rows, 0.214 + 0.113 -> 0.176 + 0.094 ms
+                                                          // against 8 per CU; 2 per CU: the same; 1 per CU: slower)
     int nchunk = (target + tiles - 1) / tiles;
     int kchunk = (Kc + nchunk - 1) / nchunk;
     kchunk = ((kchunk + TK2 - 1) / TK2) * TK2;

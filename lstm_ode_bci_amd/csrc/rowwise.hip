@@ -902,24 +902,28 @@ __global__ __launch_bounds__(256, 2) void attn_score_kernel(
     const long rows = (long)T * Bp;
     const long ntile = (rows + 127) >> 7;
     const float invw = 1.0f / (float)W;
+    // The rows run one tile AHEAD (round 4): pass p's registers are re-requested for the next tile as soon as the pass has
+    // consumed them, so a tile no longer opens with an HBM round trip.  Rows past the end: clamped address, zero value.
+    ip_bf16x8 raw[16];
+    auto load_row = [&](long tl, int p) {
+        const long r = tl * 128 + 32 * w + 2 * p + hi;
+        raw[p] = *reinterpret_cast<const ip_bf16x8*>(Y + (size_t)(r < rows ? r : rows - 1) * W + l31 * 8);
+    };
+    if ((long)blockIdx.x < ntile) {
+#pragma unroll
+        for (int p = 0; p < 16; ++p) load_row(blockIdx.x, p);
+    }
     for (long tl = blockIdx.x; tl < ntile; tl += gridDim.x) {
         const long r0 = tl * 128 + 32 * w;
+        const long nx = tl + gridDim.x < ntile ? tl + gridDim.x : tl;
         // ---- 1. LayerNorm of this wave's 32 rows (two per pass on 32 lanes each)
-        ip_bf16x8 raw[16];
-#pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            const long r = r0 + 2 * p + hi;
-            ip_bf16x8 z;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) z[i] = (__bf16)0.f;
-            raw[p] = r < rows ? *reinterpret_cast<const ip_bf16x8*>(Y + (size_t)r * W + l31 * 8) : z;
-        }
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
             const long r = r0 + 2 * p + hi;
             float v[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = (float)raw[p][i];
+            for (int i = 0; i < 8; ++i) v[i] = r < rows ? (float)raw[p][i] : 0.f;
+            load_row(nx, p);
             float s = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) s += v[i];
@@ -1436,13 +1440,14 @@ __global__ __launch_bounds__(512) void attn_score_h256_kernel(
 }
 
 // The backward tail at H = 256 (width 512, dU 256 wide): eight waves per 64-row tile; wave w owns 64 of dV's 512 columns
-// (2 column blocks x 16 k-steps = 32 B fragments of W1^T) and the LayerNorm backward of rows 8 w .. + 7 with the width-512
+// (2 column blocks x 16 k-steps = 32 B fragments of W1^T) and the LayerNorm backward of eight rows with the width-512
 // kernel's lane assignment (64 lanes x 8 columns, one row per pass).
-// Round 4: one workgroup per CU with all eight waves in the same phase left every HBM round trip exposed (1.03 ms for
-// 2.7 GB).  Now (i) the LayerNorm inputs of tile q are requested BEFORE its MFMAs and land behind them, the dU rows of
-// tile q + 1 before its LayerNorm phase, (ii) the dU tile has an LDS region of its own, so a tile costs two barriers instead of four, (iii)
-// the two 32-row blocks are multiplied one after the other (32 accumulator registers live instead of 64: room for the
-// rows in flight), (iv) gamma / beta sit in LDS.  Same arithmetic in the same order: bit-identical dx.
+// Round 4 (as attn_ln_bwd_kernel above; 0.99 -> see HISTORY.md): a tile is 8 windows x 8 time steps and wave w keeps window
+// b0 + w, so its dctx row is loaded once per tile and its attention weights are scalar loads; the LayerNorm inputs, dctx
+// and the weights are requested BEFORE the tile's MFMAs and land behind them, the dU rows of the next tile during the
+// LayerNorm passes; the dU tile has an LDS region of its own (two barriers per tile instead of four); the two 32-row blocks
+// are multiplied one after the other (32 accumulator registers live instead of 64: room for the rows in flight); gamma
+// sits in LDS.  Same arithmetic per row: bit-identical dx; dgamma / dbeta sum the rows in another order.
 constexpr int AB2_LDA = 264;           // bf16 row stride of the dU tile (528 B)
 constexpr int AB2_LDV = 520;           // bf16 row stride of the dV tile (1040 B)
 
@@ -1455,7 +1460,8 @@ __global__ __launch_bounds__(512) void attn_ln_bwd_h256_kernel(
     __shared__ __attribute__((aligned(16))) __bf16 lds[64 * AB2_LDV];          // dV tile; the dgamma / dbeta partials at the end
     __shared__ __attribute__((aligned(16))) __bf16 ldu[64 * AB2_LDA];          // dU tile
     __shared__ __attribute__((aligned(16))) float lgb[W];                       // gamma
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     ip_bf16x8 wf[2][16];
 #pragma unroll
@@ -1467,34 +1473,49 @@ __global__ __launch_bounds__(512) void attn_ln_bwd_h256_kernel(
     float dga[8], dba[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { dga[i] = 0.f; dba[i] = 0.f; }
-    const long rows = (long)T * Bp;
-    const long ntile = (rows + 63) >> 6;
+    const int nbb = Bp >> 3;                             // window blocks
+    const long ntile = (long)((T + 7) >> 3) * nbb;
     const float invw = 1.0f / (float)W;
-    // this wave's 8 rows of dU (512 B each): lane -> (row l / 32 + 2 i, 16-byte chunk l % 32); rows past the end are
-    // clamped (they only feed dV rows that nobody reads)
-    ip_bf16x8 du[4];
-    auto load_du = [&](long tl) {
-        const long r0 = tl * 64 + 8 * w;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const long r = r0 + (lane >> 5) + 2 * i;
-            du[i] = *reinterpret_cast<const ip_bf16x8*>(dU + (size_t)(r < rows ? r : rows - 1) * W2 + 8 * (lane & 31));
-        }
+    // tile -> (first time step, first window); its rows: (t0 + p) * Bp + b0 + j, p < 8, j < 8; local index 8 p + j
+    auto origin = [&](long tl, int& t0, int& b0) {
+        const int tb = (int)((unsigned)tl / (unsigned)nbb);
+        t0 = 8 * tb;
+        b0 = 8 * ((int)tl - tb * nbb);
     };
-    if ((long)blockIdx.x < ntile) load_du(blockIdx.x);
+    auto row_of = [&](int t0, int b0, int p, int j) -> size_t {      // clamped to the last time step (results masked)
+        const int t = t0 + p < T ? t0 + p : T - 1;
+        return (size_t)t * Bp + b0 + j;
+    };
+    // wave w brings in the dU rows of time step t0 + w (8 consecutive rows, 4 KB): lane -> (row l / 32 + 2 i, chunk l % 32)
+    ip_bf16x8 du[4];
+    auto load_du = [&](int t0, int b0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            du[i] = *reinterpret_cast<const ip_bf16x8*>(dU + row_of(t0, b0, w, (lane >> 5) + 2 * i) * W2 + 8 * (lane & 31));
+    };
+    if ((long)blockIdx.x < ntile) {
+        int t0, b0;
+        origin(blockIdx.x, t0, b0);
+        load_du(t0, b0);
+    }
     for (long tl = blockIdx.x; tl < ntile; tl += gridDim.x) {
-        const long r0 = tl * 64 + 8 * w;
+        int t0, b0;
+        origin(tl, t0, b0);
         // ---- 0. dU rows (requested a tile ago) into their LDS tile
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             *reinterpret_cast<ip_bf16x8*>(ldu + (8 * w + (lane >> 5) + 2 * i) * AB2_LDA + 8 * (lane & 31)) = du[i];
-        // the LayerNorm inputs of this wave's 8 rows: in flight during the MFMAs
+        // this wave's window b0 + w: its eight LayerNorm inputs, its dctx row, its attention weights (0 for a padding
+        // window): in flight during the MFMAs
         ip_bf16x8 xr[8];
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const long r = r0 + p;
-            xr[p] = *reinterpret_cast<const ip_bf16x8*>(X + (size_t)(r < rows ? r : rows - 1) * W + lane * 8);
-        }
+        for (int p = 0; p < 8; ++p) xr[p] = *reinterpret_cast<const ip_bf16x8*>(X + row_of(t0, b0, p, w) * W + lane * 8);
+        const bool real = b0 + w < B;
+        const int bb = real ? b0 + w : 0;
+        float dcv[8], av[8];
+        ldv<8>(dctx + (size_t)bb * W + lane * 8, dcv);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) av[p] = attn[(size_t)bb * T + (t0 + p < T ? t0 + p : T - 1)];
         __syncthreads();
         // ---- 1. dV = dU W1: this wave's 64 columns for the 64 rows (operands swapped like the unfused GEMM), rounded to
         //         bf16 as the unfused GEMM stores it, row-major into the dV tile
@@ -1521,32 +1542,28 @@ __global__ __launch_bounds__(512) void attn_ln_bwd_h256_kernel(
                     *reinterpret_cast<ab_bf16x4*>(lds + (32 * rb + l31) * AB2_LDV + 64 * w + 32 * cb + 8 * q4 + 4 * hi) = pk;
                 }
         }
-        {   // the next tile's dU rows: in flight during the LayerNorm phase
+        {   // the next tile's dU rows: in flight during the LayerNorm passes
             const long nx = tl + gridDim.x;
-            load_du(nx < ntile ? nx : tl);
+            int nt0, nb0;
+            origin(nx < ntile ? nx : tl, nt0, nb0);
+            load_du(nt0, nb0);
         }
         __syncthreads();
-        // ---- 2. LayerNorm backward of rows 8 w .. + 7 (layernorm_act_bwd_vec_kernel<8, 64, bf16, bf16, bf16>)
+        // ---- 2. LayerNorm backward of window b0 + w, time steps t0 .. t0 + 7
+        //         (layernorm_act_bwd_vec_kernel<8, 64, bf16, bf16, bf16>'s arithmetic)
         float gm[8];
         ldv<8>(lgb + lane * 8, gm);
-        RowTB tb(r0, Bp);
 #pragma unroll
-        for (int p = 0; p < 8; ++p, tb.step(1, Bp)) {
-            const long r = r0 + p;
-            if (r >= rows) continue;
+        for (int p = 0; p < 8; ++p) {
+            if (t0 + p >= T) continue;
             float v[8], go[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = (float)xr[p][i];
-            ldv_bf16<8>(lds + (8 * w + p) * AB2_LDV + lane * 8, go);
-            {
-                const int t = tb.t, b = tb.b;
-                if (b < B) {
-                    const float a = attn[(size_t)b * T + t];
-                    float dcv[8];
-                    ldv<8>(dctx + (size_t)b * W + lane * 8, dcv);
+            ldv_bf16<8>(lds + (8 * p + w) * AB2_LDV + lane * 8, go);
+            if (real) {
+                const float a = av[p];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) go[i] = fmaf(a, dcv[i], go[i]);
-                }
+                for (int i = 0; i < 8; ++i) go[i] = fmaf(a, dcv[i], go[i]);
             }
             float s = 0.f;
 #pragma unroll
@@ -1571,7 +1588,7 @@ __global__ __launch_bounds__(512) void attn_ln_bwd_h256_kernel(
             m2 = row_sum<64>(m2) * invw;
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = rstd * __builtin_fmaf(-v[i], m2, go[i] - m1);
-            stv_bf16<8>(dX + (size_t)r * W + lane * 8, v);
+            stv_bf16<8>(dX + ((size_t)(t0 + p) * Bp + b0 + w) * W + lane * 8, v);
         }
         // no barrier here: the next tile's dU writes go to `ldu`, last read before the barrier above; its dV writes come
         // after its own first barrier, which every wave reaches only when it has finished reading this tile's dV rows
@@ -1782,7 +1799,7 @@ extern "C" int lob_attn_ln_bwd_bf16(const void* X16, const float* gamma, const f
          reinterpret_cast<uintptr_t>(dU16) | reinterpret_cast<uintptr_t>(W1T_16) | reinterpret_cast<uintptr_t>(dX16) |
          reinterpret_cast<uintptr_t>(dctx)) & 15) return LOB_E_ALIGN;
     if (H == 256) {
-        const long nt = ((long)T * Bp + 63) / 64;
+        const long nt = (long)((T + 7) / 8) * (Bp / 8);            // tiles of 8 windows x 8 time steps
         const int nb2 = (int)(nt < 256 ? nt : 256);
         hipLaunchKernelGGL(attn_ln_bwd_h256_kernel, dim3(nb2), dim3(512), 0, (hipStream_t)stream,
                            reinterpret_cast<const __bf16*>(X16), gamma, beta, reinterpret_cast<const __bf16*>(dU16),
@@ -1791,7 +1808,7 @@ extern "C" int lob_attn_ln_bwd_bf16(const void* X16, const float* gamma, const f
         LOB_CHECK_LAUNCH();
         return 0;
     }
-    const long ntile = ((long)T * Bp + 127) / 128;
+    const long ntile = (long)((T + 7) / 8) * (Bp / 16);         // tiles of 16 windows x 8 time steps
     const int nb = (int)(ntile < 256 ? ntile : 256);      // one 8-wave workgroup per CU
     hipLaunchKernelGGL(attn_ln_bwd_kernel, dim3(nb), dim3(512), 0, (hipStream_t)stream,
                        reinterpret_cast<const __bf16*>(X16), gamma, beta, reinterpret_cast<const __bf16*>(dU16),
