@@ -86,7 +86,9 @@ const char* lob_build_id(void);
 #define LOB_VAR_F32_SPLIT    14  /* 1: fp32 gate GEMMs / recurrent kernels / backward GEMMs (H=128) carry each operand as two
                                   *    fp16 halves (22 bits) on the 16-bit matrix pipe; 0: exact-fp32 MFMA; 2: as 1, with
                                   *    lob_gemm_nt_f32_split / lob_gemm_tn_f32_split on their twins that split at every fragment
-                                  *    read instead of once while staging (same arithmetic up to the summation order)        */
+                                  *    read instead of once while staging (same arithmetic up to the summation order); 3: as 1,
+                                  *    with those two on their general kernels where the pipelined ones would run (whole
+                                  *    128 x 128 tiles; bit-identical twins)                                                    */
 #define LOB_VAR_H256_LDSW    15  /* H=256 recurrent kernels: 0 = all W_hh fragments streamed; 1 = part of them resident in LDS      */
 #define LOB_VAR_DX_KSPLIT    16  /* 1: dX = dP W_ih on the k-split weight-stationary kernel; 0: tiled LDS-DMA NT GEMM          */
 #define LOB_VAR_REC_FEW      17  /* 1: mixed inference forward with fewer than 4 windows skips the padding registers' cell update */

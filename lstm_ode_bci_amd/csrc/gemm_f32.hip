@@ -592,6 +592,32 @@ struct GemmTNS {
     const float* amax_a; const float* amax_b;
 };
 
+// One row piece (8 k-rows apart) of the staging: load / split + store.  Pieces let the pipelined kernel below spread the
+// conversion of a tile between the MFMA groups of the previous one.
+__device__ __forceinline__ f32x4 ldk_piece(const float* __restrict__ G, int ld, int k0, int c0, int tid, int i) {
+    return *reinterpret_cast<const f32x4*>(G + (size_t)(k0 + (tid >> 5) + 8 * i) * ld + c0 + (tid & 31) * 4);
+}
+__device__ __forceinline__ void stk_piece(_Float16* Shi, _Float16* Slo, int tid, const f32x4& r, float scale, int i) {
+    const int kk = tid >> 5, c4 = (tid & 31) * 4;
+    f16x4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float sv = r[e] * scale;
+        const _Float16 hh = (_Float16)sv;
+        h[e] = hh;
+        l[e] = (_Float16)((sv - (float)hh) * SPLIT_LO);
+    }
+    *reinterpret_cast<f16x4*>(Shi + (kk + 8 * i) * SLDK + c4) = h;
+    *reinterpret_cast<f16x4*>(Slo + (kk + 8 * i) * SLDK + c4) = l;
+}
+
+// FAST (round 4, second half): M, N multiples of 128 and every contraction chunk a whole, even number of 32-row tiles.
+// The general kernel (FAST = false) guards each of its 8 loads with a branch, requests a tile only ONE step ahead -- its
+// 24 MFMAs (0.4 us) do not cover an HBM round trip -- and converts after the MFMAs, behind a `if (more)` the scheduler
+// cannot move code across: the matrix pipe sat idle ~70 % of a step.  Here tile t + 2 is requested while tile t is
+// multiplied (two register sets), the loads are unguarded, and the split + LDS store of tile t + 1 is written piece by piece
+// BETWEEN the MFMA groups of tile t in one basic block.  Same products, same accumulation order: bit-identical results.
+template <bool FAST>
 __global__ __launch_bounds__(256, 2) void gemm_tn_split_kernel(GemmTNS g) {
     __shared__ __attribute__((aligned(16))) _Float16 lds[2 * 4 * STK * SLDK];      // [buf][A hi, A lo, B hi, B lo][32][160]: 80 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -612,6 +638,61 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_split_kernel(GemmTNS g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; asm_[i][j][r] = 0.f; }
 
+    if constexpr (FAST) {
+        // ONE register set: piece q of the next tile is split + stored after MFMA triple q of this tile, and the same
+        // registers are re-requested at once for the tile after next (two sets spilled next to the 128 accumulators)
+        f32x4 ra[4], rb[4];
+        auto ldp = [&](int k0, int q) {
+            k0 = k0 < kend ? k0 : kend - STK;              // past the end: the last tile again (L2 hit, never multiplied)
+            if (q < 4) ra[q] = ldk_piece(g.A, g.lda, k0, m0, tid, q);
+            else       rb[q - 4] = ldk_piece(g.B, g.ldb, k0, n0, tid, q - 4);
+        };
+        auto stp = [&](_Float16* nb, int q) {
+            if (q < 4) stk_piece(nb, nb + STK * SLDK, tid, ra[q], sa, q);
+            else       stk_piece(nb + 2 * STK * SLDK, nb + 3 * STK * SLDK, tid, rb[q - 4], sb, q - 4);
+        };
+        // multiply the tile in `buf` (contraction rows k0 ..); the registers hold tile k0 + STK, refilled with k0 + 2 STK
+        auto step = [&](int buf, int k0) {
+            const _Float16* ah_s = lds + buf * 4 * STK * SLDK;
+            const _Float16* al_s = ah_s + STK * SLDK;
+            const _Float16* bh_s = ah_s + 2 * STK * SLDK;
+            const _Float16* bl_s = ah_s + 3 * STK * SLDK;
+            _Float16* nb = lds + (buf ^ 1) * 4 * STK * SLDK;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                f16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    ah[i] = tr_frag_h(ah_s, 64 * wr + 32 * i, s2, lane);
+                    al[i] = tr_frag_h(al_s, 64 * wr + 32 * i, s2, lane);
+                    bh[i] = tr_frag_h(bh_s, 64 * wc + 32 * i, s2, lane);
+                    bl[i] = tr_frag_h(bl_s, 64 * wc + 32 * i, s2, lane);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = mfma_h(ah[i], bh[j], acc[i][j]);
+                        asm_[i][j] = mfma_h(ah[i], bl[j], asm_[i][j]);
+                        asm_[i][j] = mfma_h(al[i], bh[j], asm_[i][j]);
+                        const int q = 4 * s2 + 2 * i + j;
+                        stp(nb, q);
+                        ldp(k0 + 2 * STK, q);
+                    }
+            }
+        };
+#pragma unroll
+        for (int q = 0; q < 8; ++q) ldp(kbeg, q);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { stp(lds, q); ldp(kbeg + STK, q); }
+        __syncthreads();
+        for (int k0 = kbeg; k0 < kend; k0 += 2 * STK) {
+            step(0, k0);
+            __syncthreads();
+            step(1, k0 + STK);
+            __syncthreads();
+        }
+    } else {
     f32x4 ra[4], rb[4];
     auto load = [&](int k0) {
         ldk_f32s(g.A, g.lda, k0, kend, m0, g.M, tid, ra);
@@ -655,6 +736,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_split_kernel(GemmTNS g) {
         if (more) store(buf ^ 1);
         __syncthreads();
         buf ^= 1;
+    }
     }
     const float r_hh = 1.f / (sa * sb), r_sm = r_hh * (1.f / SPLIT_LO);
 #pragma unroll
@@ -707,6 +789,10 @@ __device__ __forceinline__ void st_rows_s(_Float16* Shi, _Float16* Slo, int tid,
     }
 }
 
+// FAST (round 4, as gemm_tn_split_kernel<true>): M, N multiples of 128, K a multiple of 64: unguarded loads two k-tiles
+// ahead (two register sets), the split + LDS store of k-tile q + 1 written piece by piece between the MFMA groups of
+// k-tile q.  Bit-identical to the general kernel.
+template <bool FAST>
 __global__ __launch_bounds__(256, 2) void gemm_nt_split_kernel(GemmNT g) {
     __shared__ __attribute__((aligned(16))) _Float16 lds[2 * 4 * 128 * NLD];       // [buf][A hi, A lo, W hi, W lo][128][40]: 80 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -718,20 +804,47 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_split_kernel(GemmNT g) {
     const float sa = lob_split_scale(*g.amax_a), sw_ = lob_split_scale(*g.amax_w);
     const float r_hh = 1.f / (sa * sw_), r_sm = r_hh * (1.f / SPLIT_LO);
 
-    f32x4 ra[4], rw[4];
+    f32x4 ra[1][4], rw[1][4];
     auto load = [&](int m0, int n0, int k0) {
-        ld_rows_s(g.A, g.lda, m0, g.M, k0, g.K, tid, ra);
-        ld_rows_s(g.W, g.ldw, n0, g.N, k0, g.K, tid, rw);
+        ld_rows_s(g.A, g.lda, m0, g.M, k0, g.K, tid, ra[0]);
+        ld_rows_s(g.W, g.ldw, n0, g.N, k0, g.K, tid, rw[0]);
     };
     auto store = [&](int b) {
         _Float16* base = lds + b * 4 * 128 * NLD;
-        st_rows_s(base, base + 128 * NLD, tid, ra, sa);
-        st_rows_s(base + 2 * 128 * NLD, base + 3 * 128 * NLD, tid, rw, sw_);
+        st_rows_s(base, base + 128 * NLD, tid, ra[0], sa);
+        st_rows_s(base + 2 * 128 * NLD, base + 3 * 128 * NLD, tid, rw[0], sw_);
+    };
+    // FAST: one register set, piece-wise (see gemm_tn_split_kernel<true>); unguarded; a k-tile past the end is the last
+    // one again (L2 hit, never multiplied)
+    auto ldp = [&](int m0, int n0, int k0, int q) {
+        k0 = k0 < g.K ? k0 : g.K - NKT;
+        const int rr = tid >> 3, c4 = (tid & 7) * 4;
+        if (q < 4) ra[0][q] = *reinterpret_cast<const f32x4*>(g.A + (size_t)(m0 + rr + 32 * q) * g.lda + k0 + c4);
+        else       rw[0][q - 4] = *reinterpret_cast<const f32x4*>(g.W + (size_t)(n0 + rr + 32 * (q - 4)) * g.ldw + k0 + c4);
+    };
+    auto stp = [&](_Float16* nb, int q) {
+        const int rr = tid >> 3, c4 = (tid & 7) * 4, i = q & 3;
+        const f32x4& r = q < 4 ? ra[0][i] : rw[0][i];
+        const float scale = q < 4 ? sa : sw_;
+        _Float16* Shi = nb + (q < 4 ? 0 : 2 * 128 * NLD);
+        f16x4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float sv = r[e] * scale;
+            const _Float16 hh = (_Float16)sv;
+            h[e] = hh;
+            l[e] = (_Float16)((sv - (float)hh) * SPLIT_LO);
+        }
+        *reinterpret_cast<f16x4*>(Shi + (rr + 32 * i) * NLD + c4) = h;
+        *reinterpret_cast<f16x4*>(Shi + 128 * NLD + (rr + 32 * i) * NLD + c4) = l;
     };
     int it = slot;
     if (it >= ntile) return;
     int m0 = ((it / ntn) * 8 + xcd) * BM, n0 = (it % ntn) * BN;
-    load(m0, n0, 0);
+    if constexpr (FAST) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) ldp(m0, n0, 0, q);
+    } else load(m0, n0, 0);
     while (true) {
         f32x16 acc[2][2], asm_[2][2];
 #pragma unroll
@@ -740,6 +853,46 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_split_kernel(GemmNT g) {
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; asm_[i][j][r] = 0.f; }
+        if constexpr (FAST) {
+            // multiply the k-tile in `buf` (kt); the registers hold k-tile kt + 1, refilled with kt + 2
+            auto step = [&](int buf, int kt) {
+                const _Float16* base = lds + buf * 4 * 128 * NLD;
+                _Float16* nb = lds + (buf ^ 1) * 4 * 128 * NLD;
+                const _Float16* ap = base + (64 * wr + (lane & 31)) * NLD + 8 * (lane >> 5);
+                const _Float16* bp = base + 2 * 128 * NLD + (64 * wc + (lane & 31)) * NLD + 8 * (lane >> 5);
+#pragma unroll
+                for (int ks = 0; ks < NKT / 16; ++ks) {
+                    f16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        ah[i] = *reinterpret_cast<const f16x8*>(ap + 32 * i * NLD + 16 * ks);
+                        al[i] = *reinterpret_cast<const f16x8*>(ap + 128 * NLD + 32 * i * NLD + 16 * ks);
+                        bh[i] = *reinterpret_cast<const f16x8*>(bp + 32 * i * NLD + 16 * ks);
+                        bl[i] = *reinterpret_cast<const f16x8*>(bp + 128 * NLD + 32 * i * NLD + 16 * ks);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            acc[i][j] = mfma_h(ah[i], bh[j], acc[i][j]);
+                            asm_[i][j] = mfma_h(ah[i], bl[j], asm_[i][j]);
+                            asm_[i][j] = mfma_h(al[i], bh[j], asm_[i][j]);
+                            const int q = 4 * ks + 2 * i + j;
+                            stp(nb, q);
+                            ldp(m0, n0, (kt + 2) * NKT, q);
+                        }
+                }
+            };
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { stp(lds, q); ldp(m0, n0, NKT, q); }
+            __syncthreads();
+            for (int kt = 0; kt < nk; kt += 2) {
+                step(0, kt);
+                __syncthreads();
+                step(1, kt + 1);
+                __syncthreads();
+            }
+        } else {
         store(0);
         __syncthreads();
         int buf = 0;
@@ -771,12 +924,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_split_kernel(GemmNT g) {
             __syncthreads();
             buf ^= 1;
         }
+        }
         const int nit = it + nslot;
         const bool more = nit < ntile;
         const int cm0 = m0, cn0 = n0;
         if (more) {                                   // the next tile's first operand tiles are requested before this tile's stores
             m0 = ((nit / ntn) * 8 + xcd) * BM; n0 = (nit % ntn) * BN;
-            load(m0, n0, 0);
+            if constexpr (FAST) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) ldp(m0, n0, 0, q);
+            } else load(m0, n0, 0);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -886,8 +1043,10 @@ extern "C" int lob_gemm_nt_f32_split(const float* A, int lda, const float* W, in
     // LOB_VAR_F32_SPLIT = 2: the twin that splits at every fragment read (LDS-DMA'd fp32 tiles)
     if (lob_variant(LOB_VAR_F32_SPLIT) == 2)
         hipLaunchKernelGGL((gemm_nt_dma_f32_kernel<0, true>), dim3((unsigned)gsz), dim3(256), 0, (hipStream_t)stream, g);
-    else
-        hipLaunchKernelGGL(gemm_nt_split_kernel, dim3((unsigned)gsz), dim3(256), 0, (hipStream_t)stream, g);
+    else if (M % BM == 0 && N % BN == 0 && K % (2 * NKT) == 0 && lob_variant(LOB_VAR_F32_SPLIT) != 3)
+        hipLaunchKernelGGL((gemm_nt_split_kernel<true>), dim3((unsigned)gsz), dim3(256), 0, (hipStream_t)stream, g);
+    else                                              // F32_SPLIT = 3: the general kernel, the pipelined one's bit-identical twin
+        hipLaunchKernelGGL((gemm_nt_split_kernel<false>), dim3((unsigned)gsz), dim3(256), 0, (hipStream_t)stream, g);
     LOB_CHECK_LAUNCH();
     return 0;
 }
@@ -958,12 +1117,16 @@ extern "C" int lob_gemm_tn_f32_split(const float* A, int lda, const float* B, in
     // split once while staging; the chunks of one contraction range sit 8 apart in blockIdx (one XCD: shared source tiles)
     int nchunk = (2048 + tiles - 1) / tiles;
     int kchunk = (Kc + nchunk - 1) / nchunk;
-    kchunk = ((kchunk + STK - 1) / STK) * STK;
+    kchunk = ((kchunk + 2 * STK - 1) / (2 * STK)) * (2 * STK);
     if (kchunk < 512) kchunk = 512;
     nchunk = (Kc + kchunk - 1) / kchunk;
     const int nchunk8 = ((nchunk + 7) / 8) * 8;
     GemmTNS g{A, B, C, lda, ldb, ldc, M, N, Kc, kchunk, tiles, amax_a, amax_b};
-    hipLaunchKernelGGL(gemm_tn_split_kernel, dim3((unsigned)(tiles * nchunk8)), dim3(256), 0, (hipStream_t)stream, g);
+    // the pipelined kernel wants whole 128 x 128 tiles and an even number of 32-row stages per chunk; F32_SPLIT = 3 forces
+    // the general kernel on the same chunks (its bit-identical twin)
+    const bool fast = M % 128 == 0 && N % 128 == 0 && Kc % (2 * STK) == 0 && lob_variant(LOB_VAR_F32_SPLIT) != 3;
+    if (fast) hipLaunchKernelGGL((gemm_tn_split_kernel<true>), dim3((unsigned)(tiles * nchunk8)), dim3(256), 0, (hipStream_t)stream, g);
+    else      hipLaunchKernelGGL((gemm_tn_split_kernel<false>), dim3((unsigned)(tiles * nchunk8)), dim3(256), 0, (hipStream_t)stream, g);
     LOB_CHECK_LAUNCH();
     return 0;
 }

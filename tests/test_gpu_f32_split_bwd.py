@@ -71,6 +71,38 @@ def test_split_tn_gemm_vs_float64(dev, Kc, M, N, scale):
     assert (twin.double() - ref).abs().max().item() / mx < 3e-6
 
 
+def test_pipelined_split_gemms_are_bit_identical_to_the_general_kernels(dev):
+    """gemm_nt_split_kernel<true> / gemm_tn_split_kernel<true> (whole 128 x 128 tiles, loads a k-tile further ahead, the split
+    of the next tile between the MFMA groups of this one) against the general kernels they replace on those shapes
+    (LOB_VAR_F32_SPLIT = 3), at the fp32 training step's shapes: same products, same order, same chunks."""
+    from lstm_ode_bci_amd import _lib, ops
+    rows = 64 * 4096
+    dP = _rnd((rows, 1024), 1e-4, dev, 11)
+    x = _rnd((rows, 256), 0.5, dev, 12)
+    w = _rnd((256, 1024), 0.05, dev, 13)
+    am = (dP.abs().max().reshape(1), w.abs().max().reshape(1))
+    ax = (dP.abs().max().reshape(1), x.abs().max().reshape(1))
+
+    def run():
+        dx = ops.gemm_nt(dP, w, amax=am)
+        dw = torch.zeros((1024, 256), device=dev)
+        ops.gemm_tn(dP, x, dw, amax=ax)
+        dwh = torch.zeros((512, 128), device=dev)          # dW_hh's operands: column slices, rows shifted by one time step
+        ops.gemm_tn(dP[4096:, 512:], x[:rows - 4096, 128:], dwh, amax=ax)
+        return dx, dw, dwh
+
+    fast = run()
+    with _lib.variant(F32_SPLIT=3):
+        gen = run()
+    # dX has no split-k: bit-identical.  The weight gradients add their chunks' partial sums with fp32 atomics in whatever
+    # order the workgroups finish, in both kernels: equal to summation order
+    assert torch.equal(fast[0], gen[0])
+    for a, b in zip(fast[1:], gen[1:]):
+        assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item()
+    ref = dP.double().t() @ x.double()
+    assert (fast[1].double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize("T,Bp,D,dyscale", [(24, 64, 2, 1e-3), (5, 32, 1, 1e-9), (40, 96, 2, 300.0)])
 def test_split_bptt_vs_exact_twin(dev, T, Bp, D, dyscale):
     """Same saved gates / cell states / dY through lob_lstm_rec_bwd_f32_x and through the exact-fp32 MFMA kernel: dP, the bias
