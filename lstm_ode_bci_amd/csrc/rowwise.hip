@@ -808,10 +808,16 @@ __global__ __launch_bounds__(256, 2) void input_proj_ln_kernel(
             for (int r = 0; r < 16; ++r)
                 tw[((r & 3) + 8 * (r >> 2) + 4 * hi) * IP_LD + 32 * cb + l31] = acc[cb][r] + bv[cb];
         // LayerNorm + activation + dropout, four rows per pass on 16 lanes each (layernorm_act_vec_kernel<8, true, 16>)
+        // (window, time) of a pass's row by increments from one 32-bit division per tile (round 4: `r / T` on the 64-bit row
+        // index was ~70 of a pass's ~250 instructions; the entry point refuses rows >= 2^31)
+        int bwi = (int)((unsigned)(r0 + sub) / (unsigned)T), tti = (int)((unsigned)(r0 + sub) - (unsigned)bwi * (unsigned)T);
 #pragma unroll 2
         for (int ps = 0; ps < 8; ++ps) {
             const int rt = 4 * ps + sub;
             const long r = r0 + rt;
+            const int orow = tti * Bp + bwi;
+            tti += 4;
+            while (tti >= T) { tti -= T; ++bwi; }
             if (r >= rows) continue;
             float v[8];
             {
@@ -823,8 +829,6 @@ __global__ __launch_bounds__(256, 2) void input_proj_ln_kernel(
                     *reinterpret_cast<f32x4*>(pre + (size_t)r * width + 8 * sl + 4) = b;
                 }
             }
-            const long bw = r / T;
-            const int orow = (int)(r - bw * T) * Bp + (int)bw;
             float s = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) s += v[i];
@@ -1717,16 +1721,19 @@ __global__ __launch_bounds__(WIDTH * 2) void input_proj_ln2_kernel(
                 tile[(32 * rb + (r & 3) + 8 * (r >> 2) + 4 * hi) * LDT + 32 * w + l31] = acc[rb][r] + bv;
         __syncthreads();
         // ---- 2. LayerNorm + activation + dropout of this wave's rows, GPW rows per pass (the unfused kernel's lanes)
+        int bwi = (int)((unsigned)(r0 + RPWAVE * w + sub) / (unsigned)T);
+        int tti = (int)((unsigned)(r0 + RPWAVE * w + sub) - (unsigned)bwi * (unsigned)T);
 #pragma unroll 2
         for (int ps = 0; ps < RPWAVE / GPW; ++ps) {
             const int rt = RPWAVE * w + GPW * ps + sub;
             const long r = r0 + rt;
+            const int orow = tti * Bp + bwi;             // (window, time) by increments: see input_proj_ln_kernel
+            tti += GPW;
+            while (tti >= T) { tti -= T; ++bwi; }
             if (r >= rows) continue;
             float v[VPL];
             ldv<VPL>(tile + rt * LDT + VPL * sl, v);
             if (SAVE) stv<VPL>(pre + (size_t)r * WIDTH + VPL * sl, v);
-            const long bw = r / T;
-            const int orow = (int)(r - bw * T) * Bp + (int)bw;
             float s = 0.f;
 #pragma unroll
             for (int i = 0; i < VPL; ++i) s += v[i];
@@ -1867,6 +1874,7 @@ extern "C" int lob_input_proj_ln_bf16(const float* x, int C, const float* W, int
          reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15)
         return LOB_E_ALIGN;
     const long rows = (long)B * T;
+    if (rows + 64 >= (1L << 31) || (long)T * Bp >= (1L << 31)) return LOB_E_SHAPE;       // 32-bit row arithmetic in the kernels
     __bf16* xbb = reinterpret_cast<__bf16*>(xb);
     __bf16* outb = reinterpret_cast<__bf16*>(out);
     // H = 128 runs the wave-per-tile kernel (0.34 against 0.38 ms at B = 4096); LOB_IP_COLWAVE in act selects the
