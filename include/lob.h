@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LOB_VERSION 206
+#define LOB_VERSION 207
 
 #define LOB_E_ARG   (-1)   /* null pointer / non-positive size                      */
 #define LOB_E_SHAPE (-2)   /* shape not supported by this kernel (see each entry)   */
@@ -123,7 +123,10 @@ int lob_gemm_nt_f32(const float* A, int lda, const float* W, int ldw, const floa
  * pre-scales are derived from them; lob_lstm_rec_bwd_f32_x produces the one of dP).  No bias / activation.  16-B aligned
  * operands, lda % 4 == ldw % 4 == 0, K % 32 == 0, K >= 128, N <= 2048; anything else LOB_E_SHAPE.                        */
 int lob_gemm_nt_f32_split(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
-                          const float* amax_a, const float* amax_w, void* stream);
+                          const float* amax_a, const float* amax_w, float drop_p, uint64_t seed, void* stream);
+/*   drop_p > 0 (207): C[row][col] *= the dropout mask of element row * ldc + col (lob_dropout_f32's, same p / seed): the
+ *   backward of a dropout that was fused into the producer of the layer below's output (lob_lstm_rec_fwd_f32_drop);
+ *   LOB_E_SHAPE under LOB_VAR_F32_SPLIT = 2 (the fragment-read twin has no such epilogue).                               */
 
 /* C[M,N] (+)= A[Kc,M]^T * B[Kc,N]  (contraction over the leading/row index; weight
  * gradients dW = dY^T X).  Split over Kc across workgroups, fp32 atomics into C, so C
@@ -169,6 +172,11 @@ int lob_lstm_rec_fwd_f32(float* P, const float* Whh, float* Y, float* Csave,
                          int T, int Bp, int H, int D, int save, const float* range, void* stream);
 /*   range (device, may be NULL; H = 128 fp16-split kernel only): range[d] = max |W_hh| of direction d -- the weight
  *   pre-scale is chosen from it (see lob_gate_gemm_x_f32); h needs none (|h| < 1).                                   */
+/* 207: the saving forward (save = 1) with nn.LSTM's inter-layer dropout (04_lstm_model.py:186) fused into the producer:
+ * Yd [T*Bp][D*H] = dropout(Y), the mask lob_dropout_f32 applies to Y with the same drop_p / seed.  H == 128, Bp % 32 == 0,
+ * LOB_VAR_F32_SPLIT != 0, 0 < drop_p < 1; anything else LOB_E_SHAPE / LOB_E_ARG (run lob_lstm_rec_fwd_f32 + lob_dropout_f32). */
+int lob_lstm_rec_fwd_f32_drop(float* P, const float* Whh, float* Y, float* Yd, float drop_p, uint64_t seed, float* Csave,
+                              int T, int Bp, int H, int D, const float* range, void* stream);
 
 /* 1 if the recurrent kernels for hidden size H use the fragment layout (H = 32, 64, 128, 256:
  * MFMA kernels; W_hh register-resident at 128, streamed from L2 otherwise), 0 for the generic

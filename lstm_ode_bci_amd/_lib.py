@@ -22,13 +22,15 @@ _SIGS = {
     "lob_gemm_tn_f32": ([_f32p, C.c_int, _f32p, C.c_int, _f32p, C.c_int, C.c_int, C.c_int, C.c_int,
                          C.c_void_p], C.c_int),
     "lob_gemm_nt_f32_split": ([_f32p, C.c_int, _f32p, C.c_int, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _f32p,
-                               C.c_void_p], C.c_int),
+                               C.c_float, C.c_uint64, C.c_void_p], C.c_int),
     "lob_gemm_tn_f32_split": ([_f32p, C.c_int, _f32p, C.c_int, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _f32p,
                                C.c_void_p], C.c_int),
     "lob_gate_gemm_x_f32": ([_f32p, C.c_int, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                              C.c_int, _f32p, C.c_void_p], C.c_int),
     "lob_lstm_rec_fwd_f32": ([_f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                               _f32p, C.c_void_p], C.c_int),
+    "lob_lstm_rec_fwd_f32_drop": ([_f32p, _f32p, _f32p, _f32p, C.c_float, C.c_uint64, _f32p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   _f32p, C.c_void_p], C.c_int),
     "lob_layernorm_act_f32": ([_f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
                                C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_void_p], C.c_int),
     "lob_input_proj_bwd_bf16": ([_f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, _f32p, C.c_int, _f32p, _f32p, _f32p, C.c_int, C.c_int,

@@ -118,7 +118,11 @@ def _forward_impl(x, ps, cfg, save):
         last = layer + 1 == L
         drop_here = not last and p_lstm > 0
         bf16_out = ops.can_fuse_dropout(H, mixed)        # the bf16-MFMA recurrent kernel emits bf16 copies itself
-        fuse = drop_here and bf16_out
+        # fp32 path on the fp16-split kernels: the saving forward writes dropout(Y) next to Y (fp32), its backward is the
+        # mask epilogue of the dX GEMM of the layer above
+        fuse32 = (drop_here and not mixed and not bf16_out and frag and r_rng is not None and P.dtype == torch.float32
+                  and ops.can_fuse_dropout_f32(H, Bp, save))
+        fuse = drop_here and (bf16_out or fuse32)
         # mixed mode: layers below the last never materialise fp32 Y (only bf16 consumers remain: the next
         # layer's GEMMs read Yd / Y16, dW_hh reads Y16); the last layer keeps fp32 Y for the LayerNorm
         Y, Cs, Y16, Yd = ops.lstm_rec_fwd(P, whh, T, Bp, H, D, save, mixed=mixed,

@@ -25,6 +25,9 @@ struct GemmNT {
     int T, Bp, H, D;
     // SPLIT kernels: device floats, an upper bound of |A| and of |W| (the operands' power-of-two pre-scales derive from them)
     const float* amax_a; const float* amax_w;
+    // gemm_nt_split_kernel: C *= dropout mask of element (row * ldc + col) -- the backward of a dropout fused into the producer
+    // of the layer below's output (lob_lstm_rec_fwd_f32_drop), as the bf16 NT kernels' epilogue
+    float drop_p; uint64_t seed;
 };
 
 // ---- fp32 products on the 16-bit matrix pipe (round 4: the backward GEMMs of the fp32 path) ---------------------------
@@ -944,7 +947,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_split_kernel(GemmNT g) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = cm0 + 64 * wr + 32 * i + acc_row(r, lane);
-                    if (row < g.M) g.C[(size_t)row * g.ldc + col] = acc[i][j][r] * r_hh + asm_[i][j][r] * r_sm;
+                    if (row < g.M) {
+                        float val = acc[i][j][r] * r_hh + asm_[i][j][r] * r_sm;
+                        if (g.drop_p > 0.f) val *= lob_dropout_scale(g.seed, (uint64_t)row * g.ldc + col, g.drop_p);
+                        g.C[(size_t)row * g.ldc + col] = val;
+                    }
                 }
             }
         if (!more) break;
@@ -1031,11 +1038,12 @@ extern "C" int lob_gemm_nt_f32(const float* A, int lda, const float* W, int ldw,
 // max|W|.  Shapes the LDS-DMA kernel takes (16-B aligned operands, lda % 4 == ldw % 4 == 0, K % 32 == 0, K >= 128,
 // N <= 2048); anything else: LOB_E_SHAPE (the caller keeps lob_gemm_nt_f32).
 extern "C" int lob_gemm_nt_f32_split(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
-                                     const float* amax_a, const float* amax_w, void* stream) {
-    if (!A || !W || !C || !amax_a || !amax_w || M <= 0 || N <= 0 || K <= 0) return LOB_E_ARG;
+                                     const float* amax_a, const float* amax_w, float drop_p, uint64_t seed, void* stream) {
+    if (!A || !W || !C || !amax_a || !amax_w || M <= 0 || N <= 0 || K <= 0 || drop_p < 0.f || drop_p >= 1.f) return LOB_E_ARG;
     if (lda < K || ldw < K || ldc < N) return LOB_E_SHAPE;
     if (!(aligned16(A) && aligned16(W) && lda % 4 == 0 && ldw % 4 == 0 && K % FTK == 0 && K / FTK >= 4 && N <= 2048)) return LOB_E_SHAPE;
-    GemmNT g{A, W, nullptr, C, lda, ldw, ldc, M, N, K, LOB_ACT_NONE, 0, 0, 0, 0, 0, amax_a, amax_w};
+    if (drop_p > 0.f && lob_variant(LOB_VAR_F32_SPLIT) == 2) return LOB_E_SHAPE;        // the fragment-read twin has no mask epilogue
+    GemmNT g{A, W, nullptr, C, lda, ldw, ldc, M, N, K, LOB_ACT_NONE, 0, 0, 0, 0, 0, amax_a, amax_w, drop_p, seed};
     const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
     long gsz = 512;
     const long tiles = (long)ntm * ntn;

@@ -21,7 +21,7 @@
 // H = 128 on 16-row sub-tiles / v_mfma_f32_16x16x4_f32 (lstm_rec_f32_s16.hip)
 int lob_rec_fwd_s16(float* P, const float* Whh, float* Y, float* Csave, int T, int Bp, int D, int save, hipStream_t s);
 int lob_rec_fwd_split(float* P, const float* Whh, float* Y, float* Csave, int T, int Bp, int D, int save, const float* range,
-                      hipStream_t s);
+                      float* Yd, float drop_p, uint64_t seed, hipStream_t s);
 // H = 32 / 64 / 256: W_hh streamed from L2 (lstm_rec_stream.hip)
 int lob_stream_supports(int H);
 int lob_stream_fwd(float* P, const float* Whh, float* Y, float* Csave, int T, int Bp, int H, int D, int save, hipStream_t s);
@@ -453,6 +453,18 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_generic_kernel(
 
 }  // namespace
 
+// The saving forward of the fp16-split kernel (H = 128, LOB_VAR_F32_SPLIT != 0) with nn.LSTM's inter-layer dropout fused into
+// the producer: Yd = dropout(Y), the stand-alone kernel's mask (lob_dropout_f32 with the same p / seed on Y).
+extern "C" int lob_lstm_rec_fwd_f32_drop(float* P, const float* Whh, float* Y, float* Yd, float drop_p, uint64_t seed,
+                                         float* Csave, int T, int Bp, int H, int D, const float* range, void* stream) {
+    if (!P || !Whh || !Y || !Yd || !Csave || T <= 0 || Bp <= 0 || (D != 1 && D != 2) || drop_p <= 0.f || drop_p >= 1.f)
+        return LOB_E_ARG;
+    if (H != 128 || (Bp % 32) || lob_variant(LOB_VAR_F32_SPLIT) == 0) return LOB_E_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(Whh) | reinterpret_cast<uintptr_t>(Csave) |
+         reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(Yd)) & 15) return LOB_E_ALIGN;
+    return lob_rec_fwd_split(P, Whh, Y, Csave, T, Bp, D, 1, range, Yd, drop_p, seed, (hipStream_t)stream);
+}
+
 extern "C" int lob_lstm_rec_fwd_f32(float* P, const float* Whh, float* Y, float* Csave,
                                     int T, int Bp, int H, int D, int save, const float* range, void* stream) {
     if (!P || !Whh || !Y || T <= 0 || Bp <= 0 || H <= 0 || (D != 1 && D != 2)) return LOB_E_ARG;
@@ -466,7 +478,7 @@ extern "C" int lob_lstm_rec_fwd_f32(float* P, const float* Whh, float* Y, float*
         // B = 4096; LOB_REC_FWD=32 selects the 32-row kernel below (kept for A/B measurements)
         // default: the fp32-accurate split kernel on the 16-bit matrix pipe (lstm_rec_f32_split.hip);
         // LOB_VAR_F32_SPLIT = 0 selects the exact-fp32 MFMA kernels (16-row, or 32-row with LOB_VAR_REC_FWD_ROWS = 32)
-        if (lob_variant(LOB_VAR_F32_SPLIT) != 0) return lob_rec_fwd_split(P, Whh, Y, Csave, T, Bp, D, save, range, s);
+        if (lob_variant(LOB_VAR_F32_SPLIT) != 0) return lob_rec_fwd_split(P, Whh, Y, Csave, T, Bp, D, save, range, nullptr, 0.f, 0, s);
         const bool rows32 = lob_variant(LOB_VAR_REC_FWD_ROWS) == 32;
         if (!rows32) return lob_rec_fwd_s16(P, Whh, Y, Csave, T, Bp, D, save, s);
         const dim3 grid(Bp / 32, D), block(256);

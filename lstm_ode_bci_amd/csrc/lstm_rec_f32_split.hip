@@ -47,10 +47,12 @@ __device__ __forceinline__ f32x4 mfma16_f16(f16x8 a, f16x8 b, f32x4 c) {
 // activations are a third of it); the other half of its h tile stays zero, the MFMAs on it are wasted.  Same arithmetic
 // per row: bit-identical to the full-tile kernel (tests/test_gpu_twins.py).  LOB_VAR_REC_HALF = 0 keeps full tiles.
 // PARTS = 4 (quarter tiles: four workgroups per tile, one row j each) where full tiles would fill an eighth of the CUs.
-template <bool SAVE, int PARTS = 1>
+// DROP (round 4): Yd = dropout(Y) (nn.LSTM's inter-layer dropout, 04:186: the next layer's input) written next to Y from the
+// same staged rows: the stand-alone dropout kernel's mask (element index row * D * H + column), without its read pass.
+template <bool SAVE, int PARTS = 1, bool DROP = false>
 __global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h128_split_kernel(
     float* __restrict__ P, const float* __restrict__ Whh, float* __restrict__ Y, float* __restrict__ Csave, int T, int Bp,
-    const float* __restrict__ range) {
+    const float* __restrict__ range, float* __restrict__ Yd, float drop_p, uint64_t seed) {
     constexpr bool HALF = PARTS > 1;
     constexpr int NJ = 4 / PARTS;
     typedef float fvec __attribute__((ext_vector_type(NJ)));
@@ -188,8 +190,16 @@ __global__ __launch_bounds__(512, 2) void lstm_rec_fwd_h128_split_kernel(
             const int r8 = tid >> 5, c4 = (tid & 31) * 4;
             const int row = PARTS == 1 ? r8 : (PARTS == 2 ? 4 * (r8 >> 1) + jb + (r8 & 1) : 4 * r8 + jb);
             if (tid < 512 / PARTS) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(yfs + (cur ^ 1) * 16 * YF_LD + row * YF_LD + c4);
-                *reinterpret_cast<f32x4*>(Y + ((size_t)t * Bp + row0 + row) * DH + d * H + c4) = v;
+                f32x4 v = *reinterpret_cast<const f32x4*>(yfs + (cur ^ 1) * 16 * YF_LD + row * YF_LD + c4);
+                const size_t e0 = ((size_t)t * Bp + row0 + row) * DH + d * H + c4;
+                *reinterpret_cast<f32x4*>(Y + e0) = v;
+                if (DROP) {
+                    float s0, s1, s2, s3;
+                    lob_dropout_scale2(seed, e0, drop_p, s0, s1);
+                    lob_dropout_scale2(seed, e0 + 2, drop_p, s2, s3);
+                    v[0] *= s0; v[1] *= s1; v[2] *= s2; v[3] *= s3;
+                    *reinterpret_cast<f32x4*>(Yd + e0) = v;
+                }
             }
         }
     };
@@ -386,9 +396,10 @@ int lob_rec_bwd_split(const float* G, const float* Csave, const float* Whh, cons
 namespace {
 }  // namespace
 
-// Internal entry point used by lob_lstm_rec_fwd_f32 (lstm_rec_f32.hip): 16-row tiles, eight waves, grid Bp/16 x D.
+// Internal entry point used by lob_lstm_rec_fwd_f32 / lob_lstm_rec_fwd_f32_drop (lstm_rec_f32.hip): 16-row tiles, eight waves,
+// grid Bp/16 x D.  Yd != NULL: the dropped copy of Y as well (saving launches only).
 int lob_rec_fwd_split(float* P, const float* Whh, float* Y, float* Csave, int T, int Bp, int D, int save, const float* range,
-                      hipStream_t s) {
+                      float* Yd, float drop_p, uint64_t seed, hipStream_t s) {
     // part tiles while full tiles would occupy at most a quarter of the 256 CUs: four workgroups per 16-row tile, measured
     // -13 % (B = 512), -25 % (B = 256), -31 % (B = 32) per fp32 forward; at B = 1024 (128 tiles) two per tile change nothing and
     // four cost +24 % (two 8-wave workgroups per CU), so the switch-over sits at 64 tiles (tools/half_tile_ab.py)
@@ -397,16 +408,19 @@ int lob_rec_fwd_split(float* P, const float* Whh, float* Y, float* Csave, int T,
     // LOB_VAR_REC_HALF: 1 = four workgroups per tile up to 64 tiles; 2 / 4 force that split (up to 128 tiles: A/B)
     const int parts = (v == 2 || v == 4) ? (tiles <= 128 ? v : 1) : ((v == 0 || tiles > 64) ? 1 : 4);
     const dim3 grid((Bp / 16) * parts, D), block(512);
-    if (parts == 2) {
-        if (save) hipLaunchKernelGGL((lstm_rec_fwd_h128_split_kernel<true, 2>), grid, block, 0, s, P, Whh, Y, Csave, T, Bp, range);
-        else      hipLaunchKernelGGL((lstm_rec_fwd_h128_split_kernel<false, 2>), grid, block, 0, s, P, Whh, Y, Csave, T, Bp, range);
+    if (Yd && !save) return LOB_E_ARG;
+#define LOB_RFS(SV, PT, DR) hipLaunchKernelGGL((lstm_rec_fwd_h128_split_kernel<SV, PT, DR>), grid, block, 0, s, P, Whh, Y, Csave, T, Bp, \
+                                               range, Yd, drop_p, seed)
+    if (Yd) {
+        if (parts == 2) LOB_RFS(true, 2, true); else if (parts == 4) LOB_RFS(true, 4, true); else LOB_RFS(true, 1, true);
+    } else if (parts == 2) {
+        if (save) LOB_RFS(true, 2, false); else LOB_RFS(false, 2, false);
     } else if (parts == 4) {
-        if (save) hipLaunchKernelGGL((lstm_rec_fwd_h128_split_kernel<true, 4>), grid, block, 0, s, P, Whh, Y, Csave, T, Bp, range);
-        else      hipLaunchKernelGGL((lstm_rec_fwd_h128_split_kernel<false, 4>), grid, block, 0, s, P, Whh, Y, Csave, T, Bp, range);
+        if (save) LOB_RFS(true, 4, false); else LOB_RFS(false, 4, false);
     } else {
-        if (save) hipLaunchKernelGGL((lstm_rec_fwd_h128_split_kernel<true>), grid, block, 0, s, P, Whh, Y, Csave, T, Bp, range);
-        else      hipLaunchKernelGGL((lstm_rec_fwd_h128_split_kernel<false>), grid, block, 0, s, P, Whh, Y, Csave, T, Bp, range);
+        if (save) LOB_RFS(true, 1, false); else LOB_RFS(false, 1, false);
     }
+#undef LOB_RFS
     LOB_CHECK_LAUNCH();
     return 0;
 }

@@ -116,7 +116,7 @@ def gemm_nt(a, w, bias=None, act=ACT_NONE, out=None, accumulate=False, mixed=Fal
     amax = (device float >= max|a|, device float >= max|w|), fp32 operands, no bias / act / accumulate: the products run
     as two-way fp16 splits on the 16-bit matrix pipe (22-bit products: the fp32 path's backward GEMMs)."""
     if (amax is not None and not mixed and a.dtype == torch.float32 and w.dtype == torch.float32 and bias is None
-            and act == ACT_NONE and not accumulate and drop_p == 0 and not out_bf16
+            and act == ACT_NONE and not accumulate and not out_bf16 and (drop_p == 0 or _lib.get_variant("F32_SPLIT") != 2)
             and f32_split_gemm_ok(a.shape[0], w.shape[0], a.shape[1]) and a.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0
             and a.shape[1] % 4 == 0):
         _chk(a, "a"); _chk(w, "w"); _chk(amax[0], "amax_a"); _chk(amax[1], "amax_w")
@@ -126,7 +126,7 @@ def gemm_nt(a, w, bias=None, act=ACT_NONE, out=None, accumulate=False, mixed=Fal
             out = torch.empty((M, N), device=a.device, dtype=torch.float32)
         _chk(out, "out")
         rc = _lib.lib().lob_gemm_nt_f32_split(_ptr(a), K, _ptr(w), K, _ptr(out), N, M, N, K, _ptr(amax[0]), _ptr(amax[1]),
-                                              _stream())
+                                              float(drop_p), C.c_uint64(seed), _stream())
         _lib.check(rc, "lob_gemm_nt_f32_split")
         return out
     a_bf16 = a.dtype == torch.bfloat16
@@ -152,12 +152,14 @@ def gemm_nt(a, w, bias=None, act=ACT_NONE, out=None, accumulate=False, mixed=Fal
         return out
     if out_bf16:
         raise _lib.LobError("gemm_nt: out_bf16 with operands the bf16 LDS-DMA kernel does not take (alignment / K % 8)")
-    if drop_p > 0:
-        raise _lib.LobError("gemm_nt: the fused dropout epilogue exists on the bf16 kernel only")
     if a_bf16:
         raise _lib.LobError("gemm_nt: bf16 operand with a shape the bf16 kernel does not support")
+    if drop_p > 0 and (accumulate or not out.is_contiguous()):
+        raise _lib.LobError("gemm_nt: the dropout epilogue on the exact-fp32 kernel is a second pass over a fresh, contiguous result")
     rc = _lib.lib().lob_gemm_nt_f32(_ptr(a), K, _ptr(w), K, _ptr(bias), _ptr(out), N, M, N, K, act, _stream())
     _lib.check(rc, "lob_gemm_nt_f32")
+    if drop_p > 0:        # the exact-fp32 kernel has no mask epilogue: the same mask as a pass of its own (element row * N + col)
+        return dropout(out, drop_p, seed)
     return out
 
 
@@ -288,6 +290,16 @@ def can_fuse_dropout(H, mixed):
     return bool(mixed) and bf16_rec(H, PG_BF16)
 
 
+FUSE_F32_DROPOUT = True      # fp32 path, H = 128, split kernels: inter-layer dropout in the recurrent forward's store and the
+                             # dX GEMM's epilogue instead of four stand-alone passes per step (A/B and twin tests: False)
+
+
+def can_fuse_dropout_f32(H, Bp, save):
+    """The fp32 path's fp16-split saving forward (H == 128) can write dropout(Y) next to Y (lob_lstm_rec_fwd_f32_drop); its
+    backward is the mask epilogue of lob_gemm_nt_f32_split, or the stand-alone kernel where that GEMM does not run."""
+    return bool(FUSE_F32_DROPOUT) and bool(save) and H == 128 and Bp % 32 == 0 and _lib.get_variant("F32_SPLIT") != 0
+
+
 def lstm_rec_fwd(P, whh, T, Bp, H, D, save, mixed=False, drop_p=0.0, seed=0, want_f32=True, want_bf16=False, nvalid=0,
                  range=None):
     """Runs the persistent recurrent kernel; returns (Y fp32 or None, Csave or None, Y16 or None, Yd or None).
@@ -318,8 +330,14 @@ def lstm_rec_fwd(P, whh, T, Bp, H, D, save, mixed=False, drop_p=0.0, seed=0, wan
         rc = _lib.lib().lob_lstm_rec_fwd_bf16(_ptr(P), int(p16), _ptr(whh), _ptr(whh16), _ptr(Y), _ptr(Cs), int(c16),
                                               _ptr(Y16), _ptr(Yd), float(drop_p), C.c_uint64(seed), T, Bp, H, D,
                                               1 if save else 0, int(nvalid), _stream())
+    elif drop_p > 0:      # fp32 path, fp16-split kernel: Yd = dropout(Y) as fp32, the stand-alone kernel's mask
+        assert not p16 and not want_bf16 and can_fuse_dropout_f32(H, Bp, save)
+        Y = torch.empty((T * Bp, D * H), device=dev, dtype=torch.float32)
+        Yd = torch.empty((T * Bp, D * H), device=dev, dtype=torch.float32)
+        rc = _lib.lib().lob_lstm_rec_fwd_f32_drop(_ptr(P), _ptr(whh), _ptr(Y), _ptr(Yd), float(drop_p), C.c_uint64(seed),
+                                                  _ptr(Cs), T, Bp, H, D, _ptr(range), _stream())
     else:
-        assert drop_p == 0 and not p16 and not want_bf16
+        assert not p16 and not want_bf16
         Y = torch.empty((T * Bp, D * H), device=dev, dtype=torch.float32)
         rc = _lib.lib().lob_lstm_rec_fwd_f32(_ptr(P), _ptr(whh), _ptr(Y), _ptr(Cs), T, Bp, H, D, 1 if save else 0,
                                              _ptr(range), _stream())

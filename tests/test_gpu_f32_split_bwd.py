@@ -159,6 +159,47 @@ def test_fp32_training_step_runs_the_split_backward_and_matches_the_exact_one(de
         assert (gs[k] - ge[k]).abs().max().item() <= 2e-5 * mx + 1e-9, (k, (gs[k] - ge[k]).abs().max().item(), mx)
 
 
+@pytest.mark.parametrize("B,T", [(64, 48), (6, 5)])
+def test_fp32_inter_layer_dropout_fused_into_producer_and_dx_epilogue_is_the_same_mask(dev, B, T):
+    """fp32 path, H = 128, training mode: nn.LSTM's inter-layer dropout (04:186) as a second output of the saving recurrent
+    forward (lob_lstm_rec_fwd_f32_drop) and as the mask epilogue of lob_gemm_nt_f32_split, against the stand-alone
+    lob_dropout_f32 passes (ops.FUSE_F32_DROPOUT = False) under the same seed: logits and the input gradient bit-identical
+    (same mask, same multiplications), weight gradients equal up to the order of their split-k atomics."""
+    from lstm_ode_bci_amd import EnhancedLSTMModel, ops
+    from lstm_ode_bci_amd import synthetic as syn
+    sd = syn.make_state_dict(61, 128, 3, 2, True)
+    x, y = syn.make_windows(B, T, 61, seed=9)
+    m = EnhancedLSTMModel(61, 128, 3, 2, 0.4, True)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m = m.to(dev).train()
+
+    def run():
+        torch.manual_seed(77)
+        m._seed_counter = 0
+        m.zero_grad(set_to_none=True)
+        xg = torch.from_numpy(x).to(dev).requires_grad_(True)
+        out = m(xg)
+        torch.nn.functional.cross_entropy(out, torch.from_numpy(y).to(dev)).backward()
+        return out.detach().clone(), {**{k: p.grad.clone() for k, p in m.named_parameters()}, "x": xg.grad.clone()}
+
+    assert ops.FUSE_F32_DROPOUT
+    o1, g1 = run()
+    ops.FUSE_F32_DROPOUT = False
+    try:
+        o0, g0 = run()
+    finally:
+        ops.FUSE_F32_DROPOUT = True
+    assert torch.equal(o1, o0)
+    assert torch.equal(g1["x"], g0["x"])
+    for k in g0:
+        mx = g0[k].abs().max().item()
+        assert (g1[k] - g0[k]).abs().max().item() <= 2e-6 * mx + 1e-12, k
+    # and the mask is really there: evaluation mode gives other logits
+    m.eval()
+    with torch.no_grad():
+        assert not torch.equal(m(torch.from_numpy(x).to(dev)), o1)
+
+
 @pytest.mark.parametrize("T,Bp,D,save", [(20, 1024, 2, False), (7, 96, 2, True), (33, 32, 1, True), (256, 1024, 2, True)])
 def test_half_tile_recurrent_forward_is_bit_identical(dev, T, Bp, D, save):
     """LOB_VAR_REC_HALF (round 4): below B = 2048 two workgroups share each 16-row tile of the fp32
