@@ -14,6 +14,18 @@ from .autograd import _seed
 from .ops import ACT_GELU, ceil32
 
 
+_SIDE = {}
+
+
+def _side_stream(dev):
+    """One second stream per device for work nobody waits for inside the backward (ops.OVERLAP_DW)."""
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    st = _SIDE.get(key)
+    if st is None:
+        st = _SIDE[key] = torch.cuda.Stream(device=dev)
+    return st
+
+
 def _t(w):
     return w.t().contiguous()
 
@@ -186,6 +198,22 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad, sink=None):
         dY, g[i_ln], g[i_ln + 1] = ops.layernorm_act_bwd(ylast, ps[i_ln], ps[i_ln + 1], dV, pool=pool_ctx, dg=dg_t, db=db_t,
                                                          dx_bf16=dx16)
 
+    side_used = False
+    pending_dw = None
+
+    def _launch_pending():
+        ev, dP_, inp_, Y_, out_ = pending_dw
+        side = _side_stream(dP_.device)
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            ops.lstm_dw(dP_, inp_, Y_, T, Bp, H, D, out=out_)
+        for t_ in (dP_, inp_, Y_):
+            t_.record_stream(side)         # the allocator must not hand these out again before the side stream is done
+
+    def _join():          # the optimizer (and anything else on this stream) must see the side stream's weight gradients
+        if side_used:
+            torch.cuda.current_stream().wait_stream(_side_stream(dlogits.device))
+
     # ---- LSTM stack, last layer first (04:211)
     for layer in reversed(range(L)):
         lay = sv["layers"][layer]
@@ -214,11 +242,22 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad, sink=None):
             if split:
                 ax_in = (amax_dp, br[0]) if br[0] is not None else None       # dW_ih = dP^T x: x bounded by the LayerNorm / |h|
                 ax_h, ax_w = (amax_dp, br[2]), (amax_dp, br[1])
+        if pending_dw is not None:        # the layer above's weight gradients, next to the BPTT just launched
+            _launch_pending()
+            pending_dw = None
+            side_used = True
         inp, Y, wih = lay["inp"], lay["Y"], lay["wih"]
         fused_dw = need_w and ops.can_fuse_dw(dP, inp, Y, T, Bp, H, D)
+        deferred_dw = None
         if fused_dw:     # one contiguous target over both directions (the sink lays the two directions out side by side)
-            dwih, dwhh_all = ops.lstm_dw(dP, inp, Y, T, Bp, H, D, out=(tgt.span(base, 4, D, (D * 4 * H, inp.shape[1])),
-                                                                        tgt.span(base + 1, 4, D, (D, 4 * H, H))))
+            dw_out = (tgt.span(base, 4, D, (D * 4 * H, inp.shape[1])), tgt.span(base + 1, 4, D, (D, 4 * H, H)))
+            if sink is not None and layer > 0 and ops.OVERLAP_DW and ops.rec_underfilled(H, Bp, D):
+                # small batches: the BPTT of the layer below occupies at most half of the CUs and is one long serial chain;
+                # this layer's weight gradients (nobody waits for them before the optimizer) run next to it on a second
+                # stream, launched AFTER dX -- the chain's only input -- has been queued
+                deferred_dw = (dP, inp, Y, dw_out)
+            else:
+                dwih, dwhh_all = ops.lstm_dw(dP, inp, Y, T, Bp, H, D, out=dw_out)
         elif need_w:
             dwih = tgt.span(base, 4, D, wih.shape)
             ops.gemm_tn(dP, inp, dwih, mixed=mixed, amax=ax_in)
@@ -257,8 +296,19 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad, sink=None):
         dx16 = carry16 and want16 and (layer > 0 or width_ok(sv["pre"].shape[1]))
         dY = ops.gemm_nt(dP, wt, mixed=mixed, drop_p=p_lstm if below_fused else 0.0,
                          seed=_seed(seed, 10 + layer - 1), out_bf16=dx16, amax=ax_w)
+        if deferred_dw is not None:
+            # queued on the side stream only AFTER the BPTT of the layer below has been launched (top of the next iteration):
+            # launched first, the GEMM's 256 workgroups take every CU and the chain starts a GEMM late (measured: no gain)
+            ev = torch.cuda.Event()
+            ev.record()
+            pending_dw = (ev,) + deferred_dw
+            deferred_dw = None
         del dP
 
+    if pending_dw is not None:            # cannot happen (only layers > 0 defer); never lose a gradient to a logic slip
+        _launch_pending()
+        pending_dw = None
+        side_used = True
     # ---- input projection: Linear -> LayerNorm -> GELU -> Dropout (04:173-178)
     # input_proj.0.bias gradient = column sums of dpre: emitted by the LayerNorm backward itself where it can
     db_fused = need_w and ops.can_fuse_colsum(sv["pre"].shape[1])
@@ -277,6 +327,7 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad, sink=None):
                                            seed=_seed(seed, 0), dg=dg_t, db=db_t, dbias=db0)
         g[0] = tgt.deliver(0, dwp[:, :C]) if sink is not None else dwp[:, :C].contiguous()
         g[1] = db0
+        _join()
         return None, (tgt.result(g) if tgt is not None else g)
     dpre, g[2], g[3] = ops.layernorm_act_bwd(sv["pre"], ps[2], ps[3], dY, act=ACT_GELU, remap=(T, B, Bp),
                                              drop_p=p_in, seed=_seed(seed, 0), dx_colsum=db0, dg=dg_t, db=db_t,
@@ -292,4 +343,5 @@ def backward_impl(sv, ps, cfg, x_shape, dlogits, needs_input_grad, sink=None):
         gx2d, g[0], g[1] = _linear_bwd(dpre, sv["x2d"], ps[0], need_dx=bool(needs_input_grad[0]), need_w=need_w,
                                        db=db0, tgt=tgt, iw=0)
     gx = gx2d.reshape(B, T, C) if gx2d is not None else None
+    _join()
     return gx, (tgt.result(g) if tgt is not None else g)

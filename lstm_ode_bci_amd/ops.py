@@ -290,6 +290,18 @@ def can_fuse_dropout(H, mixed):
     return bool(mixed) and bf16_rec(H, PG_BF16)
 
 
+OVERLAP_DW = True            # small batches: the weight-gradient GEMM of layer l on a second stream, next to the BPTT of layer
+                             # l - 1 (whose workgroups cover at most half of the CUs there); False: everything on one stream
+
+
+def rec_underfilled(H, Bp, D):
+    """True where the H = 128 recurrent kernels of a training step leave at least half of the 256 CUs idle (16-row tiles, one
+    workgroup per CU up to 128 tiles: B <= 1024 with two directions).  H = 256 is NOT in: its part-tile BPTT at B <= 512 also
+    covers only half of the CUs, but what bounds it is the W_hh stream out of L2, and a GEMM next to it takes that bandwidth:
+    measured, the BPTT ran exactly as much longer as the GEMM it overlapped took (10.75 ms with and without)."""
+    return H == 128 and (Bp // 16) * D <= 128
+
+
 FUSE_F32_DROPOUT = True      # fp32 path, H = 128, split kernels: inter-layer dropout in the recurrent forward's store and the
                              # dX GEMM's epilogue instead of four stand-alone passes per step (A/B and twin tests: False)
 

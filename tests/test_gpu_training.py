@@ -492,3 +492,40 @@ def test_gradient_sink_equals_autograd_accumulation(dev, mixed, kw):
     o1.detach_model()
     g1 = run(m1, o1)
     assert grad_sink_of(m1) is None and all(torch.isfinite(v).all() for v in g1.values())
+
+
+def test_weight_gradients_on_the_side_stream_equal_the_single_stream_step(dev):
+    """ops.OVERLAP_DW (round 4): at small batches the fused dW GEMM of LSTM layer l runs on a second stream next to the BPTT of
+    layer l - 1.  The flat gradient buffer (sink; dropout on; two accumulated micro-batches, three times over) with and
+    without it: equal up to the order of the split-k atomics, i.e. the side stream's gradients are complete when the backward
+    returns and no buffer was recycled under the GEMM; then one clipped AdamW step stays finite."""
+    from lstm_ode_bci_amd import EnhancedLSTMModel, ops
+    from lstm_ode_bci_amd.training import FusedAdamW, WeightedCrossEntropy
+    torch.manual_seed(11)
+    m = EnhancedLSTMModel(61, 128, 3, 2, 0.4, True).to(dev).train()
+    xs = [torch.randn(96, 40, 61, device=dev) for _ in range(2)]
+    ys = [torch.randint(0, 2, (96,), device=dev) for _ in range(2)]
+    crit = WeightedCrossEntropy(torch.tensor([0.8, 1.2])).to(dev)
+    o = FusedAdamW(m.parameters(), lr=3e-3, weight_decay=1e-4, model=m)
+    assert ops.OVERLAP_DW and ops.rec_underfilled(128, 96, 2)
+
+    def grads(overlap):
+        ops.OVERLAP_DW = overlap
+        try:
+            torch.manual_seed(3)
+            o.zero_grad()
+            for x, y in zip(xs, ys):
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    loss = crit(m(x), y) / 2
+                loss.backward()
+            return o.flat_grad.clone()           # same stream as the backward's join: complete here
+        finally:
+            ops.OVERLAP_DW = True
+    for _ in range(3):
+        ga, gb = grads(True), grads(False)
+        mx = gb.abs().max().item()
+        assert mx > 0 and torch.isfinite(ga).all()
+        assert (ga - gb).abs().max().item() <= 1e-5 * mx, ((ga - gb).abs().max().item(), mx)
+    grads(True)
+    o.step(clip_grad_norm=1.0)
+    assert all(torch.isfinite(p).all() for p in m.parameters())
