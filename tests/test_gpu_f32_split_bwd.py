@@ -159,7 +159,7 @@ def test_fp32_training_step_runs_the_split_backward_and_matches_the_exact_one(de
         assert (gs[k] - ge[k]).abs().max().item() <= 2e-5 * mx + 1e-9, (k, (gs[k] - ge[k]).abs().max().item(), mx)
 
 
-@pytest.mark.parametrize("B,T", [(64, 48), (6, 5)])
+@pytest.mark.parametrize("B,T", [(64, 48), (6, 5), (1024, 256)])
 def test_fp32_inter_layer_dropout_fused_into_producer_and_dx_epilogue_is_the_same_mask(dev, B, T):
     """fp32 path, H = 128, training mode: nn.LSTM's inter-layer dropout (04:186) as a second output of the saving recurrent
     forward (lob_lstm_rec_fwd_f32_drop) and as the mask epilogue of lob_gemm_nt_f32_split, against the stand-alone
