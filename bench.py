@@ -20,6 +20,7 @@ configs[1] fp32 forward at B = 1024, configs[3] the coupled LSTM -> ODE path at 
 reference's real checkpoint size, 04_lstm_model.py:877) and the B = 8192 forward (configs[4]'s per-rank shard).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -477,6 +478,10 @@ class Leg:
         if self.world > 1:
             self.dist.barrier()
         torch.cuda.synchronize()
+        # a full Python garbage collection that has become due (imports and set-up leave ~10^6 tracked objects) must not
+        # land inside a timed region a few hundred milliseconds long: measured 30-40 ms, ONCE per process, in whichever leg ran
+        # first (round 4: a forward-only leg of 12 steps read 5.9 instead of 2.9 ms per step).  Collect now; the collector stays on
+        gc.collect()
         t0 = time.perf_counter()
         for _ in range(steps):
             self.step()

@@ -370,6 +370,15 @@ int lob_attn_scores_bf16(const void* Y16, const float* gamma, const float* beta,
                          const float* w2, const float* b2, void* V, float* U, float* S, int T, int B, int Bp, int H, int D,
                          float eps, void* stream);
 
+/* The same fusion for the FP32 path, H == 128, bidirectional (207): Y, V fp32 [T*Bp][256], W1 fp32 [128][256], U fp32 [T*Bp][128]
+ * or NULL.  v is bit-identical to lob_layernorm_act_f32; the score layer's products run as two-way fp16 splits on the 16-bit
+ * matrix pipe (22-bit products, fp32 accumulate, pre-scales derived on the device from gamma / beta / W1: as
+ * lob_gate_gemm_x_f32's default arithmetic), so u and S equal lob_gemm_nt_f32(tanh) + the score sums of lob_attn_pool_fwd_f32 to
+ * ~1e-6.  The scores go to lob_attn_pool_fwd_f32 as U with W2 == 0 (v_bf16 = 0).                                          */
+int lob_attn_scores_f32(const float* Y, const float* gamma, const float* beta, const float* W1, const float* b1,
+                        const float* w2, const float* b2, float* V, float* U, float* S, int T, int B, int Bp, int H, int D,
+                        float eps, void* stream);
+
 /* Additive attention pooling over time (Attention.forward, 04_lstm_model.py:123-128):
  *   s[t,b] = U[t*Bp+b,:] . w2 + b2   (U = tanh(W1 v + b1), computed by lob_gemm_nt_f32)
  *   a[b,:] = softmax_t(s[:,b]);   ctx[b,:] = sum_t a[b,t] * V[t*Bp+b,:]

@@ -156,6 +156,12 @@ def _forward_impl(x, ps, cfg, save):
             w1 = a0w.to(bf16)
         v, u, S = ops.attn_scores(inp, ln_g, ln_b, w1, a0b, a2w.reshape(-1), a2b, T, B, Bp, H, D, save=save)
         ctx, attn = ops.attn_pool_fwd_scores(v, S, T, B, Bp)
+    elif (a0w is not None and not mixed and ln_g is not None and a0b is not None
+          and ops.attn_scores_f32_ok(inp, H, D, Bp, a0w)):
+        # fp32 path: the same fusion on the fp16-split arithmetic (v bit-identical to the LayerNorm kernel's)
+        w1 = a0w
+        v, u, S = ops.attn_scores_f32(inp, ln_g, ln_b, a0w, a0b, a2w.reshape(-1), a2b, T, B, Bp, H, D, save=save)
+        ctx, attn = ops.attn_pool_fwd_scores(v, S, T, B, Bp)
     else:
         v = ops.layernorm_act(inp, ln_g, ln_b, out_bf16=mixed)                   # (T*Bp, W)
         if a0w is None:            # no-attention ablation: mean pooling over time (09:236)

@@ -63,14 +63,18 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_kernel(
     __shared__ float red[8];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float bias2 = b2 ? b2[0] : 0.f;
-    for (int t = wave; t < T; t += 4) {
-        float s = 0.f;
-        if (U) {         // U == NULL: all scores equal -> weights 1/T (mean pooling over time, 09:236)
-            const float* u = U + ((size_t)t * Bp + b) * W2;
-            for (int j = lane; j < W2; j += 64) s = fmaf(u[j], w2[j], s);
-            s = wave_sum(s);
+    if (U && W2 == 0) {      // U = finished scores S[B][T], bias included (lob_attn_scores_f32)
+        for (int t = tid; t < T; t += 256) sc[t] = U[(size_t)b * T + t];
+    } else {
+        for (int t = wave; t < T; t += 4) {
+            float s = 0.f;
+            if (U) {         // U == NULL: all scores equal -> weights 1/T (mean pooling over time, 09:236)
+                const float* u = U + ((size_t)t * Bp + b) * W2;
+                for (int j = lane; j < W2; j += 64) s = fmaf(u[j], w2[j], s);
+                s = wave_sum(s);
+            }
+            if (lane == 0) sc[t] = s + bias2;
         }
-        if (lane == 0) sc[t] = s + bias2;
     }
     __syncthreads();
     float m = -INFINITY;
@@ -1328,6 +1332,150 @@ __global__ __launch_bounds__(256, 2) void input_proj_bwd_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The forward tail of the FP32 path at H = 128 (round 4): post-LSTM LayerNorm (04:192) + score layer u = tanh(W1 v + b1),
+// s = w2 . u + b2 (04:123-125) in one pass over the last layer's fp32 output.  Unfused (layernorm_act_vec_kernel<4, false, 64>,
+// the exact-fp32 NT GEMM with its tanh epilogue, attn_pool_fwd_kernel<float> reading u and v): 5 KB per row; here 2 KB
+// (inference: Y in, v out) or 2.5 KB (training: + u for the backward), and the pooling reads v once more.
+// The LayerNorm is the unfused kernel's, lane for lane (64 lanes x 4 columns, one row per pass): v is bit-identical.  The
+// score layer runs on the 16-bit matrix pipe like the fp32 path's gate GEMMs: both operands as two-way fp16 splits
+// (hi = fp16(x 2^k), lo = fp16((x 2^k - hi) 2^11); hi hi and the two cross terms in separate fp32 accumulators: 22-bit
+// products), W1's halves in registers for the whole launch (128 VGPRs), v's halves written to LDS as the rows are
+// normalised.  Pre-scales on the device: |v| <= 16 max|gamma| + max|beta| (|x_hat| < sqrt(256)), max|W1| by a reduction in
+// every workgroup's prologue (128 KB out of L2).  A workgroup (4 waves) owns 64 consecutive time-major rows; wave w
+// normalises rows 16 w .. + 15 and owns score columns 32 w .. + 31.
+// ------------------------------------------------------------------------------------------
+typedef _Float16 af_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 af_f16x4 __attribute__((ext_vector_type(4)));
+constexpr int AF_LDA = 264;            // fp16 row stride of the v images (528 B)
+constexpr int AF_LDU = 132;            // fp32 row stride of the u tile (528 B)
+constexpr float AF_LO = 2048.f;        // residual scale 2^11
+
+template <bool SAVE>
+__global__ __launch_bounds__(256, 2) void attn_score_f32_kernel(
+    const float* __restrict__ Y, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
+    float* __restrict__ V, float* __restrict__ U, float* __restrict__ S, int T, int B, int Bp, float eps) {
+    constexpr int W = 256, W2 = 128;
+    __shared__ __attribute__((aligned(16))) _Float16 img[2 * 64 * AF_LDA];    // v hi | v lo; the fp32 u tile aliases it
+    __shared__ float red[12];
+    float* ut = reinterpret_cast<float*>(img);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    // ---- operand ranges -> power-of-two pre-scales (every workgroup derives the same values)
+    {
+        float gmx = fabsf(gamma[tid]), bmx = fabsf(beta[tid]), wmx = 0.f;
+        for (int i = tid; i < W2 * W; i += 256) wmx = fmaxf(wmx, fabsf(W1[i]));
+        gmx = wave_max(gmx); bmx = wave_max(bmx); wmx = wave_max(wmx);
+        if (lane == 0) { red[w] = gmx; red[4 + w] = bmx; red[8 + w] = wmx; }
+        __syncthreads();
+    }
+    const float amax_v = 16.f * fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) + fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+    const float sv = lob_split_scale(amax_v), sw = lob_split_scale(fmaxf(fmaxf(red[8], red[9]), fmaxf(red[10], red[11])));
+    const float r_hh = 1.f / (sv * sw), r_sm = r_hh * (1.f / AF_LO);
+    // B fragments of this wave's 32 score columns, split: W1[32 w + l31][16 ks + 8 hi + j]
+    af_f16x8 whi[16], wlo[16];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        const float* src = W1 + (size_t)(32 * w + l31) * W + 16 * ks + 8 * hi;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float x = (j < 4 ? a[j & 3] : b[j & 3]) * sw;
+            const _Float16 h = (_Float16)x;
+            whi[ks][j] = h;
+            wlo[ks][j] = (_Float16)((x - (float)h) * AF_LO);
+        }
+    }
+    const float b1v = b1 ? b1[32 * w + l31] : 0.f;
+    float gm[4], bt[4];
+    ldv<4>(gamma + lane * 4, gm);
+    ldv<4>(beta + lane * 4, bt);
+    const float w2a = w2[lane], w2b = w2[lane + 64];
+    const float bias2 = b2 ? b2[0] : 0.f;
+    const long rows = (long)T * Bp;
+    const long ntile = (rows + 63) >> 6;
+    const float invw = 1.0f / (float)W;
+    for (long tl = blockIdx.x; tl < ntile; tl += gridDim.x) {
+        const long r0 = tl * 64 + 16 * w;
+        // ---- 1. LayerNorm of this wave's 16 rows (layernorm_act_vec_kernel<4, false, 64, float>), all loads up front
+        f32x4 raw[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const long r = r0 + p < rows ? r0 + p : rows - 1;
+            raw[p] = *reinterpret_cast<const f32x4*>(Y + (size_t)r * W + lane * 4);
+        }
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const long r = r0 + p;
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = r < rows ? raw[p][i] : 0.f;
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s += v[i];
+            const float mean = row_sum<64>(s) * invw;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const float dl = v[i] - mean; q = __builtin_fmaf(dl, dl, q); }
+            const float rstd = rsqrtf(__builtin_fmaf(row_sum<64>(q), invw, eps));
+            af_f16x4 h4, l4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i] = __builtin_fmaf((v[i] - mean) * rstd, gm[i], bt[i]);
+                const float x = v[i] * sv;
+                const _Float16 h = (_Float16)x;
+                h4[i] = h;
+                l4[i] = (_Float16)((x - (float)h) * AF_LO);
+            }
+            if (r < rows) stv<4>(V + (size_t)r * W + lane * 4, v);
+            *reinterpret_cast<af_f16x4*>(img + (16 * w + p) * AF_LDA + lane * 4) = h4;
+            *reinterpret_cast<af_f16x4*>(img + 64 * AF_LDA + (16 * w + p) * AF_LDA + lane * 4) = l4;
+        }
+        __syncthreads();
+        // ---- 2. this wave's 32 score columns for the 64 rows: three MFMAs per fragment pair, small terms apart
+        float uv[2][16];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            f32x16 ahh, asm_;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { ahh[i] = 0.f; asm_[i] = 0.f; }
+            const _Float16* ap = img + (32 * rb + l31) * AF_LDA + 8 * hi;
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const af_f16x8 ah = *reinterpret_cast<const af_f16x8*>(ap + 16 * ks);
+                const af_f16x8 al = *reinterpret_cast<const af_f16x8*>(ap + 64 * AF_LDA + 16 * ks);
+                ahh = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, whi[ks], ahh, 0, 0, 0);
+                asm_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wlo[ks], asm_, 0, 0, 0);
+                asm_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, whi[ks], asm_, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) uv[rb][i] = apply_act((ahh[i] * r_hh + asm_[i] * r_sm) + b1v, LOB_ACT_TANH);
+        }
+        __syncthreads();                       // every wave is done with the v images: the block now takes u (fp32)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                ut[(32 * rb + (i & 3) + 8 * (i >> 2) + 4 * hi) * AF_LDU + 32 * w + l31] = uv[rb][i];
+        __syncthreads();
+        // ---- 3. scores of this wave's 16 rows (attn_pool_fwd_kernel<float>'s order: columns lane, lane + 64; wave reduction)
+        RowTB tb(r0, Bp);
+        for (int rr = 0; rr < 16; ++rr, tb.step(1, Bp)) {
+            const long r = r0 + rr;
+            if (r >= rows) break;
+            const float u0 = ut[(16 * w + rr) * AF_LDU + lane], u1 = ut[(16 * w + rr) * AF_LDU + lane + 64];
+            if (SAVE) { U[(size_t)r * W2 + lane] = u0; U[(size_t)r * W2 + lane + 64] = u1; }
+            float sc = fmaf(u0, w2a, 0.f);
+            sc = fmaf(u1, w2b, sc);
+            sc = wave_sum(sc);
+            if (lane == 0 && tb.b < B) S[(size_t)tb.b * T + tb.t] = sc + bias2;
+        }
+        __syncthreads();                       // the block is free for the next tile's v images
+    }
+}
+
 // The same fusion at H = 256 (post-LSTM width 512, score layer 512 -> 256): a workgroup of EIGHT waves owns 64 rows;
 // wave w normalises rows 8 w .. + 7 with the width-512 LayerNorm kernel's lane assignment (64 lanes x 8 columns, one row
 // per pass), owns the score layer's columns 32 w .. + 31 (32 B fragments of W1 = 128 registers, 2 row blocks x 32 k-steps)
@@ -1825,6 +1973,23 @@ extern "C" int lob_attn_ln_bwd_bf16(const void* X16, const float* gamma, const f
     return 0;
 }
 
+extern "C" int lob_attn_scores_f32(const float* Y, const float* gamma, const float* beta, const float* W1, const float* b1,
+                                   const float* w2, const float* b2, float* V, float* U, float* S, int T, int B, int Bp,
+                                   int H, int D, float eps, void* stream) {
+    if (!Y || !gamma || !beta || !W1 || !w2 || !V || !S || T <= 0 || B <= 0 || Bp < B) return LOB_E_ARG;
+    if (H != 128 || D != 2 || (Bp % 32) || (long)T * Bp >= (1L << 31)) return LOB_E_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta) |
+         reinterpret_cast<uintptr_t>(W1) | reinterpret_cast<uintptr_t>(V)) & 15) return LOB_E_ALIGN;
+    const long ntile = ((long)T * Bp + 63) / 64;
+    const int nb = (int)(ntile < 512 ? ntile : 512);          // two 4-wave workgroups per CU
+    if (U) hipLaunchKernelGGL((attn_score_f32_kernel<true>), dim3(nb), dim3(256), 0, (hipStream_t)stream, Y, gamma, beta, W1, b1,
+                              w2, b2, V, U, S, T, B, Bp, eps);
+    else   hipLaunchKernelGGL((attn_score_f32_kernel<false>), dim3(nb), dim3(256), 0, (hipStream_t)stream, Y, gamma, beta, W1, b1,
+                              w2, b2, V, U, S, T, B, Bp, eps);
+    LOB_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int lob_attn_scores_bf16(const void* Y16, const float* gamma, const float* beta, const void* W1_16,
                                     const float* b1, const float* w2, const float* b2, void* V, float* U, float* S,
                                     int T, int B, int Bp, int H, int D, float eps, void* stream) {
@@ -1987,6 +2152,12 @@ extern "C" int lob_attn_pool_fwd_f32(const void* V, int v_bf16, const float* U, 
                                      void* stream) {
     if (!V || !ctx || !attn || T <= 0 || B <= 0 || Bp < B || W <= 0) return LOB_E_ARG;
     if ((size_t)T * sizeof(float) > 60 * 1024) return LOB_E_SHAPE;
+    if (U && W2 == 0 && !v_bf16) {      // fp32 v with finished scores S[B][T] (lob_attn_scores_f32): the generic kernel
+        hipLaunchKernelGGL((attn_pool_fwd_kernel<float>), dim3(B), dim3(256), (size_t)T * sizeof(float), (hipStream_t)stream,
+                           reinterpret_cast<const float*>(V), U, w2, b2, ctx, attn, T, Bp, W, 0);
+        LOB_CHECK_LAUNCH();
+        return 0;
+    }
     if (U && W2 == 0) {          // U = finished scores S[B][T] (lob_attn_scores_bf16)
         if (!v_bf16 || (W != 256 && W != 512) || (reinterpret_cast<uintptr_t>(V) & 15)) return LOB_E_SHAPE;
         const size_t smem = ((size_t)((T + 3) & ~3) + 4 * W) * sizeof(float);

@@ -470,13 +470,39 @@ def attn_scores(y16, gamma, beta, w1_16, b1, w2, b2, T, B, Bp, H, D, eps=1e-5, s
     return v, u, S
 
 
+#: fp32 path, H == 128 bidirectional: LayerNorm + score layer in ONE kernel (v bit-identical; u / scores on the fp16-split
+#: arithmetic of the fp32 path's gate GEMMs instead of the exact-fp32 MFMA GEMM); tests switch it off to compare
+FUSE_ATTN_SCORES_F32 = True
+
+
+def attn_scores_f32_ok(y, H, D, Bp, w1):
+    return (bool(FUSE_ATTN_SCORES_F32) and H == 128 and D == 2 and Bp % 32 == 0 and y.dtype == torch.float32
+            and y.is_contiguous() and w1 is not None and w1.dtype == torch.float32 and tuple(w1.shape) == (H, 2 * H)
+            and w1.is_contiguous() and _lib.get_variant("F32_SPLIT") != 0)
+
+
+def attn_scores_f32(y, gamma, beta, w1, b1, w2, b2, T, B, Bp, H, D, eps=1e-5, save=False):
+    """fp32 twin of attn_scores: v = LN(y) (fp32 [T*Bp, 256]), u = tanh(W1 v + b1) (fp32 [T*Bp, 128], only with save),
+    scores S [B, T]."""
+    _chk(y, "y"); _chk(gamma, "gamma"); _chk(beta, "beta"); _chk(w1, "w1"); _chk(b1, "b1"); _chk(w2, "w2"); _chk(b2, "b2")
+    dev = y.device
+    v = torch.empty((T * Bp, 2 * H), device=dev, dtype=torch.float32)
+    u = torch.empty((T * Bp, H), device=dev, dtype=torch.float32) if save else None
+    S = torch.empty((B, T), device=dev, dtype=torch.float32)
+    rc = _lib.lib().lob_attn_scores_f32(_ptr(y), _ptr(gamma), _ptr(beta), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(v),
+                                        _ptr(u), _ptr(S), T, B, Bp, H, D, eps, _stream())
+    _lib.check(rc, "lob_attn_scores_f32")
+    return v, u, S
+
+
 def attn_pool_fwd_scores(v, S, T, B, Bp):
     """Softmax over time of finished scores S [B, T] and the context sums (the second half of attn_pool_fwd)."""
-    _chk(v, "v", torch.bfloat16); _chk(S, "S")
+    v16 = v.dtype == torch.bfloat16
+    _chk(v, "v", torch.bfloat16 if v16 else torch.float32); _chk(S, "S")
     W = v.shape[1]
     ctx = torch.empty((B, W), device=v.device, dtype=torch.float32)
     attn = torch.empty((B, T), device=v.device, dtype=torch.float32)
-    rc = _lib.lib().lob_attn_pool_fwd_f32(_ptr(v), 1, _ptr(S), None, None, _ptr(ctx), _ptr(attn), T, B, Bp, W, 0, _stream())
+    rc = _lib.lib().lob_attn_pool_fwd_f32(_ptr(v), int(v16), _ptr(S), None, None, _ptr(ctx), _ptr(attn), T, B, Bp, W, 0, _stream())
     _lib.check(rc, "lob_attn_pool_fwd_f32")
     return ctx, attn
 

@@ -158,3 +158,75 @@ def test_model_gradients_do_not_change_with_the_fused_backward_tail(dev, H):
     for n in grads[True]:
         a, b = grads[True][n], grads[False][n]
         assert (a - b).abs().max().item() <= 2e-5 * max(1e-6, b.abs().max().item()), n
+
+
+@pytest.mark.parametrize("T,B", [(1, 1), (5, 3), (7, 40), (256, 8), (33, 70), (64, 128)])
+@pytest.mark.parametrize("save", [False, True])
+@pytest.mark.parametrize("scale", [1.0, 300.0])
+def test_fp32_fused_tail_vs_the_three_fp32_kernels_and_float64(dev, T, B, save, scale):
+    """lob_attn_scores_f32 (round 4): the fp32 path's LayerNorm + score layer in one launch.  v must be BIT-IDENTICAL to the
+    LayerNorm kernel's; u, the attention weights and the context come from two-way fp16-split products instead of the exact-fp32
+    MFMA GEMM: against that GEMM and against float64 within the fp32 path's 1e-5 budget by a wide margin.  scale = 300: a
+    LayerNorm gain and weights far outside fp16's range -- the pre-scales derived on the device must keep both halves finite."""
+    from lstm_ode_bci_amd import ops
+    H, D = 128, 2
+    W = 2 * H
+    Bp = ops.ceil32(B)
+    g = torch.Generator(device=dev).manual_seed(T * 100 + B)
+    y = torch.randn((T * Bp, W), generator=g, device=dev) * 0.7
+    gam = (torch.rand((W,), generator=g, device=dev) + 0.5) * scale
+    bet = torch.randn((W,), generator=g, device=dev) * 0.1 * scale
+    w1 = torch.randn((H, W), generator=g, device=dev) * 0.08 / scale
+    w1[3, 5] *= 40.0                                     # an outlier sets the weight range
+    b1 = torch.randn((H,), generator=g, device=dev) * 0.1
+    w2 = torch.randn((H,), generator=g, device=dev) * 0.3
+    b2 = torch.randn((1,), generator=g, device=dev)
+    assert ops.attn_scores_f32_ok(y, H, D, Bp, w1)
+    v, u, S = ops.attn_scores_f32(y, gam, bet, w1, b1, w2, b2, T, B, Bp, H, D, save=save)
+    ctx, attn = ops.attn_pool_fwd_scores(v, S, T, B, Bp)
+    vr = ops.layernorm_act(y, gam, bet)
+    ur = ops.gemm_nt(vr, w1, b1, act=ops.ACT_TANH)
+    ctxr, attnr = ops.attn_pool_fwd(vr, ur, w2, b2, T, B, Bp)
+    assert torch.equal(v, vr)
+    assert (u is not None) == save
+    if save:
+        assert torch.isfinite(u).all() and (u - ur).abs().max().item() < 3e-6
+    assert torch.isfinite(attn).all() and torch.isfinite(ctx).all()
+    assert (attn - attnr).abs().max().item() < 2e-6
+    assert (ctx - ctxr).abs().max().item() < 2e-6 * max(1.0, ctxr.abs().max().item())
+    u64 = torch.tanh(vr.double() @ w1.double().t() + b1.double())
+    s64 = (u64 @ w2.double() + b2.double()).reshape(T, Bp)[:, :B].t()
+    a64 = torch.softmax(s64, dim=1)
+    assert (attn.double() - a64).abs().max().item() < 2e-6
+    if save:
+        assert (u.double() - u64).abs().max().item() < 2e-6
+
+
+def test_fp32_model_outputs_with_and_without_the_fused_fp32_tail(dev):
+    """Whole model, fp32 path: logits and every gradient with ops.FUSE_ATTN_SCORES_F32 on / off agree far inside the 1e-5 parity
+    budget (the goldens g1 / g2 run through the fused kernel at the unchanged tolerances)."""
+    from lstm_ode_bci_amd import EnhancedLSTMModel, ops
+    sd = {k: torch.from_numpy(v) for k, v in syn.make_state_dict(61, 128, 3, 2, True).items()}
+    x, y = syn.make_windows(40, 64, 61, seed=2)
+    m = EnhancedLSTMModel(61, 128, 3, 2, 0.4, True)
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+
+    def run():
+        m.zero_grad(set_to_none=True)
+        xg = torch.from_numpy(x).to(dev).requires_grad_(True)
+        out = m(xg)
+        torch.nn.functional.cross_entropy(out, torch.from_numpy(y).to(dev)).backward()
+        return out.detach().clone(), {**{k: p.grad.clone() for k, p in m.named_parameters()}, "x": xg.grad.clone()}
+    assert ops.FUSE_ATTN_SCORES_F32
+    o1, g1 = run()
+    ops.FUSE_ATTN_SCORES_F32 = False
+    try:
+        o0, g0 = run()
+    finally:
+        ops.FUSE_ATTN_SCORES_F32 = True
+    assert not torch.equal(o1, o0) or True               # the score layer's arithmetic differs in the last bits
+    assert (o1 - o0).abs().max().item() < 2e-6
+    for k in g0:
+        mx = g0[k].abs().max().item()
+        assert (g1[k] - g0[k]).abs().max().item() <= 2e-5 * mx + 1e-9, k

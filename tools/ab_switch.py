@@ -18,6 +18,7 @@ ap.add_argument("--hidden", type=int, default=128)
 ap.add_argument("--mode", default="train")
 ap.add_argument("--precision", default="mixed")
 ap.add_argument("--batch", type=int, default=4096)
+ap.add_argument("--off-first", action="store_true", help="start with the switch OFF (is a slow first repetition the switch's or the process's?)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
@@ -26,7 +27,7 @@ old = getattr(ops, a.switch)
 res = {True: [], False: []}
 try:
     for rep in range(3):
-        for v in (True, False):
+        for v in ((False, True) if a.off_first else (True, False)):
             setattr(ops, a.switch, v)
             dt = leg.run(12, 4)
             res[v].append(dt / 12 * 1e3)
