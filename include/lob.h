@@ -333,6 +333,13 @@ int lob_layernorm_act_f32(const float* in, const float* gamma, const float* beta
 int lob_input_proj_ln_bf16(const float* x, int C, const float* W, int ldw, const float* bias,
                            const float* gamma, const float* beta, float* pre, void* xb, int Cp, void* out,
                            int B, int T, int Bp, int H, float eps, int act, float drop_p, uint64_t seed, void* stream);
+/* The same head for the FP32 path, H == 128 (207): exact fp32 products (the contraction is C <= 64 long), fp32 activations
+ * out [T*Bp][128] (time-major; rows of padding windows are left untouched: zero them once), pre (fp32 [B*T][128], rows (b,t)) for
+ * the backward or NULL.  Same results as lob_gemm_nt_f32 + lob_layernorm_act_f32(remap) (to fp32 summation order of the 61-term
+ * dot products at most).                                                                                              */
+int lob_input_proj_ln_f32(const float* x, int C, const float* W, int ldw, const float* bias, const float* gamma,
+                         const float* beta, float* pre, float* out, int B, int T, int Bp, int H, float eps, int act,
+                         float drop_p, uint64_t seed, void* stream);
 
 /* nn.Dropout (04_lstm_model.py:177,186,199,202): out[i] = in[i] * keep_i / (1-p), where
  * keep_i is a counter-based hash of (seed, i): the backward pass applies the same call to the

@@ -41,6 +41,8 @@ _SIGS = {
                               C.c_int, C.c_int, C.c_float, C.c_void_p], C.c_int),
     "lob_attn_scores_f32": ([_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int,
                              C.c_int, C.c_int, C.c_float, C.c_void_p], C.c_int),
+    "lob_input_proj_ln_f32": ([_f32p, C.c_int, _f32p, C.c_int, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int,
+                               C.c_int, C.c_float, C.c_int, C.c_float, C.c_uint64, C.c_void_p], C.c_int),
     "lob_input_proj_ln_bf16": ([_f32p, C.c_int, _f32p, C.c_int, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, _f32p, C.c_int, C.c_int,
                                 C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, C.c_uint64, C.c_void_p], C.c_int),
     "lob_lstm_rec_bwd_f32": ([_f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, _f32p, C.c_int, C.c_int, C.c_int, C.c_int,

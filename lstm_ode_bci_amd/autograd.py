@@ -73,6 +73,10 @@ def _forward_impl(x, ps, cfg, save):
         # one launch from the fp32 windows to the first layer's bf16 activations (same bits as the sequence below)
         a, pre, xb = ops.input_proj_ln(x2d, proj_w, proj_b, ln0_g, ln0_b, B, T, Bp, H, act=ACT_GELU, drop_p=p_in,
                                        seed=_seed(seed, 0), save=save)
+    elif not mixed and frag and ops.input_proj_f32_ok(x2d, H, C, proj_w):
+        # fp32 path: the same fusion with exact fp32 products (the pre-activations go to HBM only for a backward)
+        a, pre = ops.input_proj_ln_f32(x2d, proj_w, proj_b, ln0_g, ln0_b, B, T, Bp, H, act=ACT_GELU, drop_p=p_in,
+                                       seed=_seed(seed, 0), save=save)
     else:
         if mixed and C % 8 != 0 and H % 8 == 0:
             Cp = (C + 7) // 8 * 8

@@ -1907,6 +1907,137 @@ __global__ __launch_bounds__(WIDTH * 2) void input_proj_ln2_kernel(
     }
 }
 
+// The same head for the FP32 path at width 128 (round 4), column-decomposed like the kernel above (the wave-per-tile shape
+// needs 128 registers of fp32 B fragments next to 64 accumulators: it spilled): exact fp32 products (v_mfma_f32_32x32x2_f32,
+// k ascending: the contraction is 61 long, the matrix work is nothing), fp32 activations out.  Unfused, lob_gemm_nt_f32 wrote
+// the pre-activations and the LayerNorm kernel read them back: 1.8 KB per row against 0.76 (inference) / 1.27 (training,
+// which keeps the pre-activations for the backward).
+template <bool SAVE>
+__global__ __launch_bounds__(256) void input_proj_ln_f32_kernel(
+    const float* __restrict__ x, int C, const float* __restrict__ W, int ldw, const float* __restrict__ bias,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ pre,
+    float* __restrict__ out, long rows, int T, int Bp, float eps, int act, float drop_p, uint64_t seed) {
+    constexpr int WIDTH = 128;
+    constexpr int NW = WIDTH / 32, NT = NW * 64;           // waves / threads per workgroup
+    constexpr int LDT = WIDTH + 4;                         // fp32 row stride of the output tile
+    constexpr int LPR = WIDTH == 128 ? 16 : 64, VPL = WIDTH / LPR, GPW = 64 / LPR;    // the unfused LayerNorm kernel's lanes
+    constexpr int RPWAVE = 64 / NW;                        // LayerNorm rows per wave and tile
+    __shared__ __attribute__((aligned(16))) float tile[64 * LDT];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int sub = lane / LPR, sl = lane % LPR;
+    // B fragments of this wave's 32 columns: W[32 w + l31][2 ks + hi], zero beyond C
+    float wf[32];
+    {
+        const float* wrow = W + (size_t)(32 * w + l31) * ldw;
+#pragma unroll
+        for (int ks = 0; ks < 32; ++ks) wf[ks] = 2 * ks + hi < C ? wrow[2 * ks + hi] : 0.f;
+    }
+    const float bv = bias ? bias[32 * w + l31] : 0.f;
+    float gm[VPL], bt[VPL];
+    const bool norm = !(act & LOB_LN_IDENTITY);
+    act &= 0xff;
+    if (norm) { ldv<VPL>(gamma + sl * VPL, gm); ldv<VPL>(beta + sl * VPL, bt); }
+    else {
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) { gm[i] = 1.f; bt[i] = 0.f; }
+    }
+    const float invw = 1.0f / (float)WIDTH;
+    const long ntile = (rows + 63) >> 6;
+    const long total = rows * (long)C;
+    const int nch = 16 * C;                                // 16-byte chunks of a full tile (64 rows x C floats)
+    constexpr int CPT = (16 * 64 + NT - 1) / NT;           // chunks per thread (C <= 64)
+    f32x4 pf[CPT];
+    auto fetch = [&](long tl) {
+        const long f0 = tl * 64 * C;
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int ch = tid + NT * i;
+            const long f = f0 + 4L * ch;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ch < nch) {
+                if (f + 4 <= total) v = *reinterpret_cast<const f32x4*>(x + f);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (f + e < total) v[e] = x[f + e];
+                }
+            }
+            pf[i] = v;
+        }
+    };
+    long tl = blockIdx.x;
+    if (tl < ntile) fetch(tl);
+    for (; tl < ntile; tl += gridDim.x) {
+        const long r0 = tl * 64;
+        // ---- 0. the tile's floats, flat, into the block
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int ch = tid + NT * i;
+            if (ch < nch) *reinterpret_cast<f32x4*>(tile + 4 * ch) = pf[i];
+        }
+        if (tl + gridDim.x < ntile) fetch(tl + gridDim.x);
+        __syncthreads();
+        // ---- 1. this wave's 32 columns of the 64 rows
+        f32x16 acc[2];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 32; ++ks) {
+            const int k = 2 * ks + hi;
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                const float af = k < C ? tile[(32 * rb + l31) * C + k] : 0.f;
+                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, wf[ks], acc[rb], 0, 0, 0);
+            }
+        }
+        __syncthreads();                       // every wave has read the windows: the block now takes the pre-activations
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                tile[(32 * rb + (r & 3) + 8 * (r >> 2) + 4 * hi) * LDT + 32 * w + l31] = acc[rb][r] + bv;
+        __syncthreads();
+        // ---- 2. LayerNorm + activation + dropout of this wave's rows, GPW rows per pass (the unfused kernel's lanes)
+        int bwi = (int)((unsigned)(r0 + RPWAVE * w + sub) / (unsigned)T);
+        int tti = (int)((unsigned)(r0 + RPWAVE * w + sub) - (unsigned)bwi * (unsigned)T);
+#pragma unroll 2
+        for (int ps = 0; ps < RPWAVE / GPW; ++ps) {
+            const int rt = RPWAVE * w + GPW * ps + sub;
+            const long r = r0 + rt;
+            const int orow = tti * Bp + bwi;             // (window, time) by increments: see input_proj_ln_kernel
+            tti += GPW;
+            while (tti >= T) { tti -= T; ++bwi; }
+            if (r >= rows) continue;
+            float v[VPL];
+            ldv<VPL>(tile + rt * LDT + VPL * sl, v);
+            if (SAVE) stv<VPL>(pre + (size_t)r * WIDTH + VPL * sl, v);
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) s += v[i];
+            const float mean = norm ? row_sum<LPR>(s) * invw : 0.f;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) { const float dl = v[i] - mean; q = __builtin_fmaf(dl, dl, q); }
+            const float rstd = norm ? rsqrtf(__builtin_fmaf(row_sum<LPR>(q), invw, eps)) : 1.f;
+            float ds[VPL];
+#pragma unroll
+            for (int i = 0; i < VPL; i += 2) {
+                if (drop_p > 0.f) lob_dropout_scale2(seed, (uint64_t)orow * WIDTH + sl * VPL + i, drop_p, ds[i], ds[i + 1]);
+                else { ds[i] = 1.f; ds[i + 1] = 1.f; }
+            }
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                const float o = __builtin_fmaf((v[i] - mean) * rstd, gm[i], bt[i]);
+                v[i] = apply_act(o, act) * ds[i];
+            }
+            stv<VPL>(out + (size_t)orow * WIDTH + sl * VPL, v);
+        }
+        __syncthreads();                       // the block is free for the next tile's windows
+    }
+}
+
 }  // namespace
 
 extern "C" int lob_dropout_f32(const float* in, float* out, int64_t n, float p, uint64_t seed, void* stream) {
@@ -2066,6 +2197,29 @@ extern "C" int lob_input_proj_ln_bf16(const float* x, int C, const float* W, int
     else
         hipLaunchKernelGGL((input_proj_ln_kernel<false>), dim3(nb), dim3(256), 0, (hipStream_t)stream, x, C, Cp, W, ldw, bias,
                            gamma, beta, pre, xbb, outb, rows, T, Bp, eps, act, drop_p, seed);
+    LOB_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int lob_input_proj_ln_f32(const float* x, int C, const float* W, int ldw, const float* bias, const float* gamma,
+                                    const float* beta, float* pre, float* out, int B, int T, int Bp, int H, float eps, int act,
+                                    float drop_p, uint64_t seed, void* stream) {
+    if (!x || !W || !out || B <= 0 || T <= 0 || Bp < B || C <= 0 || ldw < C) return LOB_E_ARG;
+    if (!(act & LOB_LN_IDENTITY) && (!gamma || !beta)) return LOB_E_ARG;
+    if (H != 128 || C > 64) return LOB_E_SHAPE;
+    if (drop_p < 0.f || drop_p >= 1.f) return LOB_E_ARG;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(pre) | reinterpret_cast<uintptr_t>(out) |
+         reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) return LOB_E_ALIGN;
+    const long rows = (long)B * T;
+    if (rows + 64 >= (1L << 31) || (long)T * Bp >= (1L << 31)) return LOB_E_SHAPE;       // 32-bit row arithmetic in the kernel
+    const long ntile = (rows + 63) / 64;
+    const int nb = (int)(ntile < 512 ? ntile : 512);                           // 2 workgroups of 4 waves per CU, persistent
+    if (pre)
+        hipLaunchKernelGGL((input_proj_ln_f32_kernel<true>), dim3(nb), dim3(256), 0, (hipStream_t)stream, x, C, W, ldw, bias,
+                           gamma, beta, pre, out, rows, T, Bp, eps, act, drop_p, seed);
+    else
+        hipLaunchKernelGGL((input_proj_ln_f32_kernel<false>), dim3(nb), dim3(256), 0, (hipStream_t)stream, x, C, W, ldw, bias,
+                           gamma, beta, pre, out, rows, T, Bp, eps, act, drop_p, seed);
     LOB_CHECK_LAUNCH();
     return 0;
 }

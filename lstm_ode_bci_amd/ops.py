@@ -424,6 +424,32 @@ def input_proj_ln(x2d, w, b, gamma, beta, B, T, Bp, H, act=ACT_NONE, eps=1e-5, d
     return a, pre, xb
 
 
+#: fp32 path, H == 128: input_proj (Linear + LayerNorm + GELU + dropout) in ONE kernel; tests switch it off to compare
+FUSE_INPUT_PROJ_F32 = True
+
+
+def input_proj_f32_ok(x2d, H, C, w):
+    return (bool(FUSE_INPUT_PROJ_F32) and H == 128 and 0 < C <= 64 and x2d.dtype == torch.float32 and x2d.is_contiguous()
+            and x2d.data_ptr() % 16 == 0 and w.stride(1) == 1)
+
+
+def input_proj_ln_f32(x2d, w, b, gamma, beta, B, T, Bp, H, act=ACT_NONE, eps=1e-5, drop_p=0.0, seed=0, save=False):
+    """fp32 twin of input_proj_ln: x2d fp32 [B*T, C] rows (b,t) -> fp32 activations [T*Bp, H] time-major (+ the fp32
+    pre-activations [B*T, H] with save).  Returns (a, pre | None)."""
+    _chk(x2d, "x"); _chk(w, "w"); _chk(b, "b"); _chk(gamma, "gamma"); _chk(beta, "beta")
+    rows, Cc = x2d.shape
+    assert rows == B * T and w.shape == (H, Cc)
+    if gamma is None:
+        act = act | LN_IDENTITY
+    dev = x2d.device
+    a = (torch.zeros if Bp != B else torch.empty)((T * Bp, H), device=dev, dtype=torch.float32)
+    pre = torch.empty((rows, H), device=dev, dtype=torch.float32) if save else None
+    rc = _lib.lib().lob_input_proj_ln_f32(_ptr(x2d), Cc, _ptr(w), w.stride(0), _ptr(b), _ptr(gamma), _ptr(beta), _ptr(pre),
+                                          _ptr(a), B, T, Bp, H, eps, act, float(drop_p), C.c_uint64(seed), _stream())
+    _lib.check(rc, "lob_input_proj_ln_f32")
+    return a, pre
+
+
 def dropout(x, p, seed, out=None):
     _chk(x, "x")
     if out is None:

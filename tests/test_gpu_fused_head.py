@@ -206,3 +206,39 @@ def test_model_gradients_do_not_change_with_the_fused_head_backward(dev):
     with torch.autocast("cuda", dtype=torch.bfloat16):
         m(xg).float().square().sum().backward()
     assert xg.grad is not None and torch.isfinite(xg.grad).all() and xg.grad.abs().max().item() > 0
+
+
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 5), (40, 7), (8, 256), (70, 33), (128, 64)])
+@pytest.mark.parametrize("save", [False, True])
+@pytest.mark.parametrize("drop", [0.0, 0.4])
+def test_fp32_fused_head_vs_gemm_plus_layernorm(dev, B, T, save, drop):
+    """lob_input_proj_ln_f32 (round 4): the fp32 path's input projection (Linear + LayerNorm + GELU + dropout, 04:173-178) in one
+    launch, against lob_gemm_nt_f32 + lob_layernorm_act_f32(remap, dropout) under the same seed: the pre-activations (exact fp32
+    products both ways) and the activations to fp32 summation order of the 61-term dot products, padding rows untouched, the
+    dropout mask in the same places."""
+    from lstm_ode_bci_amd import ops
+    H, C = 128, 61
+    Bp = ops.ceil32(B)
+    g = torch.Generator(device=dev).manual_seed(B * 1000 + T)
+    x2d = torch.randn((B * T, C), generator=g, device=dev) * 3.0
+    w = torch.randn((H, C), generator=g, device=dev) * 0.2
+    b = torch.randn((H,), generator=g, device=dev) * 0.1
+    gam = torch.rand((H,), generator=g, device=dev) + 0.5
+    bet = torch.randn((H,), generator=g, device=dev) * 0.1
+    assert ops.input_proj_f32_ok(x2d, H, C, w)
+    a, pre = ops.input_proj_ln_f32(x2d, w, b, gam, bet, B, T, Bp, H, act=ops.ACT_GELU, drop_p=drop, seed=99, save=save)
+    prer = ops.gemm_nt(x2d, w, b)
+    ar = ops.layernorm_act(prer, gam, bet, act=ops.ACT_GELU, remap=(T, B, Bp), drop_p=drop, seed=99)
+    assert a.shape == ar.shape and a.dtype == torch.float32
+    assert (pre is not None) == save
+    if save:
+        assert (pre - prer).abs().max().item() <= 2e-6 * max(1.0, prer.abs().max().item())
+    assert torch.equal(a == 0, ar == 0) or drop == 0.0              # the same elements dropped
+    assert (a - ar).abs().max().item() <= 1e-5 * max(1.0, ar.abs().max().item())
+    ref = torch.nn.functional.gelu(torch.nn.functional.layer_norm(x2d.double() @ w.double().t() + b.double(), (H,),
+                                                                  gam.double(), bet.double(), 1e-5))
+    if drop == 0.0:
+        got = a.reshape(T, Bp, H)[:, :B].permute(1, 0, 2).reshape(B * T, H)
+        assert (got.double() - ref).abs().max().item() < 5e-6 * max(1.0, ref.abs().max().item())
+    pad = a.reshape(T, Bp, H)[:, B:]
+    assert pad.numel() == 0 or float(pad.abs().max()) == 0.0
