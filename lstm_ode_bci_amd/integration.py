@@ -8,7 +8,10 @@ kernel launch over all windows.
 """
 from __future__ import annotations
 
+import ctypes
 import os
+import threading
+import weakref
 
 import numpy as np
 import torch
@@ -27,6 +30,50 @@ def _stamp(label):
     if _probe is not None:
         import time
         _probe.append((label, time.perf_counter()))
+
+
+class _ResultPool:
+    """Pages of returned trajectory arrays that the caller has let go of, kept for the next call.
+
+    `predict_batch` returns fresh host arrays like the reference (06:396-406); at 300 points the trajectories are 7.2 KB per
+    window, i.e. 88 MB per 3 x 4096 windows.  As plain `np.empty` that is 22 k page faults on first touch in the call and an
+    munmap of as many pages when the caller drops the result: 0.6 ms per chunk + ~4 ms per call, a tenth of a call that the GPU
+    spends idle (tools/api_probe.py).  Here the memory of a result returns to a small pool when -- and only when -- the last
+    array referring to it is gone: the returned array is a view (`np.frombuffer`) of a ctypes owner object laid over the pooled
+    storage; every slice / reshape the caller takes has that same base chain, so the owner dies only with the LAST view, and
+    its finalizer puts the storage back.  Arrays from different calls never share memory while any of them is alive."""
+    MIN_BYTES = 4 << 20          # smaller results: plain np.empty
+    MAX_HELD = 1 << 30           # bytes parked in the pool at most
+
+    def __init__(self):
+        self._free = {}
+        self._held = 0
+        self._lock = threading.Lock()
+
+    def empty(self, shape, dtype):
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape)) * dtype.itemsize
+        if nbytes < self.MIN_BYTES:
+            return np.empty(shape, dtype)
+        with self._lock:
+            lst = self._free.get(nbytes)
+            store = lst.pop() if lst else None
+            if store is not None:
+                self._held -= nbytes
+        if store is None:
+            store = np.empty(nbytes, np.uint8)
+        owner = (ctypes.c_char * nbytes).from_buffer(store)
+        weakref.finalize(owner, self._give_back, store)
+        return np.frombuffer(owner, dtype=dtype).reshape(shape)
+
+    def _give_back(self, store):
+        with self._lock:
+            if self._held + store.nbytes <= self.MAX_HELD:
+                self._free.setdefault(store.nbytes, []).append(store)
+                self._held += store.nbytes
+
+
+_RESULTS = _ResultPool()
 
 
 def _copy_pool():
@@ -307,7 +354,7 @@ class LSTMODEIntegration:
         self.lstm_model.eval()
         dev = self._device()
         steps = int(forecast_steps)
-        traj = np.empty((n, steps, 3), dtype=np.float64)
+        traj = _RESULTS.empty((n, steps, 3), np.float64)
         probs = np.empty((n, 2), dtype=np.float32)
         pred = np.empty((n,), dtype=np.int64)
         nb = min(chunk, n)

@@ -356,3 +356,46 @@ def test_chunk_schedule_of_host_array_calls():
         n, c, r = rnd.randint(1, 70000), rnd.choice([512, 1000, 4096, 8192]), rnd.choice([0, 256, 1024, 5000])
         s = cs(n, c, r)
         assert sum(s) == n and all(0 < x <= c for x in s), (n, c, r, s)
+
+
+def test_result_pool_recycles_memory_only_after_the_last_view_is_gone():
+    """integration._ResultPool (round 4): the trajectories `predict_batch` returns are views of pooled storage; the storage may
+    go back to the pool only when the array AND every slice / reshape taken from it are gone, and two live results never
+    share memory."""
+    import gc
+    import numpy as np
+    from lstm_ode_bci_amd.integration import _ResultPool
+    pool = _ResultPool()
+    small = pool.empty((10, 3), np.float64)
+    assert small.flags.owndata                      # below MIN_BYTES: a plain array
+    shape = (4096, 300, 3)
+    a = pool.empty(shape, np.float64)
+    assert a.shape == shape and a.dtype == np.float64 and a.flags.writeable and a.flags.aligned and a.flags.c_contiguous
+    a[:] = 1.0
+    addr = a.ctypes.data
+    b = pool.empty(shape, np.float64)               # a is alive: other memory
+    assert b.ctypes.data != addr
+    b[:] = 2.0
+    assert float(a[5, 7, 1]) == 1.0
+    view = a[100:200, ::2]                          # what a caller may keep
+    flat = a.reshape(-1)
+    del a
+    gc.collect()
+    c = pool.empty(shape, np.float64)               # views alive: a's memory must NOT come back
+    assert c.ctypes.data != addr
+    c[:] = 3.0
+    assert float(view[0, 0, 0]) == 1.0 and float(flat[-1]) == 1.0
+    del view
+    gc.collect()
+    assert pool._held == 0
+    del flat
+    gc.collect()
+    assert pool._held == int(np.prod(shape)) * 8    # the last view is gone: parked
+    d = pool.empty(shape, np.float64)
+    assert d.ctypes.data == addr and pool._held == 0
+    assert float(b[0, 0, 0]) == 2.0 and float(c[0, 0, 0]) == 3.0
+    # never more than MAX_HELD parked
+    pool.MAX_HELD = 0
+    del d
+    gc.collect()
+    assert pool._held == 0 and not any(pool._free.values())
