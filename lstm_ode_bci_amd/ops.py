@@ -138,6 +138,7 @@ def gemm_nt(a, w, bias=None, act=ACT_NONE, out=None, accumulate=False, mixed=Fal
     assert w.shape[1] == K
     if out_bf16 and not (a_bf16 and w_bf16):
         raise _lib.LobError("gemm_nt: out_bf16 needs bf16 operands (the LDS-DMA kernel's epilogue)")
+    caller_out = out is not None
     if out is None:
         out = torch.empty((M, N), device=a.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
     _chk(out, "out", torch.bfloat16 if out_bf16 else torch.float32)
@@ -159,7 +160,8 @@ def gemm_nt(a, w, bias=None, act=ACT_NONE, out=None, accumulate=False, mixed=Fal
     rc = _lib.lib().lob_gemm_nt_f32(_ptr(a), K, _ptr(w), K, _ptr(bias), _ptr(out), N, M, N, K, act, _stream())
     _lib.check(rc, "lob_gemm_nt_f32")
     if drop_p > 0:        # the exact-fp32 kernel has no mask epilogue: the same mask as a pass of its own (element row * N + col)
-        return dropout(out, drop_p, seed)
+        masked = dropout(out, drop_p, seed)
+        return out.copy_(masked) if caller_out else masked
     return out
 
 
