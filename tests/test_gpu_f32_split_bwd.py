@@ -198,6 +198,22 @@ def test_fp32_inter_layer_dropout_fused_into_producer_and_dx_epilogue_is_the_sam
     m.eval()
     with torch.no_grad():
         assert not torch.equal(m(torch.from_numpy(x).to(dev)), o1)
+    if B == 64:
+        # a forward that fused the dropout followed by a backward on the EXACT kernels (the variant flipped in between): the dX
+        # GEMM there has no mask epilogue, ops.gemm_nt applies the same mask as a pass of its own
+        from lstm_ode_bci_amd import _lib
+        m.train()
+        torch.manual_seed(77)
+        m._seed_counter = 0
+        m.zero_grad(set_to_none=True)
+        xg = torch.from_numpy(x).to(dev).requires_grad_(True)
+        loss = torch.nn.functional.cross_entropy(m(xg), torch.from_numpy(y).to(dev))
+        with _lib.variant(F32_SPLIT=0):
+            loss.backward()
+        gx = {**{k: p.grad.clone() for k, p in m.named_parameters()}, "x": xg.grad.clone()}
+        for k in g0:
+            mx = g0[k].abs().max().item()
+            assert (gx[k] - g0[k]).abs().max().item() <= 3e-5 * mx + 1e-9, k
 
 
 @pytest.mark.parametrize("T,Bp,D,save", [(20, 1024, 2, False), (7, 96, 2, True), (33, 32, 1, True), (256, 1024, 2, True)])
