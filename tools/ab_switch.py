@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Same-box A/B of a host-side switch of ops.py on the bench's own workloads: python tools/ab_switch.py FUSE_INPUT_PROJ
-[--hidden 128] [--mode train|fwd] [--precision mixed|fp32].  Alternates the two settings three times (12 + 4 steps each)."""
+[--hidden 128] [--mode train|fwd|coupled] [--precision mixed|fp32] [--batch 4096] [--off-first].  Alternates the two settings three
+times (12 + 4 steps each); --off-first starts with the switch off (whatever runs first in a process may carry one-time costs)."""
 import argparse
 import os
 import sys
